@@ -1,0 +1,56 @@
+"""Shared helpers for the golden fixtures (tests/golden/*)."""
+import bz2
+import hashlib
+import json
+import os
+import tarfile
+
+import oracle_lib as L
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def md5(b):
+    return hashlib.md5(b).hexdigest()
+
+
+def load(name):
+    return json.load(open(os.path.join(GOLD, name)))
+
+
+def gen(kind, n, seed):
+    """Seeded inputs; same definitions as tests/golden/make_golden.py::gen."""
+    if kind == "rand":
+        return L.gen_rand(n, seed)
+    if kind == "text":
+        return L.gen_text(n, seed)
+    if kind == "zero":
+        return bytes(n)
+    if kind == "ab":
+        return (b"ab" * (n // 2 + 1))[:n]
+    if kind == "runs":
+        r = L.gen_rand(n // 4 + 1, seed)
+        out = bytearray()
+        prev = -1
+        for b in r:
+            if b == prev:
+                b = (b + 1) & 255
+            out += bytes([b]) * 4
+            prev = b
+        return bytes(out[:n])
+    raise ValueError(kind)
+
+
+_suite_cache = None
+
+
+def suite_inputs():
+    """dict name -> raw bytes of the reference's compress-test corpora."""
+    global _suite_cache
+    if _suite_cache is None:
+        d = {}
+        with tarfile.open(os.path.join(GOLD, "suite_inputs.tar")) as tf:
+            for m in tf.getmembers():
+                d[m.name] = bz2.decompress(tf.extractfile(m).read())
+        _suite_cache = d
+    return _suite_cache
