@@ -1,0 +1,121 @@
+/*
+ * lbzip2_amd.h -- C ABI of the MI355X-native bzip2 block-compression core.
+ *
+ * Two faces of the same engine (lbzip2_amd/csrc, hand-written HIP for gfx950):
+ *
+ * (A) THE DROP-IN WORK-UNIT INTERFACE.  Exactly the functions lbzip2's pipeline
+ *     (src/compress.c:89-94, 113, 220-223) calls, with the signatures and semantics of the
+ *     reference's src/encode.h:22-38, so that compress.c/process.c can be linked against this
+ *     library instead of encode.o + divbwt.o + crctab.o and drive GPU blocks instead of
+ *     pthread CPU blocks:
+ *
+ *       encoder_alloc_size()  <- encode.h:29 / encode.c:108-114
+ *       encoder_init()        <- encode.h:30 / encode.c:117-132
+ *       collect()             <- encode.h:31 / encode.c:135-336
+ *       encode()              <- encode.h:32 / encode.c:427-545
+ *       transmit()            <- encode.h:33 / encode.c:1152-1281
+ *       combine_crc()         <- encode.h:38
+ *
+ *     The same entry points are also exported with an lbzamd_ prefix for hosts that cannot
+ *     afford such generic symbol names (ctypes, cgo, JNI).
+ *
+ * (B) THE BATCH INTERFACE.  One call compresses a whole buffer: the slab split of
+ *     process.c:631, the work-unit loop of compress.c:73-118, the in-order mux and CRC fold of
+ *     compress.c:238-250 and the header/trailer of compress.c:291-321 all run on the device,
+ *     hundreds of blocks in flight, one bzip2 block per workgroup.
+ *
+ * All functions are thread-safe on distinct contexts / encoder states.  There is no CPU
+ * fallback: if no HIP device is usable every entry point fails (batch: negative return;
+ * drop-in: message on stderr + abort(), the reference's own convention for fatal errors,
+ * main.c:59-84).
+ */
+#ifndef LBZIP2_AMD_H
+#define LBZIP2_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ------------------------------------------------------------------ (A) drop-in */
+#define CLUSTER_FACTOR  8u          /* encode.h:22 */
+#define HEADER_SIZE     4u          /* encode.h:23 */
+#define TRAILER_SIZE    10u         /* encode.h:24 */
+
+struct encoder_state;               /* opaque, caller-allocated: malloc(encoder_alloc_size(mbs)) */
+
+size_t encoder_alloc_size(unsigned long mbs);
+void   encoder_init(struct encoder_state *e, unsigned long mbs, unsigned cf);
+/* Consumes a prefix of buf[0..*buf_sz) into the block (RLE1 + CRC); *buf_sz = bytes left
+ * unconsumed.  Returns 1 if the block filled up before the input ran out.              */
+int    collect(struct encoder_state *e, const uint8_t *buf, size_t *buf_sz);
+/* Runs BWT, MTF/ZRLE and prefix-code selection; returns the exact compressed size in bytes
+ * and the block's un-inverted CRC through *crc.                                          */
+size_t encode(struct encoder_state *e, uint32_t *crc);
+/* Writes the compressed block (size rounded up to a multiple of 4 bytes) to buf, or to an
+ * internal buffer if buf == NULL; returns the buffer.                                    */
+void  *transmit(struct encoder_state *e, void *buf);
+
+#define combine_crc(cc, c) (((cc) << 1) ^ ((cc) >> 31) ^ (c) ^ -1)   /* encode.h:38 */
+
+size_t lbzamd_encoder_alloc_size(unsigned long mbs);
+void   lbzamd_encoder_init(struct encoder_state *e, unsigned long mbs, unsigned cf);
+int    lbzamd_collect(struct encoder_state *e, const uint8_t *buf, size_t *buf_sz);
+size_t lbzamd_encode(struct encoder_state *e, uint32_t *crc);
+void  *lbzamd_transmit(struct encoder_state *e, void *buf);
+/* Give back the device resources of a state that will not reach transmit(). */
+void   lbzamd_encoder_abandon(struct encoder_state *e);
+
+/* ------------------------------------------------------------------ (B) batch */
+typedef struct lbzamd_ctx lbzamd_ctx;
+
+typedef struct lbzamd_stats {
+  uint64_t n_in;        /* input bytes */
+  uint64_t n_rle;       /* sum of block lengths after RLE1 */
+  uint64_t n_mtf;       /* sum of MTF/ZRLE symbols */
+  uint64_t n_out;       /* stream bytes */
+  uint64_t sort_elems;  /* elements passed through the radix sorter (all rounds) */
+  uint32_t nblocks;
+  uint32_t nperiodic;   /* exactly periodic blocks (origin pointer = smallest equal row) */
+  float ms_collect, ms_bwt, ms_mtf, ms_encode, ms_finish, ms_total;  /* device time, HIP events */
+} lbzamd_stats;
+
+/* device < 0: current device.  max_slabs: slabs resident at once (input beyond that is
+ * streamed through in chunks).  nslots: concurrently resident BWT workgroups (0 = one per CU). */
+int  lbzamd_create(lbzamd_ctx **ctx, int device, unsigned bs100k, unsigned max_slabs, unsigned nslots);
+void lbzamd_destroy(lbzamd_ctx *ctx);
+const char *lbzamd_last_error(void);
+
+/* d_in/d_out are device pointers.  Writes a complete .bz2 stream; *out_len = its size.
+ * Work is enqueued on the context's stream and waited for.  0 on success.              */
+int  lbzamd_compress_device(lbzamd_ctx *ctx, const void *d_in, size_t len,
+                            void *d_out, size_t out_cap, size_t *out_len);
+/* Same with host buffers (H2D + compress + D2H). */
+int  lbzamd_compress_host(lbzamd_ctx *ctx, const uint8_t *in, size_t len,
+                          uint8_t *out, size_t out_cap, size_t *out_len);
+/* Upper bound of the stream size for len input bytes. */
+size_t lbzamd_bound(size_t len);
+int  lbzamd_get_stats(lbzamd_ctx *ctx, lbzamd_stats *st);
+/* The HIP stream (hipStream_t) all kernels of this context are launched on. */
+void *lbzamd_stream(lbzamd_ctx *ctx);
+
+/* ---- stage access for parity tests (valid for the last chunk of the last call) ---- */
+typedef struct lbzamd_block_info {
+  uint32_t n, crc, consumed, bwt_idx, periodic, nmtf, alpha, num_trees, num_sel, out_len, err, rounds;
+  uint8_t inuse[256];
+} lbzamd_block_info;
+enum { LBZAMD_STAGE_RLE = 0, LBZAMD_STAGE_BWT = 1, LBZAMD_STAGE_MTFV = 2, LBZAMD_STAGE_OUT = 3 };
+uint32_t lbzamd_block_slots(lbzamd_ctx *ctx);           /* 2 * slabs of the last chunk */
+int  lbzamd_block_info_get(lbzamd_ctx *ctx, uint32_t blk, lbzamd_block_info *info);
+/* Copies a stage's bytes of block blk to host dst (cap bytes); returns bytes copied or <0.
+ * RLE is only valid before the MTF stage ran: use lbzamd_run_stages() to stop early.    */
+long lbzamd_read_stage(lbzamd_ctx *ctx, uint32_t blk, int stage, void *dst, size_t cap);
+/* Run only stages [0, upto] (0 collect, 1 bwt, 2 mtf, 3 encode) of one chunk of host input. */
+int  lbzamd_run_stages(lbzamd_ctx *ctx, const uint8_t *in, size_t len, int upto);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,265 @@
+"""ctypes binding of the C ABI declared in include/lbzip2_amd.h.
+
+Host-side mirror of the reference's work-unit interface (src/encode.h:22-38) and of its
+compression pipeline (src/compress.c): same names, same argument meaning, same error
+behaviour (the hot-path functions cannot fail; fatal problems abort, as lbzip2's fail() does).
+No codec arithmetic happens in Python: every byte of the stream comes from the HIP kernels.
+"""
+import ctypes as C
+import os
+
+HEADER_SIZE = 4       # encode.h:23
+TRAILER_SIZE = 10     # encode.h:24
+CLUSTER_FACTOR = 8    # encode.h:22
+
+STAGE_RLE, STAGE_BWT, STAGE_MTFV, STAGE_OUT = 0, 1, 2, 3
+
+EXPORTS = [
+    "encoder_alloc_size", "encoder_init", "collect", "encode", "transmit",
+    "lbzamd_encoder_alloc_size", "lbzamd_encoder_init", "lbzamd_collect", "lbzamd_encode",
+    "lbzamd_transmit", "lbzamd_encoder_abandon",
+    "lbzamd_create", "lbzamd_destroy", "lbzamd_last_error", "lbzamd_compress_device",
+    "lbzamd_compress_host", "lbzamd_bound", "lbzamd_get_stats", "lbzamd_stream",
+    "lbzamd_block_slots", "lbzamd_block_info_get", "lbzamd_read_stage", "lbzamd_run_stages",
+]
+
+
+def combine_crc(cc, c):
+    """encode.h:38 -- cc' = rotl32(cc, 1) ^ ~c on 32-bit values."""
+    return (((cc << 1) | (cc >> 31)) ^ c ^ 0xFFFFFFFF) & 0xFFFFFFFF
+
+
+class Stats(C.Structure):
+    _fields_ = [("n_in", C.c_uint64), ("n_rle", C.c_uint64), ("n_mtf", C.c_uint64),
+                ("n_out", C.c_uint64), ("sort_elems", C.c_uint64),
+                ("nblocks", C.c_uint32), ("nperiodic", C.c_uint32),
+                ("ms_collect", C.c_float), ("ms_bwt", C.c_float), ("ms_mtf", C.c_float),
+                ("ms_encode", C.c_float), ("ms_finish", C.c_float), ("ms_total", C.c_float)]
+
+
+class BlockInfo(C.Structure):
+    _fields_ = [(n, C.c_uint32) for n in ("n", "crc", "consumed", "bwt_idx", "periodic", "nmtf",
+                                           "alpha", "num_trees", "num_sel", "out_len", "err",
+                                           "rounds")] + [("inuse", C.c_uint8 * 256)]
+
+
+class LbzError(RuntimeError):
+    pass
+
+
+class Library:
+    """One loaded build of the C ABI."""
+
+    def __init__(self, path):
+        if not os.path.exists(path):
+            raise LbzError(
+                f"{path} not found: the HIP extension is not built "
+                "(run `python -c 'import __graft_entry__ as g; g.build()'` or "
+                "`make -C lbzip2_amd/csrc`). There is no CPU fallback.")
+        self.path = path
+        lib = C.CDLL(path)
+        self.lib = lib
+        vp, sz, u32p = C.c_void_p, C.c_size_t, C.POINTER(C.c_uint32)
+        szp = C.POINTER(C.c_size_t)
+        for pre in ("", "lbzamd_"):
+            getattr(lib, pre + "encoder_alloc_size").argtypes = [C.c_ulong]
+            getattr(lib, pre + "encoder_alloc_size").restype = sz
+            getattr(lib, pre + "encoder_init").argtypes = [vp, C.c_ulong, C.c_uint]
+            getattr(lib, pre + "encoder_init").restype = None
+            getattr(lib, pre + "collect").argtypes = [vp, vp, szp]
+            getattr(lib, pre + "collect").restype = C.c_int
+            getattr(lib, pre + "encode").argtypes = [vp, u32p]
+            getattr(lib, pre + "encode").restype = sz
+            getattr(lib, pre + "transmit").argtypes = [vp, vp]
+            getattr(lib, pre + "transmit").restype = vp
+        lib.lbzamd_encoder_abandon.argtypes = [vp]
+        lib.lbzamd_encoder_abandon.restype = None
+        lib.lbzamd_create.argtypes = [C.POINTER(vp), C.c_int, C.c_uint, C.c_uint, C.c_uint]
+        lib.lbzamd_create.restype = C.c_int
+        lib.lbzamd_destroy.argtypes = [vp]
+        lib.lbzamd_destroy.restype = None
+        lib.lbzamd_last_error.restype = C.c_char_p
+        lib.lbzamd_compress_device.argtypes = [vp, vp, sz, vp, sz, szp]
+        lib.lbzamd_compress_device.restype = C.c_int
+        lib.lbzamd_compress_host.argtypes = [vp, vp, sz, vp, sz, szp]
+        lib.lbzamd_compress_host.restype = C.c_int
+        lib.lbzamd_bound.argtypes = [sz]
+        lib.lbzamd_bound.restype = sz
+        lib.lbzamd_get_stats.argtypes = [vp, C.POINTER(Stats)]
+        lib.lbzamd_get_stats.restype = C.c_int
+        lib.lbzamd_stream.argtypes = [vp]
+        lib.lbzamd_stream.restype = vp
+        lib.lbzamd_block_slots.argtypes = [vp]
+        lib.lbzamd_block_slots.restype = C.c_uint32
+        lib.lbzamd_block_info_get.argtypes = [vp, C.c_uint32, C.POINTER(BlockInfo)]
+        lib.lbzamd_block_info_get.restype = C.c_int
+        lib.lbzamd_read_stage.argtypes = [vp, C.c_uint32, C.c_int, vp, sz]
+        lib.lbzamd_read_stage.restype = C.c_long
+        lib.lbzamd_run_stages.argtypes = [vp, vp, sz, C.c_int]
+        lib.lbzamd_run_stages.restype = C.c_int
+
+    def error(self):
+        return (self.lib.lbzamd_last_error() or b"").decode()
+
+    def bound(self, n):
+        return self.lib.lbzamd_bound(n)
+
+    def context(self, level=9, max_slabs=64, nslots=0, device=-1):
+        return Context(self, level, max_slabs, nslots, device)
+
+    def encoder(self, max_block_size):
+        return Encoder(self, max_block_size)
+
+    # ---- whole-stream helpers -------------------------------------------------
+    def compress(self, data, level=9, max_slabs=None):
+        """bytes -> .bz2 bytes through the batch interface."""
+        M = level * 100000
+        if max_slabs is None:
+            max_slabs = max(1, min(1200, (len(data) + M - 1) // M))
+        with self.context(level, max_slabs) as ctx:
+            return ctx.compress(data)
+
+    def compress_workunits(self, data, level=9):
+        """bytes -> .bz2 bytes through the drop-in work-unit interface, reproducing the call
+        sequence of the reference's compress.c (slab split process.c:631, do_collect :73-118,
+        do_transmit :210-228, do_reorder :238-250, header/trailer :291-321)."""
+        M = level * 100000
+        out = bytearray(b"BZh" + bytes([0x30 + level]))
+        combined = 0
+        for off in range(0, len(data), M):
+            slab = data[off:off + M]
+            pos = 0
+            while pos < len(slab):
+                enc = self.encoder(M)
+                pos += enc.collect(slab[pos:])
+                size, crc = enc.encode()
+                out += enc.transmit()[:size]
+                combined = combine_crc(combined, crc)
+        out += bytes([0x17, 0x72, 0x45, 0x38, 0x50, 0x90]) + combined.to_bytes(4, "big")
+        return bytes(out)
+
+
+class Context:
+    """Batch interface: a device context holding max_slabs resident slabs."""
+
+    def __init__(self, library, level=9, max_slabs=64, nslots=0, device=-1):
+        self.L = library
+        self.level = level
+        self.h = C.c_void_p()
+        if library.lib.lbzamd_create(C.byref(self.h), device, level, max_slabs, nslots):
+            raise LbzError("lbzamd_create: " + library.error())
+
+    def close(self):
+        if self.h:
+            self.L.lib.lbzamd_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def compress(self, data):
+        cap = self.L.bound(len(data))
+        out = C.create_string_buffer(cap)
+        n = C.c_size_t()
+        buf = (C.c_char * len(data)).from_buffer_copy(data) if len(data) else None
+        if self.L.lib.lbzamd_compress_host(self.h, buf, len(data), out, cap, C.byref(n)):
+            raise LbzError("lbzamd_compress_host: " + self.L.error())
+        return out.raw[:n.value]
+
+    def compress_device(self, d_in, length, d_out, out_cap):
+        """d_in/d_out: integer device addresses (e.g. torch tensor .data_ptr())."""
+        n = C.c_size_t()
+        if self.L.lib.lbzamd_compress_device(self.h, C.c_void_p(d_in), length, C.c_void_p(d_out),
+                                             out_cap, C.byref(n)):
+            raise LbzError("lbzamd_compress_device: " + self.L.error())
+        return n.value
+
+    def stats(self):
+        s = Stats()
+        self.L.lib.lbzamd_get_stats(self.h, C.byref(s))
+        return s
+
+    @property
+    def stream(self):
+        return self.L.lib.lbzamd_stream(self.h)
+
+    # ---- stage access (parity tests) ----
+    def run_stages(self, data, upto=3):
+        buf = (C.c_char * len(data)).from_buffer_copy(data)
+        if self.L.lib.lbzamd_run_stages(self.h, buf, len(data), upto):
+            raise LbzError("lbzamd_run_stages: " + self.L.error())
+
+    def block_slots(self):
+        return self.L.lib.lbzamd_block_slots(self.h)
+
+    def block_info(self, blk):
+        bi = BlockInfo()
+        if self.L.lib.lbzamd_block_info_get(self.h, blk, C.byref(bi)):
+            raise LbzError("lbzamd_block_info_get: " + self.L.error())
+        return bi
+
+    def read_stage(self, blk, stage, cap):
+        buf = C.create_string_buffer(max(cap, 1))
+        n = self.L.lib.lbzamd_read_stage(self.h, blk, stage, buf, cap)
+        if n < 0:
+            raise LbzError("lbzamd_read_stage: " + self.L.error())
+        return buf.raw[:n]
+
+    def blocks(self, data, upto=3):
+        """Per-block stage records of one chunk of input (list of dicts, stream order)."""
+        self.run_stages(data, upto)
+        out = []
+        for blk in range(self.block_slots()):
+            bi = self.block_info(blk)
+            if bi.n == 0:
+                continue
+            rec = dict(blk=blk, nblock=bi.n, crc=bi.crc, consumed=bi.consumed, inuse=bytes(bi.inuse),
+                       block=self.read_stage(blk, STAGE_RLE, bi.n), err=bi.err)
+            if upto >= 1:
+                rec.update(bwt=self.read_stage(blk, STAGE_BWT, bi.n), bwt_idx=bi.bwt_idx,
+                           periodic=bool(bi.periodic), rounds=bi.rounds)
+            if upto >= 2:
+                rec.update(nmtf=bi.nmtf, alpha=bi.alpha,
+                           mtfv=self.read_stage(blk, STAGE_MTFV, 2 * bi.nmtf))
+            if upto >= 3:
+                rec.update(num_trees=bi.num_trees, num_selectors=bi.num_sel, out_len=bi.out_len,
+                           out=self.read_stage(blk, STAGE_OUT, bi.out_len))
+            out.append(rec)
+        return out
+
+
+class Encoder:
+    """The reference's work unit (encode.h:27-33): caller-allocated opaque state."""
+
+    def __init__(self, library, max_block_size, cluster_factor=CLUSTER_FACTOR):
+        self.L = library
+        self.mbs = max_block_size
+        self.state = C.create_string_buffer(library.lib.encoder_alloc_size(max_block_size))
+        library.lib.encoder_init(self.state, max_block_size, cluster_factor)
+        self.size = 0
+
+    def collect(self, buf):
+        """Returns the number of bytes consumed from buf."""
+        left = C.c_size_t(len(buf))
+        b = (C.c_char * len(buf)).from_buffer_copy(buf)
+        self.L.lib.collect(self.state, b, C.byref(left))
+        return len(buf) - left.value
+
+    def encode(self):
+        crc = C.c_uint32()
+        self.size = self.L.lib.encode(self.state, C.byref(crc))
+        return self.size, crc.value
+
+    def transmit(self):
+        buf = C.create_string_buffer((self.size + 3) // 4 * 4)
+        self.L.lib.transmit(self.state, buf)
+        return buf.raw

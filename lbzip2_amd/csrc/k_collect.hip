@@ -1,0 +1,228 @@
+/*
+ * k_collect.hip -- stage 1 of the block compressor: initial run-length coding (RLE1),
+ * block cutting, used-byte map and CRC-32, one workgroup per input slab.
+ *
+ * Replaces collect() (reference src/encode.c:135-336) plus the closing of an open run in
+ * encode() (encode.c:443-447) and the slab re-queue loop of do_collect()
+ * (compress.c:93-104).  The reference is a byte-serial state machine; here every input
+ * position decides locally what it emits:
+ *
+ *   rs(p)  = start of the maximal run containing p (never before the block's first byte)
+ *   kk     = (p - rs(p)) mod 259                  position inside its <=259-byte run chunk
+ *   emits  = 1 byte  if kk < 3,   2 bytes (byte + count) if kk == 3,   nothing otherwise
+ *   count  = min(255, equal bytes following p inside the slab)
+ *
+ * rs() is a workgroup max-scan of run-head positions, output offsets an add-scan of
+ * `emits`.  The block is cut at the first position whose output would pass the block
+ * capacity M (this reproduces encode.c:162-221 incl. the "never separate the 4th run byte
+ * from its count" rule, :218); the rest of the slab becomes the slab's spill block, with
+ * run positions restarted at the cut.  CRC-32 (poly 0x04C11DB7, MSB first, crctab.c) is
+ * computed per thread over equal chunks and folded with x^(8*len) multiplications.
+ *
+ * Memory: reads the slab once (16 B per lane, coalesced), writes <= 1.25 bytes per input
+ * byte; algorithmic traffic N_in + N_rle.
+ */
+#include "lbz_kernels.h"
+
+#define COL_IPT 16u
+#define COL_TILE (LBZ_WG * COL_IPT)
+#define CRC_POLY 0x04C11DB7u
+
+struct collect_lds {
+  wg_scratch sc;
+  u32 crc_tab[256];
+  u32 part[LBZ_WG];
+  u32 inuse[256];
+  u32 bc[4];
+};
+
+__device__ __forceinline__ u32 crc_mulmod(u32 a, u32 b)
+{
+  u32 r = 0;
+  for (int i = 31; i >= 0; i--) {
+    r = (r << 1) ^ ((r >> 31) ? CRC_POLY : 0u);
+    if ((b >> i) & 1u) r ^= a;
+  }
+  return r;
+}
+
+__device__ __forceinline__ u32 crc_xpow(u32 nbits)     /* x^nbits mod P */
+{
+  u32 r = 1u, b = 2u;
+  while (nbits) {
+    if (nbits & 1u) r = crc_mulmod(r, b);
+    b = crc_mulmod(b, b);
+    nbits >>= 1;
+  }
+  return r;
+}
+
+/* CRC (init 0xFFFFFFFF, no final inversion) of x[a..b).  All threads must call. */
+__device__ u32 wg_crc32(const u8 *x, u32 a, u32 b, collect_lds *S)
+{
+  const u32 tid = threadIdx.x;
+  const u32 len = b - a;
+  const u32 C = (len + LBZ_WG - 1) / LBZ_WG;            /* bytes per thread */
+  const u32 padn = C * LBZ_WG - len;                    /* virtual leading zero bytes */
+  u32 crc = 0;
+  {
+    u32 v0 = tid * C, v1 = v0 + C;
+    if (v1 > padn) {
+      u32 p = a + (v0 > padn ? v0 - padn : 0u);
+      const u32 pe = a + (v1 - padn);
+      for (; p < pe; p++) crc = (crc << 8) ^ S->crc_tab[(crc >> 24) ^ x[p]];
+    }
+  }
+  S->part[tid] = crc;
+  u32 xp = crc_xpow(8u * C);
+  __syncthreads();
+  for (u32 stride = 1; stride < LBZ_WG; stride <<= 1) {
+    if ((tid & (2u * stride - 1u)) == 0u)
+      S->part[tid] = crc_mulmod(S->part[tid], xp) ^ S->part[tid + stride];
+    xp = crc_mulmod(xp, xp);
+    __syncthreads();
+  }
+  u32 r = S->part[0] ^ crc_mulmod(0xFFFFFFFFu, crc_xpow(8u * len));
+  __syncthreads();
+  return r;
+}
+
+/* Tokenise x[base..end) into out[] (capacity cap).  Returns via S->bc: [0] = bytes written,
+ * [1] = first unconsumed position (== end if everything fitted).                        */
+__device__ void collect_pass(const u8 *x, u32 base, u32 end, u32 cap, u8 *out, collect_lds *S)
+{
+  const u32 tid = threadIdx.x;
+  const bool vec_ok = ((uintptr_t)x & 15u) == 0u;
+  u32 carry_rs = 0;        /* (run start of the last byte seen) + 1; 0 = none yet */
+  u32 o_base = 0;
+  u32 cut = end;
+
+  for (u32 t0 = base & ~(COL_TILE - 1u); t0 < end; t0 += COL_TILE) {
+    const u32 p0 = t0 + tid * COL_IPT;
+    u8 b[COL_IPT];
+    if (vec_ok && p0 + COL_IPT <= end) {
+      const uint4 q = *reinterpret_cast<const uint4 *>(x + p0);
+      const u32 wq[4] = { q.x, q.y, q.z, q.w };
+#pragma unroll
+      for (u32 i = 0; i < COL_IPT; i++) b[i] = (u8)(wq[i >> 2] >> (8u * (i & 3u)));
+    } else {
+#pragma unroll
+      for (u32 i = 0; i < COL_IPT; i++) b[i] = (p0 + i < end) ? x[p0 + i] : (u8)0;
+    }
+    const u8 prevb = (p0 > base && p0 <= end) ? x[p0 - 1] : (u8)0;
+
+    /* run heads and the start of the run each position belongs to */
+    u32 headmask = 0, lh = 0;
+#pragma unroll
+    for (u32 i = 0; i < COL_IPT; i++) {
+      const u32 p = p0 + i;
+      const bool act = p >= base && p < end;
+      const bool head = act && (p == base || b[i] != (i ? b[i - 1] : prevb));
+      if (head) { headmask |= 1u << i; lh = p + 1u; }
+    }
+    u32 emax, eadd_unused, tmax, tadd_unused;
+    wg_excl_max_add(lh, 0u, &emax, &eadd_unused, &tmax, &tadd_unused, &S->sc);
+    u32 rs = emax > carry_rs ? emax : carry_rs;
+
+    u32 emit2 = 0;             /* 2 bits per position: bytes emitted */
+    u8 cnt[COL_IPT];
+    u32 nout = 0;
+#pragma unroll
+    for (u32 i = 0; i < COL_IPT; i++) {
+      const u32 p = p0 + i;
+      const bool act = p >= base && p < end;
+      cnt[i] = 0;
+      if (headmask & (1u << i)) rs = p + 1u;
+      if (act) {
+        const u32 kk = (p - (rs - 1u)) % LBZ_RUN_CAP;
+        u32 e = kk < 3u ? 1u : (kk == 3u ? 2u : 0u);
+        if (kk == 3u) {
+          u32 c = 0;
+          while (c < 255u && p + 1u + c < end && x[p + 1u + c] == b[i]) c++;
+          cnt[i] = (u8)c;
+        }
+        emit2 |= e << (2u * i);
+        nout += e;
+      }
+    }
+    u32 ttot;
+    u32 o = o_base + wg_excl_add(nout, &ttot, &S->sc);
+
+    u32 limit = end;           /* positions >= limit are not consumed */
+    if (o_base + ttot > cap) { /* the block fills inside this tile: find the cut */
+      u32 cand = 0xFFFFFFFFu, oo = o, at = 0;
+#pragma unroll
+      for (u32 i = 0; i < COL_IPT; i++) {
+        const u32 e = (emit2 >> (2u * i)) & 3u;
+        if (cand == 0xFFFFFFFFu && e && oo + e > cap) { cand = p0 + i; at = oo; }
+        oo += e;
+      }
+      limit = wg_min(cand, &S->sc);
+      if (cand == limit) S->bc[0] = at;
+      __syncthreads();
+      cut = limit;
+    }
+
+    u32 oo = o;
+#pragma unroll
+    for (u32 i = 0; i < COL_IPT; i++) {
+      const u32 e = (emit2 >> (2u * i)) & 3u;
+      if (e && p0 + i < limit) {
+        out[oo] = b[i];
+        S->inuse[b[i]] = 1u;
+        if (e == 2u) { out[oo + 1u] = cnt[i]; S->inuse[cnt[i]] = 1u; }
+      }
+      oo += e;
+    }
+    if (cut != end) break;
+    o_base += ttot;
+    carry_rs = tmax > carry_rs ? tmax : carry_rs;
+  }
+  __syncthreads();
+  if (tid == 0) {
+    if (cut == end) S->bc[0] = o_base;
+    S->bc[1] = cut;
+  }
+  __syncthreads();
+}
+
+__global__ void __launch_bounds__(LBZ_WG)
+k_collect(const u8 *in, u64 in_len, lbz_layout L, u8 *Tbase, lbz_block_meta *meta)
+{
+  __shared__ collect_lds S;
+  const u32 tid = threadIdx.x;
+  const u32 slab = blockIdx.x;
+  const u8 *x = in + (u64)slab * L.M;
+  const u64 left = in_len - (u64)slab * L.M;
+  const u32 len = left < L.M ? (u32)left : L.M;
+
+  if (tid < 256) {
+    u32 c = tid << 24;
+    for (int k = 0; k < 8; k++) c = (c & 0x80000000u) ? (c << 1) ^ CRC_POLY : (c << 1);
+    S.crc_tab[tid] = c;
+  }
+
+  u32 base = 0;
+  for (u32 part = 0; part < 2; part++) {
+    const u32 blk = 2u * slab + part;
+    lbz_block_meta *m = &meta[blk];
+    if (base >= len) {                       /* no spill block */
+      if (tid == 0) { m->n = 0; m->consumed = 0; m->out_len = 0; m->err = 0; m->nmtf = 0; }
+      continue;
+    }
+    if (tid < 256) S.inuse[tid] = 0;
+    __syncthreads();
+    collect_pass(x, base, len, part ? L.cap_b : L.M, Tbase + lbz_elem_off(L, blk), &S);
+    const u32 nblock = S.bc[0], stop = S.bc[1];
+    __syncthreads();
+    const u32 crc = wg_crc32(x, base, stop, &S);
+    if (tid < 256) m->inuse[tid] = (u8)S.inuse[tid];
+    if (tid == 0) {
+      m->n = nblock; m->crc = crc; m->consumed = stop - base;
+      m->err = (part && stop != len) ? 1u : 0u;
+      m->out_len = 0; m->nmtf = 0; m->periodic = 0; m->bwt_idx = 0;
+    }
+    base = stop;
+    __syncthreads();
+  }
+}

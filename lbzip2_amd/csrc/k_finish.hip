@@ -1,0 +1,77 @@
+/*
+ * k_finish.hip -- stream assembly on the device: block offsets, the stream CRC fold and the
+ * gather of the byte-aligned blocks into one contiguous .bz2 stream.
+ *
+ * Replaces, for the batch path, do_reorder()/write_header()/write_trailer() of the
+ * reference's src/compress.c:238-250, 291-321 and the combine_crc macro (encode.h:38):
+ * the stream is  "BZh"+level | blocks in slab order | 0x177245385090 | combined CRC.
+ * Every block is a whole number of bytes (encode.c:514-525), so assembly is a prefix sum of
+ * block sizes plus a copy.  The fold  cc' = rotl(cc,1) ^ ~crc  is order dependent and tiny:
+ * one lane walks the blocks.
+ */
+#include "lbz_kernels.h"
+
+
+/* one workgroup; offs[b] = absolute stream offset of block b of this chunk */
+__global__ void __launch_bounds__(LBZ_WG)
+k_offsets(const lbz_block_meta *meta, u32 nblk, u32 bs100k, u32 first, u32 last,
+          u64 *offs, lbz_stream_state *st, u8 *out, u64 out_cap)
+{
+  if (threadIdx.x != 0) return;
+  u64 pos = st->pos;
+  u32 cc = st->crc;
+  if (first) {
+    pos = 0; cc = 0;
+    st->nblocks = 0; st->n_rle = 0; st->n_mtf = 0; st->sort_elems = 0; st->nperiodic = 0; st->err = 0;
+    if (out_cap >= 4) { out[0] = 'B'; out[1] = 'Z'; out[2] = 'h'; out[3] = (u8)('0' + bs100k); }
+    pos = 4;
+  }
+  for (u32 b = 0; b < nblk; b++) {
+    const lbz_block_meta *m = &meta[b];
+    offs[b] = pos;
+    if (m->n == 0u) continue;
+    if (m->err) st->err = m->err;
+    pos += m->out_len;
+    cc = ((cc << 1) | (cc >> 31)) ^ ~m->crc;
+    st->nblocks++;
+    st->n_rle += m->n;
+    st->n_mtf += m->nmtf;
+    st->sort_elems += m->sort_elems;
+    st->nperiodic += m->periodic;
+  }
+  if (pos + (last ? 10u : 0u) > out_cap) { st->err = 100u; st->pos = pos; st->crc = cc; return; }
+  if (last) {
+    const u8 tr[6] = { 0x17, 0x72, 0x45, 0x38, 0x50, 0x90 };
+    for (u32 i = 0; i < 6; i++) out[pos + i] = tr[i];
+    out[pos + 6] = (u8)(cc >> 24); out[pos + 7] = (u8)(cc >> 16);
+    out[pos + 8] = (u8)(cc >> 8);  out[pos + 9] = (u8)cc;
+    pos += 10;
+  }
+  st->pos = pos;
+  st->crc = cc;
+}
+
+/* one workgroup per block: byte copy into the (arbitrarily aligned) stream position */
+__global__ void __launch_bounds__(LBZ_WG)
+k_gather(const u8 *Obase, const lbz_block_meta *meta, lbz_layout L, const u64 *offs,
+         const lbz_stream_state *st, u8 *out)
+{
+  const u32 blk = blockIdx.x;
+  const lbz_block_meta *m = &meta[blk];
+  if (m->n == 0u || st->err) return;
+  const u8 *src = Obase + lbz_out_off(L, blk);
+  u8 *dst = out + offs[blk];
+  const u32 len = m->out_len;
+  /* dword stores where dst is aligned; src is always 4-byte aligned */
+  const u32 head = (u32)((4u - ((uintptr_t)dst & 3u)) & 3u);
+  const u32 h = head < len ? head : len;
+  if (threadIdx.x < h) dst[threadIdx.x] = src[threadIdx.x];
+  const u32 nw = (len - h) >> 2;
+  u32 *d32 = reinterpret_cast<u32 *>(dst + h);
+  for (u32 i = threadIdx.x; i < nw; i += LBZ_WG) {
+    const u8 *s = src + h + 4u * i;
+    d32[i] = (u32)s[0] | ((u32)s[1] << 8) | ((u32)s[2] << 16) | ((u32)s[3] << 24);
+  }
+  const u32 done = h + 4u * nw;
+  if (threadIdx.x < len - done) dst[done + threadIdx.x] = src[done + threadIdx.x];
+}

@@ -1,0 +1,191 @@
+/*
+ * k_mtf.hip -- stage 3: move-to-front ranks, zero-run (RUNA/RUNB) coding and the symbol
+ * histogram of one block, one block per workgroup.
+ *
+ * Replaces make_map_e() and do_mtf() (reference src/encode.c:340-355, 360-425).  The
+ * reference walks a 255-entry list per byte; here the MTF rank of a symbol is computed as
+ *
+ *     rank(i) = #{ symbols s' : last occurrence of s' before i  >  last occurrence of c_i }
+ *
+ * with never-seen symbols ordered by their index (virtual positions -1-s).  Each wave owns
+ * one contiguous slice of the BWT string; its 64 lanes hold the 256 "last seen at" positions
+ * (4 per lane), a rank is 4 ballots + popcounts, and only run heads (c_i != c_{i-1}) need
+ * one -- every other position has rank 0.  The slices' start states come from a per-slice
+ * "last occurrence" table (LDS atomicMax) chained over the 16 slices.
+ *
+ * Zero runs: a maximal run of k rank-0 positions becomes the bijective base-2 digits of k
+ * (encode.c:381-386); non-zero rank r becomes symbol r+1; EOB closes the block.  Output
+ * offsets are a workgroup add-scan over positions, after a max-scan that tells each
+ * non-zero position where the previous one was.
+ *
+ * Traffic: reads N_rle bytes twice (+1 B/pos of rank scratch), writes 2 B per MTF symbol.
+ */
+#include "lbz_kernels.h"
+
+#define MTF_IPT 16u
+#define MTF_TILE (LBZ_WG * MTF_IPT)
+
+struct mtf_lds {
+  wg_scratch sc;
+  int last[LBZ_NW][256];       /* per-slice last occurrence, then slice start state */
+  u32 hist[LBZ_MAX_ALPHA + 2];
+  u8 cmap[256];
+  u32 bc[4];
+};
+
+__device__ __forceinline__ u32 zrun_digits(u32 z)          /* floor(log2(z+1)) */
+{
+  return 31u - (u32)__clz(z + 1u);
+}
+
+__global__ void __launch_bounds__(LBZ_WG)
+k_mtf(const u8 *Bbase, u8 *Rbase, u16 *Vbase, u32 *freq_out, lbz_block_meta *meta, lbz_layout L)
+{
+  __shared__ mtf_lds S;
+  const u32 tid = threadIdx.x, lane = lane_id(), w = wave_id();
+  const u32 blk = blockIdx.x;
+  lbz_block_meta *M = &meta[blk];
+  const u32 n = M->n;
+  if (n == 0u) return;
+  const size_t off = lbz_elem_off(L, blk);
+  const u8 *bwt = Bbase + off;
+  u8 *rk = Rbase + off;
+  u16 *mtfv = Vbase + off;               /* room for n + 1 + 50 symbols (cap >= M + 64) */
+
+  /* dense symbol numbering of the used bytes (encode.c:340-355) */
+  u32 tot_inuse;
+  {
+    const u32 f = (tid < 256u && M->inuse[tid]) ? 1u : 0u;
+    const u32 ex = wg_excl_add(f, &tot_inuse, &S.sc);
+    if (tid < 256u) S.cmap[tid] = (u8)ex;
+  }
+  const u32 eob = tot_inuse + 1u;
+  for (u32 i = tid; i < LBZ_NW * 256u; i += LBZ_WG) (&S.last[0][0])[i] = -1;
+  for (u32 i = tid; i < LBZ_MAX_ALPHA + 2u; i += LBZ_WG) S.hist[i] = 0;
+  __syncthreads();
+
+  /* slices: one per wave, multiples of 64 positions */
+  const u32 cs = (((n + LBZ_NW - 1u) / LBZ_NW) + 63u) & ~63u;
+  const u32 lo = w * cs < n ? w * cs : n;
+  const u32 hi = lo + cs < n ? lo + cs : n;
+
+  for (u32 b0 = lo; b0 < hi; b0 += 64u) {
+    const u32 p = b0 + lane;
+    if (p < hi) atomicMax(&S.last[w][S.cmap[bwt[p]]], (int)p);
+  }
+  __syncthreads();
+  if (tid < 256u) {
+    int run = -1 - (int)tid;
+#pragma unroll
+    for (u32 w2 = 0; w2 < LBZ_NW; w2++) {
+      const int t = S.last[w2][tid];
+      S.last[w2][tid] = run;
+      if (t >= 0) run = t;
+    }
+  }
+  __syncthreads();
+
+  /* ranks at run heads, wave-serial over heads */
+  {
+    int L0 = S.last[w][lane], L1 = S.last[w][lane + 64u];
+    int L2 = S.last[w][lane + 128u], L3 = S.last[w][lane + 192u];
+    for (u32 b0 = lo; b0 < hi; b0 += 64u) {
+      const u32 p = b0 + lane;
+      const bool ok = p < hi;
+      const int c = ok ? (int)S.cmap[bwt[p]] : 0;
+      const int cprev = (ok && p > 0u) ? (int)S.cmap[bwt[p - 1u]] : -1;
+      u64 heads = __ballot(ok && c != cprev);
+      u32 myrank = 0;
+      while (heads) {
+        const u32 l = (u32)__ffsll((long long)heads) - 1u;
+        heads &= heads - 1ull;
+        const int s = __shfl(c, (int)l);
+        const u32 q = (u32)s >> 6, owner = (u32)s & 63u;
+        const int mine = q == 0u ? L0 : q == 1u ? L1 : q == 2u ? L2 : L3;
+        const int pv = __shfl(mine, (int)owner);
+        const u32 cnt = (u32)__popcll(__ballot(L0 > pv)) + (u32)__popcll(__ballot(L1 > pv))
+                      + (u32)__popcll(__ballot(L2 > pv)) + (u32)__popcll(__ballot(L3 > pv));
+        if (lane == l) myrank = cnt;
+        if (lane == owner) {
+          const int np = (int)(b0 + l);
+          if (q == 0u) L0 = np; else if (q == 1u) L1 = np; else if (q == 2u) L2 = np; else L3 = np;
+        }
+      }
+      if (ok) rk[p] = (u8)myrank;
+    }
+  }
+  __syncthreads();
+
+  /* zero-run coding + histogram */
+  u32 carry_nz = 0;        /* (position of the last non-zero rank) + 1 */
+  u32 o_base = 0;
+  for (u32 t0 = 0; t0 < n; t0 += MTF_TILE) {
+    const u32 p0 = t0 + tid * MTF_IPT;
+    u8 r[MTF_IPT];
+    if (p0 + MTF_IPT <= n && ((uintptr_t)(rk + p0) & 15u) == 0u) {
+      const uint4 qv = *reinterpret_cast<const uint4 *>(rk + p0);
+      const u32 wq[4] = { qv.x, qv.y, qv.z, qv.w };
+#pragma unroll
+      for (u32 i = 0; i < MTF_IPT; i++) r[i] = (u8)(wq[i >> 2] >> (8u * (i & 3u)));
+    } else {
+#pragma unroll
+      for (u32 i = 0; i < MTF_IPT; i++) r[i] = (p0 + i < n) ? rk[p0 + i] : (u8)0;
+    }
+    u32 lastnz = 0;
+#pragma unroll
+    for (u32 i = 0; i < MTF_IPT; i++) if (r[i]) lastnz = p0 + i + 1u;
+    u32 enz, d0, tnz, d1;
+    wg_excl_max_add(lastnz, 0u, &enz, &d0, &tnz, &d1, &S.sc);
+    u32 prev1 = enz > carry_nz ? enz : carry_nz;
+    const u32 prev1_start = prev1;
+    u32 nout = 0;
+#pragma unroll
+    for (u32 i = 0; i < MTF_IPT; i++) {
+      if (r[i]) {
+        const u32 z = p0 + i - prev1;
+        nout += (z ? zrun_digits(z) : 0u) + 1u;
+        prev1 = p0 + i + 1u;
+      }
+    }
+    u32 ttot;
+    u32 o = o_base + wg_excl_add(nout, &ttot, &S.sc);
+    prev1 = prev1_start;
+#pragma unroll
+    for (u32 i = 0; i < MTF_IPT; i++) {
+      if (r[i]) {
+        u32 z = p0 + i - prev1;
+        while (z) {
+          const u32 d = (z - 1u) & 1u;
+          mtfv[o++] = (u16)d;
+          atomicAdd(&S.hist[d], 1u);
+          z = (z - 1u) >> 1;
+        }
+        mtfv[o++] = (u16)(r[i] + 1u);
+        atomicAdd(&S.hist[r[i] + 1u], 1u);
+        prev1 = p0 + i + 1u;
+      }
+    }
+    o_base += ttot;
+    carry_nz = tnz > carry_nz ? tnz : carry_nz;
+  }
+  __syncthreads();
+  if (tid == 0) {
+    u32 o = o_base;
+    u32 z = n - carry_nz;                        /* trailing zero run */
+    while (z) {
+      const u32 d = (z - 1u) & 1u;
+      mtfv[o++] = (u16)d;
+      S.hist[d]++;
+      z = (z - 1u) >> 1;
+    }
+    mtfv[o++] = (u16)eob;
+    S.hist[eob]++;
+    const u32 nm = o;
+    const u32 padded = (nm + LBZ_GROUP - 1u) / LBZ_GROUP * LBZ_GROUP;
+    for (; o < padded; o++) mtfv[o] = (u16)(eob + 1u);      /* dummy symbol, encode.c:1034-1035 */
+    M->nmtf = nm;
+    M->alpha = eob + 1u;
+  }
+  __syncthreads();
+  for (u32 i = tid; i < LBZ_MAX_ALPHA + 2u; i += LBZ_WG) freq_out[(size_t)blk * 260u + i] = S.hist[i];
+}

@@ -1,0 +1,441 @@
+/*
+ * lbz_api.hip -- host runtime and C ABI (include/lbzip2_amd.h) of the MI355X block
+ * compressor: device buffers laid out per block (lbz_common.h), one HIP stream per
+ * context, HIP events around every kernel, chunked streaming for inputs larger than the
+ * resident capacity, and the drop-in encode.h work-unit functions on top of a pool of
+ * one-slab contexts.
+ *
+ * Mirrors the call sequence of the reference's src/compress.c (work units :73-118,
+ * transmit :210-228, reorder + CRC fold :238-250, header/trailer :291-321); nothing here
+ * computes any part of the codec on the CPU.
+ */
+#include <hip/hip_runtime.h>
+
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "../../include/lbzip2_amd.h"
+#include "lbz_kernels.h"
+
+static thread_local std::string g_err;
+static int fail_msg(const char *what, hipError_t e)
+{
+  char buf[256];
+  snprintf(buf, sizeof buf, "%s: %s", what, hipGetErrorString(e));
+  g_err = buf;
+  return -1;
+}
+#define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) return fail_msg(#x, e_); } while (0)
+
+extern "C" const char *lbzamd_last_error(void) { return g_err.c_str(); }
+
+static inline uint32_t round_up(uint32_t v, uint32_t a) { return (v + a - 1u) / a * a; }
+
+struct lbzamd_ctx {
+  int device = 0;
+  unsigned bs100k = 9;
+  lbz_layout L{};
+  uint32_t max_slabs = 0, nslots = 0;
+  uint64_t slot_bytes = 0;
+  hipStream_t stream = nullptr;
+  hipEvent_t ev[8] = {};
+  /* device */
+  u8 *T = nullptr, *B = nullptr, *R = nullptr, *O = nullptr, *ws = nullptr;
+  u16 *V = nullptr;
+  u32 *freq = nullptr, *queue = nullptr;
+  u64 *offs = nullptr;
+  lbz_block_meta *meta = nullptr;
+  lbz_stream_state *st = nullptr;
+  u8 *d_in = nullptr, *d_out = nullptr;      /* staging for the host-buffer path */
+  size_t d_in_cap = 0, d_out_cap = 0;
+  /* host */
+  std::vector<lbz_block_meta> h_meta;
+  uint32_t last_nslabs = 0;
+  lbzamd_stats stats{};
+};
+
+static int ctx_free(lbzamd_ctx *c)
+{
+  if (!c) return 0;
+  hipFree(c->T); hipFree(c->B); hipFree(c->R); hipFree(c->O); hipFree(c->ws); hipFree(c->V);
+  hipFree(c->freq); hipFree(c->queue); hipFree(c->offs); hipFree(c->meta); hipFree(c->st);
+  hipFree(c->d_in); hipFree(c->d_out);
+  for (auto &e : c->ev) if (e) hipEventDestroy(e);
+  if (c->stream) hipStreamDestroy(c->stream);
+  delete c;
+  return 0;
+}
+
+extern "C" void lbzamd_destroy(lbzamd_ctx *c) { ctx_free(c); }
+
+extern "C" int lbzamd_create(lbzamd_ctx **out, int device, unsigned bs100k, unsigned max_slabs, unsigned nslots)
+{
+  if (!out || bs100k < 1 || bs100k > 9 || max_slabs < 1) { g_err = "lbzamd_create: bad argument"; return -1; }
+  int ndev = 0;
+  HIPCHK(hipGetDeviceCount(&ndev));
+  if (ndev < 1) { g_err = "lbzamd_create: no HIP device (this library has no CPU path)"; return -1; }
+  if (device < 0) HIPCHK(hipGetDevice(&device));
+  HIPCHK(hipSetDevice(device));
+  hipDeviceProp_t prop;
+  HIPCHK(hipGetDeviceProperties(&prop, device));
+
+  lbzamd_ctx *c = new lbzamd_ctx;
+  c->device = device;
+  c->bs100k = bs100k;
+  c->max_slabs = max_slabs;
+  const uint32_t M = bs100k * 100000u;
+  c->L.M = M;
+  c->L.cap_a = round_up(M + 64u, 256u);
+  c->L.cap_b = round_up(M / 4u + 128u, 256u);
+  c->L.out_a = round_up(M + M / 8u + 4096u, 256u);
+  c->L.out_b = round_up(c->L.cap_b + c->L.cap_b / 8u + 4096u, 256u);
+  if (nslots == 0) {
+    const char *env = getenv("LBZAMD_SLOTS");
+    nslots = env ? (unsigned)atoi(env) : (unsigned)prop.multiProcessorCount;
+    if (nslots == 0) nslots = 1;
+  }
+  if (nslots > 2u * max_slabs) nslots = 2u * max_slabs;
+  c->nslots = nslots;
+  c->slot_bytes = (LBZ_BWT_SLOT_BYTES(c->L.cap_a) + 255u) & ~(uint64_t)255u;
+
+  const size_t elems = (size_t)max_slabs * ((size_t)c->L.cap_a + c->L.cap_b);
+  const size_t outb = (size_t)max_slabs * ((size_t)c->L.out_a + c->L.out_b);
+  const size_t nblk = 2u * (size_t)max_slabs;
+#define ALLOC(p, bytes) do { hipError_t e_ = hipMalloc((void **)&(p), (bytes)); \
+    if (e_ != hipSuccess) { ctx_free(c); return fail_msg("hipMalloc " #p, e_); } } while (0)
+  ALLOC(c->T, elems);
+  ALLOC(c->B, elems);
+  ALLOC(c->R, elems);
+  ALLOC(c->V, elems * 2u);
+  ALLOC(c->O, outb);
+  ALLOC(c->ws, (size_t)nslots * c->slot_bytes);
+  ALLOC(c->freq, nblk * 260u * sizeof(u32));
+  ALLOC(c->queue, 256);
+  ALLOC(c->offs, nblk * sizeof(u64));
+  ALLOC(c->meta, nblk * sizeof(lbz_block_meta));
+  ALLOC(c->st, sizeof(lbz_stream_state));
+#undef ALLOC
+  hipError_t e = hipStreamCreate(&c->stream);
+  if (e != hipSuccess) { ctx_free(c); return fail_msg("hipStreamCreate", e); }
+  for (auto &ev : c->ev) {
+    e = hipEventCreate(&ev);
+    if (e != hipSuccess) { ctx_free(c); return fail_msg("hipEventCreate", e); }
+  }
+  c->h_meta.resize(nblk);
+  *out = c;
+  return 0;
+}
+
+extern "C" size_t lbzamd_bound(size_t len)
+{
+  return len + len / 8u + 8192u + (len / 100000u + 2u) * 64u;
+}
+
+extern "C" void *lbzamd_stream(lbzamd_ctx *c) { return (void *)c->stream; }
+
+/* Enqueue stages [0, upto] for one chunk of nsl slabs already resident at d_in. */
+static int run_chunk(lbzamd_ctx *c, const u8 *d_in, size_t len, uint32_t nsl, int upto, float ms[5])
+{
+  const uint32_t nblk = 2u * nsl;
+  hipStream_t s = c->stream;
+  HIPCHK(hipEventRecord(c->ev[0], s));
+  hipLaunchKernelGGL(k_collect, dim3(nsl), dim3(LBZ_WG), 0, s, d_in, (u64)len, c->L, c->T, c->meta);
+  HIPCHK(hipEventRecord(c->ev[1], s));
+  if (upto >= 1) {
+    HIPCHK(hipMemsetAsync(c->queue, 0, 256, s));
+    const uint32_t grid = c->nslots < nblk ? c->nslots : nblk;
+    hipLaunchKernelGGL(k_bwt, dim3(grid), dim3(LBZ_WG), 0, s, (const u8 *)c->T, c->B, c->meta, c->L,
+                       nsl, c->queue, c->ws, (u64)c->slot_bytes);
+  }
+  HIPCHK(hipEventRecord(c->ev[2], s));
+  if (upto >= 2)
+    hipLaunchKernelGGL(k_mtf, dim3(nblk), dim3(LBZ_WG), 0, s, (const u8 *)c->B, c->R, c->V, c->freq, c->meta, c->L);
+  HIPCHK(hipEventRecord(c->ev[3], s));
+  if (upto >= 3)
+    hipLaunchKernelGGL(k_encode, dim3(nblk), dim3(LBZ_WG), 0, s, (const u16 *)c->V, (const u32 *)c->freq, c->O, c->meta, c->L);
+  HIPCHK(hipEventRecord(c->ev[4], s));
+  HIPCHK(hipGetLastError());
+  (void)ms;
+  c->last_nslabs = nsl;
+  return 0;
+}
+
+static int add_times(lbzamd_ctx *c, int nev, float *acc)
+{
+  for (int i = 0; i + 1 < nev; i++) {
+    float t = 0;
+    HIPCHK(hipEventElapsedTime(&t, c->ev[i], c->ev[i + 1]));
+    acc[i] += t;
+  }
+  return 0;
+}
+
+extern "C" int lbzamd_compress_device(lbzamd_ctx *c, const void *d_in_v, size_t len,
+                                      void *d_out_v, size_t out_cap, size_t *out_len)
+{
+  if (!c || !d_out_v || !out_len || (len && !d_in_v)) { g_err = "lbzamd_compress_device: bad argument"; return -1; }
+  HIPCHK(hipSetDevice(c->device));
+  const u8 *d_in = (const u8 *)d_in_v;
+  u8 *d_out = (u8 *)d_out_v;
+  const uint32_t M = c->L.M;
+  const size_t nslabs = (len + M - 1u) / M;
+  float acc[6] = { 0, 0, 0, 0, 0, 0 };
+  hipStream_t s = c->stream;
+
+  size_t done = 0;
+  bool first = true;
+  do {
+    const size_t nsl = nslabs - done < c->max_slabs ? nslabs - done : c->max_slabs;
+    const bool last = done + nsl == nslabs;
+    const size_t off = done * (size_t)M;
+    const size_t clen = last ? len - off : nsl * (size_t)M;
+    if (nsl) {
+      if (run_chunk(c, d_in + off, clen, (uint32_t)nsl, 3, acc)) return -1;
+    } else {
+      HIPCHK(hipEventRecord(c->ev[0], s));
+      for (int i = 1; i <= 4; i++) HIPCHK(hipEventRecord(c->ev[i], s));
+    }
+    hipLaunchKernelGGL(k_offsets, dim3(1), dim3(64), 0, s, (const lbz_block_meta *)c->meta, (u32)(2u * nsl),
+                       (u32)c->bs100k, (u32)first, (u32)last, c->offs, c->st, d_out, (u64)out_cap);
+    if (nsl)
+      hipLaunchKernelGGL(k_gather, dim3((u32)(2u * nsl)), dim3(LBZ_WG), 0, s, (const u8 *)c->O,
+                         (const lbz_block_meta *)c->meta, c->L, (const u64 *)c->offs,
+                         (const lbz_stream_state *)c->st, d_out);
+    HIPCHK(hipEventRecord(c->ev[5], s));
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(s));
+    if (add_times(c, 6, acc)) return -1;
+    done += nsl;
+    first = false;
+  } while (done < nslabs);
+
+  lbz_stream_state st;
+  HIPCHK(hipMemcpy(&st, c->st, sizeof st, hipMemcpyDeviceToHost));
+  c->stats.n_in = len; c->stats.n_rle = st.n_rle; c->stats.n_mtf = st.n_mtf; c->stats.n_out = st.pos;
+  c->stats.sort_elems = st.sort_elems; c->stats.nblocks = st.nblocks; c->stats.nperiodic = st.nperiodic;
+  c->stats.ms_collect = acc[0]; c->stats.ms_bwt = acc[1]; c->stats.ms_mtf = acc[2];
+  c->stats.ms_encode = acc[3]; c->stats.ms_finish = acc[4];
+  c->stats.ms_total = acc[0] + acc[1] + acc[2] + acc[3] + acc[4];
+  if (st.err) {
+    char buf[96];
+    snprintf(buf, sizeof buf, "device pipeline error code %u%s", st.err, st.err == 100u ? " (output buffer too small)" : "");
+    g_err = buf;
+    return -2;
+  }
+  *out_len = (size_t)st.pos;
+  return 0;
+}
+
+static int ensure_staging(lbzamd_ctx *c, size_t in_bytes, size_t out_bytes)
+{
+  if (in_bytes > c->d_in_cap) {
+    hipFree(c->d_in); c->d_in = nullptr; c->d_in_cap = 0;
+    HIPCHK(hipMalloc((void **)&c->d_in, in_bytes + 256));
+    c->d_in_cap = in_bytes;
+  }
+  if (out_bytes > c->d_out_cap) {
+    hipFree(c->d_out); c->d_out = nullptr; c->d_out_cap = 0;
+    HIPCHK(hipMalloc((void **)&c->d_out, out_bytes + 256));
+    c->d_out_cap = out_bytes;
+  }
+  return 0;
+}
+
+extern "C" int lbzamd_compress_host(lbzamd_ctx *c, const uint8_t *in, size_t len,
+                                    uint8_t *out, size_t out_cap, size_t *out_len)
+{
+  if (!c || !out || !out_len || (len && !in)) { g_err = "lbzamd_compress_host: bad argument"; return -1; }
+  HIPCHK(hipSetDevice(c->device));
+  const size_t bound = lbzamd_bound(len);
+  if (ensure_staging(c, len ? len : 1, bound)) return -1;
+  if (len) HIPCHK(hipMemcpyAsync(c->d_in, in, len, hipMemcpyHostToDevice, c->stream));
+  size_t n = 0;
+  const int rc = lbzamd_compress_device(c, c->d_in, len, c->d_out, bound, &n);
+  if (rc) return rc;
+  if (n > out_cap) { g_err = "lbzamd_compress_host: output buffer too small"; return -2; }
+  HIPCHK(hipMemcpy(out, c->d_out, n, hipMemcpyDeviceToHost));
+  *out_len = n;
+  return 0;
+}
+
+extern "C" int lbzamd_get_stats(lbzamd_ctx *c, lbzamd_stats *st)
+{
+  if (!c || !st) return -1;
+  *st = c->stats;
+  return 0;
+}
+
+extern "C" int lbzamd_run_stages(lbzamd_ctx *c, const uint8_t *in, size_t len, int upto)
+{
+  if (!c || !in || !len) { g_err = "lbzamd_run_stages: bad argument"; return -1; }
+  HIPCHK(hipSetDevice(c->device));
+  const uint32_t M = c->L.M;
+  const size_t nsl = (len + M - 1u) / M;
+  if (nsl > c->max_slabs) { g_err = "lbzamd_run_stages: input exceeds one chunk"; return -1; }
+  if (ensure_staging(c, len, 0)) return -1;
+  HIPCHK(hipMemcpyAsync(c->d_in, in, len, hipMemcpyHostToDevice, c->stream));
+  float acc[6] = { 0 };
+  if (run_chunk(c, c->d_in, len, (uint32_t)nsl, upto, acc)) return -1;
+  HIPCHK(hipStreamSynchronize(c->stream));
+  return 0;
+}
+
+extern "C" uint32_t lbzamd_block_slots(lbzamd_ctx *c) { return c ? 2u * c->last_nslabs : 0u; }
+
+extern "C" int lbzamd_block_info_get(lbzamd_ctx *c, uint32_t blk, lbzamd_block_info *info)
+{
+  if (!c || !info || blk >= 2u * c->last_nslabs) { g_err = "lbzamd_block_info_get: bad argument"; return -1; }
+  HIPCHK(hipSetDevice(c->device));
+  lbz_block_meta m;
+  HIPCHK(hipMemcpy(&m, c->meta + blk, sizeof m, hipMemcpyDeviceToHost));
+  info->n = m.n; info->crc = m.crc; info->consumed = m.consumed; info->bwt_idx = m.bwt_idx;
+  info->periodic = m.periodic; info->nmtf = m.nmtf; info->alpha = m.alpha; info->num_trees = m.num_trees;
+  info->num_sel = m.num_sel; info->out_len = m.out_len; info->err = m.err; info->rounds = m.rounds;
+  memcpy(info->inuse, m.inuse, 256);
+  return 0;
+}
+
+extern "C" long lbzamd_read_stage(lbzamd_ctx *c, uint32_t blk, int stage, void *dst, size_t cap)
+{
+  if (!c || !dst || blk >= 2u * c->last_nslabs) { g_err = "lbzamd_read_stage: bad argument"; return -1; }
+  if (hipSetDevice(c->device) != hipSuccess) return -1;
+  lbz_block_meta m;
+  if (hipMemcpy(&m, c->meta + blk, sizeof m, hipMemcpyDeviceToHost) != hipSuccess) return -1;
+  const size_t eo = lbz_elem_off(c->L, blk);
+  const void *src = nullptr;
+  size_t bytes = 0;
+  switch (stage) {
+    case LBZAMD_STAGE_RLE:  src = c->T + eo; bytes = m.n; break;
+    case LBZAMD_STAGE_BWT:  src = c->B + eo; bytes = m.n; break;
+    case LBZAMD_STAGE_MTFV: src = c->V + eo; bytes = 2u * (size_t)m.nmtf; break;
+    case LBZAMD_STAGE_OUT:  src = c->O + lbz_out_off(c->L, blk); bytes = m.out_len; break;
+    default: g_err = "lbzamd_read_stage: bad stage"; return -1;
+  }
+  if (bytes > cap) { g_err = "lbzamd_read_stage: buffer too small"; return -1; }
+  if (bytes && hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost) != hipSuccess) return -1;
+  return (long)bytes;
+}
+
+/* ===================================================================== drop-in (A) */
+/* encoder_state as seen by the caller: an opaque blob it malloc'ed.  We keep a small header
+ * in it, the raw bytes collect() consumed are uploaded at once, and the compressed block is
+ * staged after the header for transmit(NULL).                                             */
+struct encoder_state {
+  uint32_t magic;
+  uint32_t mbs;
+  uint32_t cf;
+  uint32_t out_len;
+  uint32_t crc;
+  uint32_t collected;
+  lbzamd_ctx *ctx;            /* one-slab context leased from the pool */
+  uint32_t pad_[8];
+};
+#define ENC_MAGIC 0x6c627a41u
+
+static std::mutex g_pool_mu;
+static std::vector<lbzamd_ctx *> g_pool[10];
+
+[[noreturn]] static void die(const char *what)
+{
+  fprintf(stderr, "lbzip2_amd: fatal: %s: %s\n", what, g_err.c_str());
+  abort();
+}
+
+static lbzamd_ctx *lease(unsigned bs100k)
+{
+  {
+    std::lock_guard<std::mutex> lk(g_pool_mu);
+    auto &v = g_pool[bs100k];
+    if (!v.empty()) { lbzamd_ctx *c = v.back(); v.pop_back(); return c; }
+  }
+  lbzamd_ctx *c = nullptr;
+  if (lbzamd_create(&c, -1, bs100k, 1, 2)) die("cannot create a device context");
+  return c;
+}
+
+static void release(lbzamd_ctx *c)
+{
+  std::lock_guard<std::mutex> lk(g_pool_mu);
+  g_pool[c->bs100k].push_back(c);
+}
+
+extern "C" size_t lbzamd_encoder_alloc_size(unsigned long mbs)
+{
+  /* header + room for the compressed block (transmit(NULL)); cf. encode.c:108-114 */
+  return sizeof(encoder_state) + (size_t)mbs + mbs / 8u + 8192u;
+}
+
+extern "C" void lbzamd_encoder_init(encoder_state *e, unsigned long mbs, unsigned cf)
+{
+  if (!e || mbs == 0 || mbs > LBZ_MAX_BLOCK || mbs % 100000u || cf != LBZ_CLUSTER) {
+    g_err = "block size must be k*100000 (1<=k<=9) and cluster factor 8"; die("encoder_init");
+  }
+  memset(e, 0, sizeof *e);
+  e->magic = ENC_MAGIC; e->mbs = (uint32_t)mbs; e->cf = cf;
+}
+
+extern "C" int lbzamd_collect(encoder_state *e, const uint8_t *buf, size_t *buf_sz)
+{
+  if (!e || e->magic != ENC_MAGIC || !buf || !buf_sz) { g_err = "bad encoder state"; die("collect"); }
+  if (e->ctx) { g_err = "collect() called twice on one state (only the default, non -u mode is supported)"; die("collect"); }
+  const size_t avail = *buf_sz < e->mbs ? *buf_sz : e->mbs;
+  if (avail == 0) return 0;
+  lbzamd_ctx *c = lease(e->mbs / 100000u);
+  e->ctx = c;
+  if (lbzamd_run_stages(c, buf, avail, 0)) die("collect");
+  lbzamd_block_info bi;
+  if (lbzamd_block_info_get(c, 0, &bi)) die("collect");
+  e->collected = bi.consumed;
+  *buf_sz -= bi.consumed;
+  return bi.consumed < avail;
+}
+
+extern "C" size_t lbzamd_encode(encoder_state *e, uint32_t *crc)
+{
+  if (!e || e->magic != ENC_MAGIC || !e->ctx || !crc) { g_err = "encode() before collect()"; die("encode"); }
+  lbzamd_ctx *c = e->ctx;
+  hipStream_t s = c->stream;
+  /* the slab is resident and collected; run the remaining stages on its primary block only */
+  if (hipSetDevice(c->device) != hipSuccess) die("encode");
+  hipMemsetAsync(c->queue, 0, 256, s);
+  hipLaunchKernelGGL(k_bwt, dim3(1), dim3(LBZ_WG), 0, s, (const u8 *)c->T, c->B, c->meta, c->L, 1u, c->queue, c->ws, (u64)c->slot_bytes);
+  hipLaunchKernelGGL(k_mtf, dim3(1), dim3(LBZ_WG), 0, s, (const u8 *)c->B, c->R, c->V, c->freq, c->meta, c->L);
+  hipLaunchKernelGGL(k_encode, dim3(1), dim3(LBZ_WG), 0, s, (const u16 *)c->V, (const u32 *)c->freq, c->O, c->meta, c->L);
+  if (hipStreamSynchronize(s) != hipSuccess || hipGetLastError() != hipSuccess) { g_err = "kernel failure"; die("encode"); }
+  lbzamd_block_info bi;
+  if (lbzamd_block_info_get(c, 0, &bi) || bi.err) { g_err = "device pipeline error"; die("encode"); }
+  e->out_len = bi.out_len;
+  e->crc = bi.crc;
+  *crc = bi.crc;
+  return bi.out_len;
+}
+
+extern "C" void *lbzamd_transmit(encoder_state *e, void *buf)
+{
+  if (!e || e->magic != ENC_MAGIC || !e->ctx) { g_err = "transmit() before encode()"; die("transmit"); }
+  lbzamd_ctx *c = e->ctx;
+  if (!buf) buf = (void *)(e + 1);
+  const size_t bytes = ((size_t)e->out_len + 3u) / 4u * 4u;          /* whole words, compress.c:220 */
+  if (hipSetDevice(c->device) != hipSuccess ||
+      hipMemcpy(buf, c->O, bytes, hipMemcpyDeviceToHost) != hipSuccess) { g_err = "D2H failed"; die("transmit"); }
+  e->ctx = nullptr;
+  release(c);
+  return buf;
+}
+
+extern "C" void lbzamd_encoder_abandon(encoder_state *e)
+{
+  if (e && e->magic == ENC_MAGIC && e->ctx) { release(e->ctx); e->ctx = nullptr; }
+}
+
+/* the reference's own symbol names (encode.h:29-33) */
+extern "C" size_t encoder_alloc_size(unsigned long mbs) { return lbzamd_encoder_alloc_size(mbs); }
+extern "C" void encoder_init(encoder_state *e, unsigned long mbs, unsigned cf) { lbzamd_encoder_init(e, mbs, cf); }
+extern "C" int collect(encoder_state *e, const uint8_t *buf, size_t *buf_sz) { return lbzamd_collect(e, buf, buf_sz); }
+extern "C" size_t encode(encoder_state *e, uint32_t *crc) { return lbzamd_encode(e, crc); }
+extern "C" void *transmit(encoder_state *e, void *buf) { return lbzamd_transmit(e, buf); }

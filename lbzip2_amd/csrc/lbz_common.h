@@ -1,0 +1,85 @@
+/*
+ * lbz_common.h -- format constants and the HBM data layout shared by the host runtime
+ * and the gfx950 kernels.
+ *
+ * Scope: the per-block compressor of lbzip2's src/encode.c +
+ * src/divbwt.c.  One bzip2 block is owned by ONE workgroup in every kernel; a slab
+ * (bs100k*100000 input bytes, process.c:631) yields a primary block and, when RLE1
+ * expanded it, one small spill block (compress.c:98-104).
+ */
+#ifndef LBZ_COMMON_H
+#define LBZ_COMMON_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+/* bzip2 format constants (values of common.h:42-52, they ARE the format) */
+#define LBZ_MAX_ALPHA   258u
+#define LBZ_MAX_TREES   6u
+#define LBZ_GROUP       50u
+#define LBZ_MAX_CODELEN 20u
+#define LBZ_MAX_BLOCK   900000u
+#define LBZ_MAX_SEL     18002u       /* ceil(900001/50) + pad selector */
+#define LBZ_RUN_CAP     259u         /* 4 + 255, encode.c:105 */
+#define LBZ_CLUSTER     8u           /* EM iterations, encode.h:22 */
+
+/* workgroup geometry: 16 waves of 64 lanes on one CU */
+#ifndef LBZ_WG
+#define LBZ_WG 1024
+#endif
+#define LBZ_NW (LBZ_WG / 64)
+
+/* Per-block record in HBM.  Blocks are numbered 2*slab (primary) and 2*slab+1 (spill). */
+typedef struct lbz_block_meta {
+  uint32_t n;          /* RLE1'd length (nblock); 0 = block absent */
+  uint32_t crc;        /* running CRC of the consumed raw bytes, un-inverted (encode.c:542) */
+  uint32_t consumed;   /* raw bytes consumed */
+  uint32_t bwt_idx;    /* row of rotation 0 (smallest equal row if exactly periodic) */
+  uint32_t periodic;   /* 1 if rows were still tied at depth >= n (T = u^k) */
+  uint32_t nmtf;       /* MTF/ZRLE symbols incl. EOB */
+  uint32_t alpha;      /* alphabet size = EOB + 1 */
+  uint32_t num_trees;
+  uint32_t num_sel;    /* incl. pad selector */
+  uint32_t out_len;    /* bytes; every block is byte aligned (encode.c:514-525) */
+  uint32_t err;        /* non-zero: internal capacity problem */
+  uint32_t rounds;     /* prefix-doubling rounds run (diagnostic) */
+  uint32_t sort_elems; /* sum of elements passed through the radix sorter (diagnostic) */
+  uint32_t pad_[3];
+  uint8_t  inuse[256]; /* used-byte map (encode.c:63) */
+} lbz_block_meta;
+
+/* Arithmetic layout of the per-block arrays.  cap_a / cap_b are element capacities of a
+ * primary / spill block, rounded up so every block starts 256-byte aligned.           */
+typedef struct lbz_layout {
+  uint32_t M;          /* bs100k * 100000 */
+  uint32_t cap_a;      /* >= M + 64 */
+  uint32_t cap_b;      /* >= M/4 + 64: a spill holds at most ~0.25 M bytes */
+  uint32_t out_a;      /* bytes of compressed output reserved per primary block */
+  uint32_t out_b;
+} lbz_layout;
+
+#if defined(__cplusplus)
+static inline
+#if defined(__HIPCC__) || defined(LBZ_EMULATED)
+__host__ __device__
+#endif
+size_t lbz_elem_off(const lbz_layout L, uint32_t blk)
+{
+  return (size_t)(blk >> 1) * ((size_t)L.cap_a + L.cap_b) + ((blk & 1u) ? L.cap_a : 0u);
+}
+static inline
+#if defined(__HIPCC__) || defined(LBZ_EMULATED)
+__host__ __device__
+#endif
+size_t lbz_out_off(const lbz_layout L, uint32_t blk)
+{
+  return (size_t)(blk >> 1) * ((size_t)L.out_a + L.out_b) + ((blk & 1u) ? L.out_a : 0u);
+}
+#endif
+
+/* BWT workspace of one resident workgroup ("slot"), elements of capacity cap_a:
+ *   k0,k1 : u64 sort keys (ping-pong)      v0,v1 : u32 sort values (ping-pong)
+ *   sufx,grp,pos : u32 active-list columns  sa,isa : u32 suffix array and ranks      */
+#define LBZ_BWT_SLOT_BYTES(cap) ((size_t)(cap) * (8u * 2u + 4u * 2u + 4u * 5u))
+
+#endif

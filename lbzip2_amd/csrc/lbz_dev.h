@@ -1,0 +1,154 @@
+/*
+ * lbz_dev.h -- wavefront / workgroup primitives for the gfx950 kernels.
+ *
+ * CDNA4 model used throughout: 64-lane wavefronts, LBZ_NW waves per workgroup, one
+ * workgroup per bzip2 block; cross-lane traffic by shuffles/ballots, cross-wave traffic
+ * by LDS; every scan below is "wave scan -> LBZ_NW partials in LDS -> wave 0 scans them".
+ */
+#ifndef LBZ_DEV_H
+#define LBZ_DEV_H
+
+#include <hip/hip_runtime.h>
+
+#include "lbz_common.h"
+
+typedef unsigned long long u64;
+typedef unsigned int u32;
+typedef unsigned short u16;
+typedef unsigned char u8;
+
+__device__ __forceinline__ u32 lane_id() { return threadIdx.x & 63u; }
+__device__ __forceinline__ u32 wave_id() { return threadIdx.x >> 6; }
+__device__ __forceinline__ u64 lanes_below() { return (1ull << lane_id()) - 1ull; }
+
+/* Lanes of one wave run in lockstep on the hardware; this only pins the compiler's
+ * ordering of LDS accesses around a wave-private read-modify-write.                  */
+__device__ __forceinline__ void wave_sync() { __builtin_amdgcn_wave_barrier(); }
+
+template <class T> __device__ __forceinline__ T wave_incl_add(T v)
+{
+  const u32 l = lane_id();
+#pragma unroll
+  for (u32 d = 1; d < 64; d <<= 1) {
+    T o = __shfl_up(v, d);
+    if (l >= d) v += o;
+  }
+  return v;
+}
+
+template <class T> __device__ __forceinline__ T wave_incl_max(T v)
+{
+  const u32 l = lane_id();
+#pragma unroll
+  for (u32 d = 1; d < 64; d <<= 1) {
+    T o = __shfl_up(v, d);
+    if (l >= d && o > v) v = o;
+  }
+  return v;
+}
+
+template <class T> __device__ __forceinline__ T wave_sum(T v)
+{
+#pragma unroll
+  for (u32 d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, (int)d);
+  return v;
+}
+
+template <class T> __device__ __forceinline__ T wave_min(T v)
+{
+#pragma unroll
+  for (u32 d = 32; d >= 1; d >>= 1) { T o = __shfl_xor(v, (int)d); if (o < v) v = o; }
+  return v;
+}
+
+template <class T> __device__ __forceinline__ T wave_max(T v)
+{
+#pragma unroll
+  for (u32 d = 32; d >= 1; d >>= 1) { T o = __shfl_xor(v, (int)d); if (o > v) v = o; }
+  return v;
+}
+
+/* LDS scratch for the workgroup scans/reductions: one object, reused everywhere. */
+struct wg_scratch {
+  u32 a[LBZ_NW + 1];
+  u32 b[LBZ_NW + 1];
+};
+
+/* Exclusive add-scan over the workgroup.  Returns this thread's exclusive prefix,
+ * *total = sum over all threads.  Three barriers; sc may be reused right after.       */
+__device__ __forceinline__ u32 wg_excl_add(u32 v, u32 *total, wg_scratch *sc)
+{
+  const u32 l = lane_id(), w = wave_id();
+  u32 inc = wave_incl_add(v);
+  if (l == 63) sc->a[w] = inc;
+  __syncthreads();
+  if (w == 0) {
+    u32 p = l < LBZ_NW ? sc->a[l] : 0u;
+    u32 pi = wave_incl_add(p);
+    if (l < LBZ_NW) sc->a[l] = pi - p;
+    if (l == LBZ_NW - 1) sc->a[LBZ_NW] = pi;
+  }
+  __syncthreads();
+  u32 r = sc->a[w] + inc - v;
+  *total = sc->a[LBZ_NW];
+  __syncthreads();
+  return r;
+}
+
+/* Exclusive max-scan (identity 0) and exclusive add-scan in one pass. */
+__device__ __forceinline__ void wg_excl_max_add(u32 vmax, u32 vadd, u32 *emax, u32 *eadd,
+                                                 u32 *tmax, u32 *tadd, wg_scratch *sc)
+{
+  const u32 l = lane_id(), w = wave_id();
+  u32 im = wave_incl_max(vmax);
+  u32 ia = wave_incl_add(vadd);
+  if (l == 63) { sc->a[w] = im; sc->b[w] = ia; }
+  __syncthreads();
+  if (w == 0) {
+    u32 pm = l < LBZ_NW ? sc->a[l] : 0u;
+    u32 pa = l < LBZ_NW ? sc->b[l] : 0u;
+    u32 qm = wave_incl_max(pm);
+    u32 qa = wave_incl_add(pa);
+    u32 qm_ex = __shfl_up(qm, 1u);
+    if (l == 0) qm_ex = 0u;
+    if (l < LBZ_NW) { sc->a[l] = qm_ex; sc->b[l] = qa - pa; }
+    if (l == LBZ_NW - 1) { sc->a[LBZ_NW] = qm; sc->b[LBZ_NW] = qa; }
+  }
+  __syncthreads();
+  u32 pm_ex = __shfl_up(im, 1u);
+  if (l == 0) pm_ex = 0u;
+  u32 bm = sc->a[w];
+  *emax = bm > pm_ex ? bm : pm_ex;
+  *eadd = sc->b[w] + ia - vadd;
+  *tmax = sc->a[LBZ_NW];
+  *tadd = sc->b[LBZ_NW];
+  __syncthreads();
+}
+
+__device__ __forceinline__ u32 wg_min(u32 v, wg_scratch *sc)
+{
+  const u32 l = lane_id(), w = wave_id();
+  v = wave_min(v);
+  if (l == 0) sc->a[w] = v;
+  __syncthreads();
+  u32 r = sc->a[0];
+#pragma unroll
+  for (u32 i = 1; i < LBZ_NW; i++) { u32 o = sc->a[i]; if (o < r) r = o; }
+  __syncthreads();
+  return r;
+}
+
+__device__ __forceinline__ u32 wg_sum(u32 v, wg_scratch *sc)
+{
+  const u32 l = lane_id(), w = wave_id();
+  v = wave_sum(v);
+  if (l == 0) sc->a[w] = v;
+  __syncthreads();
+  u32 r = 0;
+#pragma unroll
+  for (u32 i = 0; i < LBZ_NW; i++) r += sc->a[i];
+  __syncthreads();
+  return r;
+}
+
+#endif

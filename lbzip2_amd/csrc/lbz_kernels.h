@@ -1,0 +1,28 @@
+/* lbz_kernels.h -- prototypes of the gfx950 kernels (one .hip file each). */
+#ifndef LBZ_KERNELS_H
+#define LBZ_KERNELS_H
+
+#include "lbz_dev.h"
+
+struct lbz_stream_state {
+  u64 pos;          /* bytes of stream written so far */
+  u32 crc;          /* combined CRC so far */
+  u32 nblocks;
+  u64 n_rle;
+  u64 n_mtf;
+  u64 sort_elems;
+  u32 nperiodic;
+  u32 err;
+};
+
+__global__ void k_collect(const u8 *in, u64 in_len, lbz_layout L, u8 *Tbase, lbz_block_meta *meta);
+__global__ void k_bwt(const u8 *Tbase, u8 *Bbase, lbz_block_meta *meta, lbz_layout L,
+                      u32 nslabs, u32 *queue, u8 *ws, u64 slot_bytes);
+__global__ void k_mtf(const u8 *Bbase, u8 *Rbase, u16 *Vbase, u32 *freq_out, lbz_block_meta *meta, lbz_layout L);
+__global__ void k_encode(const u16 *Vbase, const u32 *freq_in, u8 *Obase, lbz_block_meta *meta, lbz_layout L);
+__global__ void k_offsets(const lbz_block_meta *meta, u32 nblk, u32 bs100k, u32 first, u32 last,
+                          u64 *offs, lbz_stream_state *st, u8 *out, u64 out_cap);
+__global__ void k_gather(const u8 *Obase, const lbz_block_meta *meta, lbz_layout L, const u64 *offs,
+                         const lbz_stream_state *st, u8 *out);
+
+#endif
