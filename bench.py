@@ -1,0 +1,196 @@
+#!/usr/bin/env python3
+"""bench.py -- the reference's headline metric on MI355X: bzip2 -9 compress throughput.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+One "step" = one pass of the hot path (RLE1+CRC -> BWT -> MTF/ZRLE -> prefix codes -> bit
+packing -> stream assembly) over the workload, input already resident in HBM, the complete
+.bz2 stream left in HBM.  Workload (BASELINE.json configs[1]): enwik9-sized text, 10^9 bytes,
+level -9, per GPU; the real enwik9 is used if $LBZ_ENWIK9 points at it, else the seeded
+stand-in text(10^9, seed 2+rank) of SURVEY.md 8d.  With N GPUs every rank compresses its own
+10^9-byte shard into its own complete stream (independent slabs, no data-path collective;
+concatenated streams are a valid .bz2 file) -> weak scaling; value = all ranks' input bytes
+over the max-over-ranks time.
+
+Prints ONE JSON line on rank 0.  Extra objects:
+  roofline      dominant kernel (k_bwt): SURVEY 8(d) algorithmic bytes of the BWT stage
+                (11 B per RLE1'd byte) per launch / mean launch time from HIP events recorded
+                on the library's own stream; peak 8000 GB/s (MI355X HBM3E)
+  cpu_baseline  reference lbzip2's block codec (oracle/_ref, "reference") or the bit-exact
+                restatement (oracle/, "port") on the box's host cores over a bounded sample
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+from concurrent.futures import ThreadPoolExecutor
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8 TB/s HBM3E
+BWT_ALG_BYTES_PER_RLE = 11.0   # T read 1 + SA write 4 + SA read 4 + gather 1 + BWT write 1
+
+
+def gen_input(kind, n, seed):
+    g = C.CDLL(os.path.join(ROOT, "lbzip2_amd", "host", "libgen_inputs.so"))
+    buf = bytearray(n)
+    cbuf = (C.c_uint8 * n).from_buffer(buf)
+    fn = g.lbzgen_text if kind == "text" else g.lbzgen_rand
+    fn.argtypes = [C.c_void_p, C.c_size_t, C.c_uint32]
+    fn(cbuf, n, seed)
+    del cbuf
+    return buf
+
+
+def cpu_baseline(data, level, seconds_budget=20.0):
+    """Time the CPU codec on the host cores over a bounded sample of the same workload."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_lib as L   # test infrastructure: only used here as the timed CPU baseline
+    kind = "reference" if L.have_ref() else "port"
+    fn = L.ref_compress if kind == "reference" else L.orc_compress
+    M = level * 100000
+    cores = os.cpu_count() or 1
+    # single thread: ~20 MB/s -> 3 slabs ~ 0.15 s; probe the rate first
+    t0 = time.perf_counter()
+    fn(bytes(data[:3 * M]), level)
+    t1 = time.perf_counter() - t0
+    rate1 = 3 * M / t1
+    # all cores: slabs_per_thread sized for the budget
+    per_thread = max(1, min(16, int(seconds_budget * rate1 / M)))
+    nthreads = min(cores, max(1, len(data) // (per_thread * M)))
+    pieces = [bytes(data[i * per_thread * M:(i + 1) * per_thread * M]) for i in range(nthreads)]
+    with ThreadPoolExecutor(nthreads) as ex:
+        t0 = time.perf_counter()
+        list(ex.map(lambda p: fn(p, level), pieces))     # ctypes releases the GIL
+        t = time.perf_counter() - t0
+    total = sum(len(p) for p in pieces)
+    return {"value": round(total / t / 1e6, 2), "unit": "MB/s", "cores": nthreads, "kind": kind,
+            "sample": f"{nthreads} threads x {per_thread} slabs of {M} B ({total} B) of the same workload, level -{level}",
+            "single_thread_MBps": round(rate1 / 1e6, 2), "host_cpus": cores}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--bytes", type=int, default=1_000_000_000, help="input bytes per GPU")
+    ap.add_argument("--level", type=int, default=9)
+    ap.add_argument("--kind", default="text", choices=["text", "rand"])
+    ap.add_argument("--slabs", type=int, default=0, help="resident slabs per chunk (0 = all)")
+    ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    ap.add_argument("--verify", action="store_true", help="decode the stream with Python's bz2 (untimed)")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU path exists)"
+    torch.cuda.set_device(local)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+
+    import lbzip2_amd
+    lib = lbzip2_amd.library()
+
+    n = args.bytes
+    M = args.level * 100000
+    path = os.environ.get("LBZ_ENWIK9")
+    if path and os.path.exists(path) and args.kind == "text":
+        data = bytearray(open(path, "rb").read()[:n])
+        source = "enwik9 file"
+    else:
+        data = gen_input(args.kind, n, 2 + rank)
+        source = f"synthetic {args.kind}({n}, seed {2 + rank})"
+    n = len(data)
+    nslabs = (n + M - 1) // M
+    slabs = args.slabs or nslabs
+
+    src = torch.frombuffer(data, dtype=torch.uint8).cuda()
+    dst = torch.empty(lib.bound(n), dtype=torch.uint8, device="cuda")
+    ctx = lib.context(args.level, slabs, 0, local)
+
+    def step():
+        return ctx.compress_device(src.data_ptr(), n, dst.data_ptr(), dst.numel())
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    out_len = 0
+    for _ in range(args.warmup):
+        out_len = step()
+    barrier()
+    t0 = time.perf_counter()
+    bwt_ms = tot_ms = 0.0
+    st = None
+    for _ in range(args.steps):
+        out_len = step()
+        st = ctx.stats()
+        bwt_ms += st.ms_bwt
+        tot_ms += st.ms_total
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+        o = torch.tensor([out_len, n], dtype=torch.int64, device="cuda")
+        dist.all_reduce(o)
+        total_out, total_in = int(o[0].item()), int(o[1].item())
+    else:
+        total_out, total_in = out_len, n
+
+    if args.verify:
+        import bz2
+        assert bz2.decompress(bytes(dst[:out_len].cpu().numpy())) == bytes(data)
+
+    if rank == 0:
+        nchunks = (nslabs + slabs - 1) // slabs
+        launches = args.steps * nchunks
+        bwt_alg = BWT_ALG_BYTES_PER_RLE * st.n_rle * args.steps          # bytes over all launches
+        achieved = bwt_alg / (bwt_ms * 1e-3) / 1e9 if bwt_ms > 0 else 0.0
+        pipe_alg = st.n_in + 13.0 * st.n_rle + 20.0 * st.n_mtf + st.n_out  # SURVEY 8(d), per step
+        res = {
+            "metric": "compress MB/s (whole node), enwik9-style text -9", "value": round(total_in * args.steps / elapsed / 1e6, 1),
+            "unit": "MB/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 2), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic" if "synthetic" in source else "enwik9",
+            "config": {"workload": f"{source}, level -{args.level}, {nslabs} slabs of {M} B per GPU, "
+                                   f"{slabs} resident per chunk, one bzip2 block per workgroup",
+                       "bytes_per_gpu": n, "level": args.level, "parallelism": f"{world} independent shard(s)"},
+            "ratio": round(total_in / total_out, 4), "out_bytes": total_out,
+            "bit_exact": "vs reference lbzip2 (tests/test_gpu_parity.py); periodic blocks: origin pointer only",
+            "roofline": {"bound": "hbm", "kernel": "k_bwt", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+                         "alg_bytes_per_launch": round(bwt_alg / launches), "launches": launches,
+                         "avg_launch_ms": round(bwt_ms / launches, 3),
+                         "pipeline_alg_bytes_per_step": round(pipe_alg),
+                         "pipeline_achieved_GBps": round(pipe_alg * args.steps / (tot_ms * 1e-3) / 1e9, 2),
+                         "pipeline_frac": round(pipe_alg * args.steps / (tot_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)},
+            "kernel_ms_per_step": {"collect": round(st.ms_collect, 2), "bwt": round(st.ms_bwt, 2), "mtf": round(st.ms_mtf, 2),
+                                   "encode": round(st.ms_encode, 2), "finish": round(st.ms_finish, 2)},
+            "sorter": {"elements_per_block_byte": round(st.sort_elems / max(1, st.n_rle), 3), "blocks": st.nblocks,
+                       "periodic_blocks": st.nperiodic},
+        }
+        if not args.no_cpu:
+            res["cpu_baseline"] = cpu_baseline(data, args.level)
+        print(json.dumps(res), flush=True)
+    ctx.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -24,6 +24,12 @@ def library() -> Library:
     """The product library (HIP, gfx950). Raises LbzError if it has not been built."""
     global _lib
     if _lib is None:
+        try:
+            # torch ships its own libamdhip64; load it first so the process holds ONE HIP runtime
+            # (loading ROCm's copy first leaves torch with "No HIP GPUs are available").
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         _lib = Library(LIB_PATH)
     return _lib
 

@@ -1,0 +1,72 @@
+"""CPU: kernel LOGIC under the fiber emulator (tests/emu) against the oracle, small blocks.
+The emulator build is test infrastructure; the product library is hipcc/gfx950 only."""
+import bz2
+import os
+import subprocess
+
+import pytest
+
+import oracle_lib as L
+from golden_util import gen, suite_inputs
+from lbzip2_amd._binding import Library
+
+EMU_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "emu")
+
+
+@pytest.fixture(scope="module")
+def emu():
+    subprocess.check_call(["make", "-s", "-C", EMU_DIR, "WG=1024"])
+    return Library(os.path.join(EMU_DIR, "_build", "liblbzamd_emu_1024.so"))
+
+
+KEYS = ["consumed", "nblock", "crc", "inuse", "block", "bwt", "bwt_idx", "nmtf", "alpha", "mtfv",
+        "num_trees", "num_selectors", "out_len", "out"]
+
+
+def _stages(emu, data, level):
+    M = level * 100000
+    with emu.context(level, max(1, (len(data) + M - 1) // M), 8) as ctx:
+        gb = ctx.blocks(data, 3)
+    ob = L.orc_blocks(data, level)
+    assert len(gb) == len(ob)
+    for g, o in zip(gb, ob):
+        assert g["err"] == 0
+        for k in KEYS:
+            assert g[k] == o[k], k
+        assert g["periodic"] == o["periodic"]
+
+
+@pytest.mark.parametrize("name,data", [
+    ("banana", b"banana"), ("one", b"a"), ("two", b"ab"), ("same", b"\0" * 7),
+    ("text3k", gen("text", 3000, 5)), ("rand5k", gen("rand", 5000, 6)),
+    ("zeros", bytes(10000)), ("abab", b"ab" * 500), ("all256", bytes(range(256)) * 3),
+    ("text30k", gen("text", 30000, 7)),
+])
+def test_stages_small(emu, name, data):
+    _stages(emu, data, 1)
+
+
+def test_streams_multi_slab_spill_chunked(emu):
+    for kind, n, seed, slabs in [("text", 230000, 3, 2), ("runs", 150000, 4, 2)]:
+        data = gen(kind, n, seed)
+        with emu.context(1, slabs, 4) as ctx:
+            got = ctx.compress(data)
+        assert got == L.orc_compress(data, 1)
+        assert bz2.decompress(got) == data
+    assert emu.compress(b"", 9) == L.orc_compress(b"", 9)
+
+
+def test_workunit_interface(emu):
+    data = gen("runs", 110000, 2) + gen("text", 20000, 9)
+    assert emu.compress_workunits(data, 1) == L.orc_compress(data, 1)
+
+
+def test_reference_suite_sample(emu):
+    """A slice of the reference's own compress corpora (small members only: emulation is slow)."""
+    inputs = suite_inputs()
+    names = [n for n in sorted(inputs) if len(inputs[n]) <= 6000][::12]
+    assert len(names) > 30
+    for n in names:
+        raw = inputs[n]
+        if raw:
+            assert emu.compress(raw, 9) == L.orc_compress(raw, 9), n
