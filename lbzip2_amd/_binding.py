@@ -40,7 +40,8 @@ class Stats(C.Structure):
 class BlockInfo(C.Structure):
     _fields_ = [(n, C.c_uint32) for n in ("n", "crc", "consumed", "bwt_idx", "periodic", "nmtf",
                                            "alpha", "num_trees", "num_sel", "out_len", "err",
-                                           "rounds")] + [("inuse", C.c_uint8 * 256)]
+                                           "rounds", "sort_elems")] + [("ticks", C.c_uint32 * 8),
+                                                                        ("inuse", C.c_uint8 * 256)]
 
 
 class LbzError(RuntimeError):

@@ -5,45 +5,100 @@
  * Replaces divbwt() (reference src/divbwt.c:1706-1726; its sort_typeBstar/sssort/trsort/
  * construct_BWT machinery, divbwt.c:1488-1699, is a serial induced-sorting design with no
  * data-parallel analogue).  The BWT byte string is mathematically unique, so any correct
- * rotation sorter reproduces it; this one is prefix doubling built from two workgroup
- * primitives:
+ * rotation sorter reproduces it.  This one is a most-significant-digit string sort staged
+ * through LDS:
  *
- *   1. an LSD radix sort of (64-bit key, 32-bit value) pairs over the workgroup's private
- *      arrays in HBM: per-digit histograms and per-wave digit counters live in LDS, ranks
- *      inside a wave come from 8 ballots per item ("match-any"), tiles are scattered in
- *      order so every pass is stable;
- *   2. tiled max/add scans that turn equal-key runs into groups, ranks and the compacted
- *      list of still-tied rows.
+ *   keys      every rotation i gets a 64-bit key: the dense codes (b = ceil(log2 #used bytes)
+ *             bits each) of its first S = 64/b symbols, plus a 32-bit value
+ *             (preceding byte << 24 | i) -- the BWT output byte rides along with the index.
+ *   partition three stable 8-bit radix passes in HBM on the key's top 24 bits.  Keys are built
+ *             on the fly from the block text streamed through an LDS tile (the first pass
+ *             never reads a key array); per-wave digit counters live in LDS, ranks inside a
+ *             wave come from 8 ballots per row, tiles are scattered in order so every write
+ *             is a run of equal-digit rows.
+ *   batches   consecutive whole 24-bit groups of <= 4096 rows are pulled into LDS; rows are
+ *             ranked inside their group by counting smaller keys (groups are short), and every
+ *             run of equal 64-bit keys is refined IN LDS by fetching the rotation's next S
+ *             symbols from the text and ranking inside the run, up to 4 times.  A finished
+ *             batch writes 1 B (BWT byte) + 4 B (row) per rotation.
+ *   oversized a 24-bit group larger than a batch is sorted on its remaining 40 key bits by the
+ *             HBM radix sorter and then cut into batches at key boundaries.
+ *   deep ties rows still tied after the LDS refinements (long repeats, periodic blocks) are
+ *             finished by prefix doubling on ranks: (group << 20 | rank of the rotation h
+ *             further on) keys, HBM radix sort, regroup by max/add scans; it ends when every
+ *             row is unique or h >= n.  In the latter case the block is exactly periodic
+ *             (T = u^k), equal rows stay tied and the origin pointer is the smallest equal row
+ *             (the reference's choice among the k equal rows is an artefact of its unstable
+ *             quicksort, SURVEY.md 8a-4 -- documented divergence, identical BWT bytes).
  *
- * Round 0 sorts all n rotations by their first 8 bytes.  Round r (depth h = 8,16,...) re-keys
- * only rows that are still tied with (current group << 20 | rank of the rotation h further on)
- * and sorts that list (40 significant bits -> 5 passes, constant digits skipped).  The loop
- * ends when every row is unique or h >= n; in the latter case the block is exactly periodic
- * (T = u^k), equal rows stay tied and the origin pointer is the smallest equal row (the
- * reference's choice among the k equal rows is an artefact of its unstable quicksort,
- * SURVEY.md 8a-4 -- documented divergence, identical BWT bytes).
- *
- * HBM per slot: 44 B per element (lbz_common.h).  Algorithmic traffic of the stage as priced
- * in SURVEY.md 8(d): read T (1) + write SA (4) + read SA (4) + gather T (1) + write BWT (1)
- * = 11 B per block byte; the sorter's real traffic is reported next to it by bench.py.
+ * Algorithmic traffic of the stage as priced in SURVEY.md 8(d): read T (1) + write SA (4) +
+ * read SA (4) + gather T (1) + write BWT (1) = 11 B per block byte.
  */
+/* This kernel runs 512-thread workgroups (8 waves) with 2048-row batches: 73 KB of LDS, so
+ * two blocks share a CU and cover each other's barrier and LDS latencies.                */
+#include "lbz_common.h"
+#undef LBZ_WG
+#define LBZ_WG LBZ_BWT_WG
+#undef LBZ_NW
+#define LBZ_NW (LBZ_WG / 64)
 #include "lbz_kernels.h"
 
 #define SORT_IPT 4u
 #define SORT_TILE (LBZ_WG * SORT_IPT)
 #define RANK_BITS 20u                   /* n <= 900000 < 2^20 */
+#define MSD_BITS 24u                    /* three 8-bit partition passes in HBM */
+#define MSD_SHIFT (64u - MSD_BITS)
+#define PART_HALO 48u
+#define BATCH_CAP (LBZ_WG * 4u)
+#define COUNT_GROUP 48u                 /* chunks of groups this short are ordered by counting */
+#define WAVE_GROUP 1024u                /* batches holding a longer group are sorted by the whole workgroup */
+#define MAX_SYMS 32u                    /* symbols per key, capped (halo of the text tile) */
+#define REFINE_ROUNDS 4u
+#define TIE_FLAG 0x80000000u
+static_assert(BATCH_CAP == LBZ_WG * 4u, "a batch is one 4-rows-per-thread tile");
 
-struct bwt_lds {
-  wg_scratch sc;
+struct glb_sort_lds {                   /* HBM radix sorter */
   u32 hist[8][256];
   u32 wcnt[LBZ_NW][256];
   u32 dbase[256];
-  u32 bc[4];
+};
+struct part_lds {                       /* MSD partition passes */
+  u32 hist[3][256];
+  u32 wcnt[LBZ_NW][256];
+  u32 dbase[256];
+  u8 tile[SORT_TILE + PART_HALO + 16u];
+};
+struct batch_lds {                      /* one batch resident in LDS */
+  u64 kA[BATCH_CAP], kB[BATCH_CAP];
+  u32 vA[BATCH_CAP], vB[BATCH_CAP];
+  u16 gh[BATCH_CAP], ghn[BATCH_CAP];    /* local row of the run's first element */
+  u16 gend[BATCH_CAP];                  /* indexed by a run's first row: one past its last row */
+  u8 tied[BATCH_CAP], tiedn[BATCH_CAP];
+  u32 wcnt[LBZ_NW][256];
+  u32 dbase[256];
+  u32 nlong, next_long;                 /* work list of long groups of the batch */
+  u16 lgroup[BATCH_CAP / COUNT_GROUP + 4u];
+};
+struct bwt_lds {
+  wg_scratch sc;
+  u32 bc[16];
+  u8 cmap[256];
+  union {
+    glb_sort_lds G;
+    part_lds P;
+    batch_lds B;
+  } u;
 };
 
 struct bwt_slot {
   u64 *k0, *k1;
-  u32 *v0, *v1, *sufx, *grp, *pos, *sa, *isa;
+  u32 *v0, *v1, *sufx, *grp, *pos, *sa, *isa, *gb;
+};
+
+struct keycfg {
+  u32 b;        /* bits per symbol */
+  u32 sy;       /* symbols per key */
+  u32 pad;      /* 64 - b*sy: keys are left aligned */
 };
 
 __device__ __forceinline__ bwt_slot slot_carve(u8 *ws, u32 cap)
@@ -58,22 +113,41 @@ __device__ __forceinline__ bwt_slot slot_carve(u8 *ws, u32 cap)
   s.grp = (u32 *)p; p += (size_t)cap * 4u;
   s.pos = (u32 *)p; p += (size_t)cap * 4u;
   s.sa = (u32 *)p; p += (size_t)cap * 4u;
-  s.isa = (u32 *)p;
+  s.isa = (u32 *)p; p += (size_t)cap * 4u;
+  s.gb = (u32 *)p;                                   /* spare */
   return s;
 }
 
-/* Stable LSD radix sort of m (key,value) pairs on key bits [0, nbits).  Input in (k0,v0);
- * returns 0 if the sorted result is in (k0,v0), 1 if in (k1,v1).                       */
+/* Lanes of the wave holding the same 8-bit digit ("match any"): 8 ballots; each ballot is
+ * folded in with an xnor against the lane's own sign-extended bit.                        */
+__device__ __forceinline__ u64 match_digit(u32 d, bool ok)
+{
+  const u64 act = __ballot(ok);
+  u32 lo = (u32)act, hi = (u32)(act >> 32);
+#pragma unroll
+  for (u32 b = 0; b < 8u; b++) {
+    const int bm = -(int)((d >> b) & 1u);               /* 0 or ~0 */
+    const u64 bal = __ballot(bm != 0);
+    lo &= ~((u32)bal ^ (u32)bm);
+    hi &= ~((u32)(bal >> 32) ^ (u32)bm);
+  }
+  return ((u64)hi << 32) | lo;
+}
+
+/* ======================================================================= HBM radix sorter
+ * Stable LSD radix sort of m (key,value) pairs on key bits [0, nbits).  Input in (k0,v0);
+ * returns 0 if the sorted result is in (k0,v0), 1 if in (k1,v1).                        */
 __device__ u32 wg_radix_sort(u64 *k0, u32 *v0, u64 *k1, u32 *v1, u32 m, u32 nbits, bwt_lds *S)
 {
+  glb_sort_lds *G = &S->u.G;
   const u32 tid = threadIdx.x, lane = lane_id(), w = wave_id();
   const u32 npass = (nbits + 7u) / 8u;
 
-  for (u32 i = tid; i < 8u * 256u; i += LBZ_WG) (&S->hist[0][0])[i] = 0;
+  for (u32 i = tid; i < 8u * 256u; i += LBZ_WG) (&G->hist[0][0])[i] = 0;
   __syncthreads();
   for (u32 i = tid; i < m; i += LBZ_WG) {
     const u64 key = k0[i];
-    for (u32 p = 0; p < npass; p++) atomicAdd(&S->hist[p][(u32)(key >> (8u * p)) & 255u], 1u);
+    for (u32 p = 0; p < npass; p++) atomicAdd(&G->hist[p][(u32)(key >> (8u * p)) & 255u], 1u);
   }
   __syncthreads();
 
@@ -81,10 +155,10 @@ __device__ u32 wg_radix_sort(u64 *k0, u32 *v0, u64 *k1, u32 *v1, u32 m, u32 nbit
   for (u32 p = 0; p < npass; p++) {
     const u32 shift = 8u * p;
     /* digit offsets; a digit shared by every key makes the pass a no-op */
-    const u32 c = tid < 256u ? S->hist[p][tid] : 0u;
+    const u32 c = tid < 256u ? G->hist[p][tid] : 0u;
     u32 tot;
     const u32 ex = wg_excl_add(c, &tot, &S->sc);
-    if (tid < 256u) S->dbase[tid] = ex;
+    if (tid < 256u) G->dbase[tid] = ex;
     if (tid == 0) S->bc[0] = 0;
     __syncthreads();
     if (tid < 256u && c == m) S->bc[0] = 1;
@@ -97,7 +171,7 @@ __device__ u32 wg_radix_sort(u64 *k0, u32 *v0, u64 *k1, u32 *v1, u32 m, u32 nbit
     u32 *vout = cur ? v0 : v1;
 
     for (u32 t0 = 0; t0 < m; t0 += SORT_TILE) {
-      for (u32 i = tid; i < LBZ_NW * 256u; i += LBZ_WG) (&S->wcnt[0][0])[i] = 0;
+      for (u32 i = tid; i < LBZ_NW * 256u; i += LBZ_WG) (&G->wcnt[0][0])[i] = 0;
       __syncthreads();
       u64 key[SORT_IPT];
       u32 val[SORT_IPT], rnk[SORT_IPT];
@@ -113,30 +187,24 @@ __device__ u32 wg_radix_sort(u64 *k0, u32 *v0, u64 *k1, u32 *v1, u32 m, u32 nbit
         const u32 i = wbase + k * 64u + lane;
         const bool ok = i < m;
         const u32 d = (u32)(key[k] >> shift) & 255u;
-        u64 mask = __ballot(ok);
-#pragma unroll
-        for (u32 b = 0; b < 8u; b++) {
-          const bool bit = (d >> b) & 1u;
-          const u64 bal = __ballot(bit);
-          mask &= bit ? bal : ~bal;
-        }
+        const u64 mask = match_digit(d, ok);
         const u32 below = (u32)__popcll(mask & lanes_below());
-        const u32 prev = ok ? S->wcnt[w][d] : 0u;
+        const u32 prev = ok ? G->wcnt[w][d] : 0u;
         wave_sync();
-        if (ok && below == 0u) S->wcnt[w][d] = prev + (u32)__popcll(mask);
+        if (ok && below == 0u) G->wcnt[w][d] = prev + (u32)__popcll(mask);
         wave_sync();
         rnk[k] = prev + below;
       }
       __syncthreads();
       if (tid < 256u) {
-        u32 run = S->dbase[tid];
+        u32 run = G->dbase[tid];
 #pragma unroll
         for (u32 w2 = 0; w2 < LBZ_NW; w2++) {
-          const u32 t = S->wcnt[w2][tid];
-          S->wcnt[w2][tid] = run;
+          const u32 t = G->wcnt[w2][tid];
+          G->wcnt[w2][tid] = run;
           run += t;
         }
-        S->dbase[tid] = run;
+        G->dbase[tid] = run;
       }
       __syncthreads();
 #pragma unroll
@@ -144,7 +212,7 @@ __device__ u32 wg_radix_sort(u64 *k0, u32 *v0, u64 *k1, u32 *v1, u32 m, u32 nbit
         const u32 i = wbase + k * 64u + lane;
         if (i < m) {
           const u32 d = (u32)(key[k] >> shift) & 255u;
-          const u32 dst = S->wcnt[w][d] + rnk[k];
+          const u32 dst = G->wcnt[w][d] + rnk[k];
           kout[dst] = key[k];
           vout[dst] = val[k];
         }
@@ -156,12 +224,13 @@ __device__ u32 wg_radix_sort(u64 *k0, u32 *v0, u64 *k1, u32 *v1, u32 m, u32 nbit
   return cur;
 }
 
-/* Turn a key-sorted list into groups.  For list entry k (row pos_k of the suffix array):
- *   head  = key differs from the previous entry
+/* Turn a sorted list into groups.  For list entry k (row pos_k of the suffix array):
+ *   head  = starts a group: FLAGS ? the value's tie flag is clear : key differs from entry k-1
  *   rank  = row of the group's first entry
  * writes sa[row] = suffix, isa[suffix] = rank, and compacts the entries that are still
- * tied into (sufx, grp, pos).  pin == nullptr means row == k (round 0).  Returns the
- * number of still-tied entries.                                                         */
+ * tied into (sufx, grp, pos).  pin == nullptr means row == k.  Returns the number of
+ * still-tied entries.                                                                    */
+template <bool FLAGS>
 __device__ u32 wg_regroup(const u64 *key, const u32 *val, const u32 *pin, u32 m,
                           bwt_slot s, bwt_lds *S)
 {
@@ -169,33 +238,50 @@ __device__ u32 wg_regroup(const u64 *key, const u32 *val, const u32 *pin, u32 m,
   u32 carry_rank = 0, carry_cnt = 0;
   for (u32 t0 = 0; t0 < m; t0 += SORT_TILE) {
     const u32 k0 = t0 + tid * SORT_IPT;
-    u64 kk[SORT_IPT + 2];
     u32 vv[SORT_IPT], row[SORT_IPT];
+    u32 headmask = 0, nextmask = 0;      /* bit i: entry k0+i / entry k0+i+1 starts a group */
+    if (FLAGS) {
 #pragma unroll
-    for (u32 i = 0; i < SORT_IPT; i++) {
-      const u32 k = k0 + i;
-      kk[i + 1] = k < m ? key[k] : 0ull;
-      vv[i] = k < m ? val[k] : 0u;
-      row[i] = k < m ? (pin ? pin[k] : k) : 0u;
-    }
-    kk[0] = (k0 > 0 && k0 <= m) ? key[k0 - 1] : 0ull;
-    kk[SORT_IPT + 1] = (k0 + SORT_IPT < m) ? key[k0 + SORT_IPT] : 0ull;
-
-    u32 headmask = 0, lastrank = 0, nact = 0;
+      for (u32 i = 0; i < SORT_IPT; i++) {
+        const u32 k = k0 + i;
+        vv[i] = k < m ? val[k] : 0u;
+        row[i] = k;
+      }
+      const u32 vnext = (k0 + SORT_IPT < m) ? val[k0 + SORT_IPT] : 0u;
 #pragma unroll
-    for (u32 i = 0; i < SORT_IPT; i++) {
-      const u32 k = k0 + i;
-      if (k < m && (k == 0 || kk[i + 1] != kk[i])) { headmask |= 1u << i; lastrank = row[i] + 1u; }
+      for (u32 i = 0; i < SORT_IPT; i++) {
+        const u32 k = k0 + i;
+        if (k < m && !(vv[i] & TIE_FLAG)) headmask |= 1u << i;
+        const u32 vn = (i + 1u < SORT_IPT) ? vv[(i + 1u) % SORT_IPT] : vnext;
+        if (k + 1u >= m || !(vn & TIE_FLAG)) nextmask |= 1u << i;
+        vv[i] &= 0x00FFFFFFu;
+      }
+    } else {
+      u64 kk[SORT_IPT + 2];
+#pragma unroll
+      for (u32 i = 0; i < SORT_IPT; i++) {
+        const u32 k = k0 + i;
+        kk[i + 1] = k < m ? key[k] : 0ull;
+        vv[i] = k < m ? val[k] : 0u;
+        row[i] = k < m ? (pin ? pin[k] : k) : 0u;
+      }
+      kk[0] = (k0 > 0 && k0 <= m) ? key[k0 - 1] : 0ull;
+      kk[SORT_IPT + 1] = (k0 + SORT_IPT < m) ? key[k0 + SORT_IPT] : 0ull;
+#pragma unroll
+      for (u32 i = 0; i < SORT_IPT; i++) {
+        const u32 k = k0 + i;
+        if (k < m && (k == 0 || kk[i + 1] != kk[i])) headmask |= 1u << i;
+        if (k + 1u >= m || kk[i + 2] != kk[i + 1]) nextmask |= 1u << i;
+      }
     }
-    /* entry k is still tied unless it and its successor both start a group */
-    u32 actmask = 0;
+    u32 lastrank = 0, nact = 0, actmask = 0;
 #pragma unroll
     for (u32 i = 0; i < SORT_IPT; i++) {
       const u32 k = k0 + i;
       if (k < m) {
-        const bool h = (headmask >> i) & 1u;
-        const bool hn = (k + 1u >= m) || (kk[i + 2] != kk[i + 1]);
-        if (!(h && hn)) { actmask |= 1u << i; nact++; }
+        if ((headmask >> i) & 1u) lastrank = row[i] + 1u;
+        /* entry k is still tied unless it and its successor both start a group */
+        if (!(((headmask >> i) & 1u) && ((nextmask >> i) & 1u))) { actmask |= 1u << i; nact++; }
       }
     }
     u32 erank, eact, trank, tact;
@@ -226,34 +312,15 @@ __device__ u32 wg_regroup(const u64 *key, const u32 *val, const u32 *pin, u32 m,
   return carry_cnt;
 }
 
-__device__ void bwt_block(const u8 *T, u32 n, u8 *bwt, lbz_block_meta *meta, bwt_slot s, bwt_lds *S)
+/* ======================================================================= deep ties
+ * Prefix doubling from depth h0 on a suffix array whose unresolved rows carry TIE_FLAG.   */
+__device__ void finish_by_doubling(const u8 *T, u32 n, u8 *bwt, lbz_block_meta *meta, bwt_slot s,
+                                   bwt_lds *S, u32 h0, u32 *rounds_out, u32 *work_out)
 {
   const u32 tid = threadIdx.x;
-  if (n == 1u) {                              /* divbwt.c:1712 */
-    if (tid == 0) { bwt[0] = T[0]; meta->bwt_idx = 0; meta->periodic = 0; meta->rounds = 0; meta->sort_elems = 0; }
-    __syncthreads();
-    return;
-  }
-
-  /* round 0: first 8 bytes of every rotation, big-endian */
-  for (u32 i = tid; i < n; i += LBZ_WG) {
-    u64 key = 0;
-    if (i + 8u <= n) {
-#pragma unroll
-      for (u32 k = 0; k < 8u; k++) key = (key << 8) | T[i + k];
-    } else {
-      u32 j = i;
-      for (u32 k = 0; k < 8u; k++) { key = (key << 8) | T[j]; j = (j + 1u == n) ? 0u : j + 1u; }
-    }
-    s.k0[i] = key;
-    s.v0[i] = i;
-  }
-  __syncthreads();
-  u32 which = wg_radix_sort(s.k0, s.v0, s.k1, s.v1, n, 64u, S);
-  u32 m = wg_regroup(which ? s.k1 : s.k0, which ? s.v1 : s.v0, nullptr, n, s, S);
-  u32 rounds = 0, work = n;
-
-  for (u32 h = 8u; m > 0u && h < n; h <<= 1) {
+  u32 m = wg_regroup<true>(nullptr, s.sa, nullptr, n, s, S);
+  u32 rounds = 0, work = 0;
+  for (u32 h = h0; m > 0u && h < n; h <<= 1) {
     /* re-key the tied rows: (group, rank of the rotation h bytes further on) */
     for (u32 k = tid; k < m; k += LBZ_WG) {
       const u32 sfx = s.sufx[k];
@@ -263,12 +330,11 @@ __device__ void bwt_block(const u8 *T, u32 n, u8 *bwt, lbz_block_meta *meta, bwt
       s.v0[k] = sfx;
     }
     __syncthreads();
-    which = wg_radix_sort(s.k0, s.v0, s.k1, s.v1, m, 2u * RANK_BITS, S);
+    const u32 which = wg_radix_sort(s.k0, s.v0, s.k1, s.v1, m, 2u * RANK_BITS, S);
     work += m;
-    m = wg_regroup(which ? s.k1 : s.k0, which ? s.v1 : s.v0, s.pos, m, s, S);
+    m = wg_regroup<false>(which ? s.k1 : s.k0, which ? s.v1 : s.v0, s.pos, m, s, S);
     rounds++;
   }
-
   for (u32 j = tid; j < n; j += LBZ_WG) {
     const u32 sfx = s.sa[j];
     bwt[j] = T[sfx ? sfx - 1u : n - 1u];
@@ -276,15 +342,634 @@ __device__ void bwt_block(const u8 *T, u32 n, u8 *bwt, lbz_block_meta *meta, bwt
   if (tid == 0) {
     meta->bwt_idx = s.isa[0];
     meta->periodic = m > 0u ? 1u : 0u;
+  }
+  *rounds_out = rounds;
+  *work_out = work;
+  __syncthreads();
+}
+
+/* ======================================================================= keys */
+/* The sy symbols starting at rotation `start`, packed b bits each, left aligned. */
+__device__ __forceinline__ u64 key_from_text(const u8 *T, u32 n, u32 start, const u8 *cmap, keycfg c)
+{
+  u64 key = 0;
+  if (c.sy <= 16u && start + 20u <= n) {
+    /* five aligned dwords cover the 16 bytes; one wait instead of sy dependent loads */
+    const u32 shb = (start & 3u) * 8u;
+    const u32 *p = reinterpret_cast<const u32 *>(T + (start & ~3u));
+    const u32 w0 = p[0], w1 = p[1], w2 = p[2], w3 = p[3], w4 = p[4];
+    const u64 lo = (u64)w0 | ((u64)w1 << 32), mid = (u64)w2 | ((u64)w3 << 32), hi = (u64)w4;
+    const u64 x0 = shb ? (lo >> shb) | (mid << (64u - shb)) : lo;
+    const u64 x1 = shb ? (mid >> shb) | (hi << (64u - shb)) : mid;
+    for (u32 k = 0; k < c.sy; k++) {
+      const u32 byte = (u32)((k < 8u ? x0 : x1) >> (8u * (k & 7u))) & 255u;
+      key = (key << c.b) | cmap[byte];
+    }
+  } else {
+    u32 j = start;
+    for (u32 k = 0; k < c.sy; k++) {
+      key = (key << c.b) | cmap[T[j]];
+      j = (j + 1u == n) ? 0u : j + 1u;
+    }
+  }
+  return key << c.pad;
+}
+
+/* One stable counting-sort step of a 4096-row tile on digit (key >> shift) & 255: rows are
+ * held wave-striped (row = wbase + k*64 + lane), ranks inside a wave come from ballots, the
+ * per-wave counters and the running digit offsets (dbase) live in LDS.                     */
+__device__ __forceinline__ void radix_tile_scatter(u32 (*wcnt)[256], u32 *dbase, const u64 (&key)[SORT_IPT],
+                                                   const u32 (&val)[SORT_IPT], u32 okmask, u32 shift,
+                                                   u64 *kout, u32 *vout)
+{
+  const u32 tid = threadIdx.x, w = wave_id();
+  u32 rnk[SORT_IPT];
+  for (u32 i = tid; i < LBZ_NW * 256u; i += LBZ_WG) (&wcnt[0][0])[i] = 0;
+  __syncthreads();
+#pragma unroll
+  for (u32 k = 0; k < SORT_IPT; k++) {
+    const bool ok = (okmask >> k) & 1u;
+    const u32 d = (u32)(key[k] >> shift) & 255u;
+    const u64 mask = match_digit(d, ok);
+    const u32 below = (u32)__popcll(mask & lanes_below());
+    const u32 prev = ok ? wcnt[w][d] : 0u;
+    wave_sync();
+    if (ok && below == 0u) wcnt[w][d] = prev + (u32)__popcll(mask);
+    wave_sync();
+    rnk[k] = prev + below;
+  }
+  __syncthreads();
+  if (tid < 256u) {
+    u32 run = dbase[tid];
+#pragma unroll
+    for (u32 w2 = 0; w2 < LBZ_NW; w2++) {
+      const u32 t = wcnt[w2][tid];
+      wcnt[w2][tid] = run;
+      run += t;
+    }
+    dbase[tid] = run;
+  }
+  __syncthreads();
+#pragma unroll
+  for (u32 k = 0; k < SORT_IPT; k++) {
+    if ((okmask >> k) & 1u) {
+      const u32 d = (u32)(key[k] >> shift) & 255u;
+      const u32 dst = wcnt[w][d] + rnk[k];
+      kout[dst] = key[k];
+      vout[dst] = val[k];
+    }
+  }
+  __syncthreads();
+}
+
+/* A pass over the block text through the LDS tile, keys built on the fly.
+ * SCATTER = false: histogram the three partition digits of every rotation;
+ * SCATTER = true : first partition pass (digit at `shift`) straight from the text.          */
+template <bool SCATTER>
+__device__ void msd_text_pass(const u8 *T, u32 n, keycfg c, u32 shift, u64 *kout, u32 *vout, bwt_lds *S)
+{
+  part_lds *P = &S->u.P;
+  const u32 tid = threadIdx.x, lane = lane_id(), w = wave_id();
+  for (u32 t0 = 0; t0 < n; t0 += SORT_TILE) {
+    /* tile[1 + j] = T[(t0 + j) mod n] for j in [-1, SORT_TILE + PART_HALO) */
+    const u32 q0 = t0 + 4u * tid;
+    if (q0 + 4u <= n) {
+      const u32 v = *reinterpret_cast<const u32 *>(T + q0);
+      P->tile[1u + 4u * tid] = (u8)v; P->tile[2u + 4u * tid] = (u8)(v >> 8);
+      P->tile[3u + 4u * tid] = (u8)(v >> 16); P->tile[4u + 4u * tid] = (u8)(v >> 24);
+    } else {
+#pragma unroll
+      for (u32 i = 0; i < 4u; i++) P->tile[1u + 4u * tid + i] = T[(q0 + i) % n];
+    }
+    if (tid < PART_HALO) P->tile[1u + SORT_TILE + tid] = T[(t0 + SORT_TILE + tid) % n];
+    if (tid == PART_HALO) P->tile[0] = T[(t0 + n - 1u) % n];
+    __syncthreads();
+    u64 key[SORT_IPT];
+    u32 val[SORT_IPT], okmask = 0;
+    const u32 wbase = w * 64u * SORT_IPT;
+#pragma unroll
+    for (u32 k = 0; k < SORT_IPT; k++) {
+      const u32 j = wbase + k * 64u + lane;            /* position inside the tile */
+      const u32 p = t0 + j;
+      u64 kk = 0;
+      for (u32 q = 0; q < c.sy; q++) kk = (kk << c.b) | S->cmap[P->tile[1u + j + q]];
+      key[k] = kk << c.pad;
+      val[k] = ((u32)P->tile[j] << 24) | p;
+      if (p < n) okmask |= 1u << k;
+    }
+    if (SCATTER) {
+      radix_tile_scatter(P->wcnt, P->dbase, key, val, okmask, shift, kout, vout);
+    } else {
+#pragma unroll
+      for (u32 k = 0; k < SORT_IPT; k++)
+        if ((okmask >> k) & 1u) {
+          atomicAdd(&P->hist[0][(u32)(key[k] >> MSD_SHIFT) & 255u], 1u);
+          atomicAdd(&P->hist[1][(u32)(key[k] >> (MSD_SHIFT + 8u)) & 255u], 1u);
+          atomicAdd(&P->hist[2][(u32)(key[k] >> (MSD_SHIFT + 16u)) & 255u], 1u);
+        }
+      __syncthreads();
+    }
+  }
+}
+
+/* A partition pass from (kin,vin) to (kout,vout) on the digit at `shift`. */
+__device__ void msd_array_pass(const u64 *kin, const u32 *vin, u32 n, u32 shift, u64 *kout, u32 *vout, bwt_lds *S)
+{
+  part_lds *P = &S->u.P;
+  const u32 lane = lane_id(), w = wave_id();
+  for (u32 t0 = 0; t0 < n; t0 += SORT_TILE) {
+    u64 key[SORT_IPT];
+    u32 val[SORT_IPT], okmask = 0;
+    const u32 wbase = t0 + w * 64u * SORT_IPT;
+#pragma unroll
+    for (u32 k = 0; k < SORT_IPT; k++) {
+      const u32 i = wbase + k * 64u + lane;
+      key[k] = i < n ? kin[i] : 0ull;
+      val[k] = i < n ? vin[i] : 0u;
+      if (i < n) okmask |= 1u << k;
+    }
+    radix_tile_scatter(P->wcnt, P->dbase, key, val, okmask, shift, kout, vout);
+  }
+}
+
+/* exclusive offsets of one digit histogram into dbase */
+__device__ __forceinline__ void load_digit_offsets(const u32 *hist, u32 *dbase, bwt_lds *S)
+{
+  const u32 tid = threadIdx.x;
+  u32 tot;
+  const u32 ex = wg_excl_add(tid < 256u ? hist[tid] : 0u, &tot, &S->sc);
+  if (tid < 256u) dbase[tid] = ex;
+  __syncthreads();
+}
+
+/* ======================================================================= LDS batch */
+/* Radix sort of cnt <= BATCH_CAP pairs held in (kA,vA); returns 0/1 = result in A/B. */
+__device__ u32 lds_radix_sort(batch_lds *B, u32 cnt, bwt_lds *S)
+{
+  const u32 tid = threadIdx.x, lane = lane_id(), w = wave_id();
+  /* which key bytes differ between any two keys of the batch? */
+  u64 vo = 0, va = ~0ull;
+  for (u32 i = tid; i < cnt; i += LBZ_WG) { const u64 k = B->kA[i]; vo |= k; va &= k; }
+  u64 ro, ra;
+  wg_or_and64(vo, va, &ro, &ra, &S->sc);
+  const u64 varying = ro ^ ra;
+
+  u32 cur = 0;
+  for (u32 p = 0; p < 8u; p++) {
+    const u32 shift = 8u * p;
+    if (((varying >> shift) & 255ull) == 0ull) continue;
+    const u64 *kin = cur ? B->kB : B->kA;
+    const u32 *vin = cur ? B->vB : B->vA;
+    u64 key[SORT_IPT];
+    u32 val[SORT_IPT], okmask = 0;
+    const u32 wbase = w * 64u * SORT_IPT;
+#pragma unroll
+    for (u32 k = 0; k < SORT_IPT; k++) {
+      const u32 i = wbase + k * 64u + lane;
+      key[k] = i < cnt ? kin[i] : 0ull;
+      val[k] = i < cnt ? vin[i] : 0u;
+      if (i < cnt) okmask |= 1u << k;
+    }
+    if (tid < 256u) B->dbase[tid] = 0;
+    __syncthreads();
+    /* digit totals -> exclusive offsets: count first, then the ordinary tile scatter */
+#pragma unroll
+    for (u32 k = 0; k < SORT_IPT; k++)
+      if ((okmask >> k) & 1u) atomicAdd(&B->dbase[(u32)(key[k] >> shift) & 255u], 1u);
+    __syncthreads();
+    load_digit_offsets(B->dbase, B->dbase, S);
+    radix_tile_scatter(B->wcnt, B->dbase, key, val, okmask, shift, cur ? B->kA : B->kB, cur ? B->vA : B->vB);
+    cur ^= 1u;
+  }
+  return cur;
+}
+
+/* Wave-private LSD radix sort of rows [cs, ce) of the batch (data in A, result in A): strips
+ * of 64 rows, the wave's own digit counters, no workgroup barrier.  Key bytes that do not
+ * vary inside the range are skipped, so a group that shares its top 24 bits costs <= 5 passes. */
+__device__ void wave_radix_range(batch_lds *B, u32 cs, u32 ce)
+{
+  const u32 lane = lane_id(), w = wave_id();
+  u64 vo = 0, va = ~0ull;
+  for (u32 j = cs + lane; j < ce; j += 64u) { const u64 k = B->kA[j]; vo |= k; va &= k; }
+#pragma unroll
+  for (u32 d = 32; d >= 1; d >>= 1) { vo |= __shfl_xor(vo, (int)d); va &= __shfl_xor(va, (int)d); }
+  const u64 varying = vo ^ va;
+  u32 cur = 0;
+  for (u32 p = 0; p < 8u; p++) {
+    const u32 shift = 8u * p;
+    if (((varying >> shift) & 255ull) == 0ull) continue;
+    const u64 *kin = cur ? B->kB : B->kA;
+    const u32 *vin = cur ? B->vB : B->vA;
+    u64 *kout = cur ? B->kA : B->kB;
+    u32 *vout = cur ? B->vA : B->vB;
+    u32 *cntw = B->wcnt[w];
+#pragma unroll
+    for (u32 i = 0; i < 4u; i++) cntw[lane + 64u * i] = 0;
+    wave_sync();
+    for (u32 j0 = cs; j0 < ce; j0 += 64u) {             /* ranks of equal digits, in row order */
+      const u32 j = j0 + lane;
+      const bool ok = j < ce;
+      const u32 d = ok ? (u32)(kin[j] >> shift) & 255u : 0u;
+      const u64 mask = match_digit(d, ok);
+      const u32 below = (u32)__popcll(mask & lanes_below());
+      const u32 prev = ok ? cntw[d] : 0u;
+      wave_sync();
+      if (ok && below == 0u) cntw[d] = prev + (u32)__popcll(mask);
+      wave_sync();
+      if (ok) B->ghn[j] = (u16)(prev + below);
+    }
+    {                                                   /* exclusive scan of the 256 counters */
+      const u32 c0 = cntw[4u * lane], c1 = cntw[4u * lane + 1u], c2 = cntw[4u * lane + 2u], c3 = cntw[4u * lane + 3u];
+      const u32 sum = c0 + c1 + c2 + c3;
+      const u32 ex = wave_incl_add(sum) - sum;
+      wave_sync();
+      cntw[4u * lane] = ex; cntw[4u * lane + 1u] = ex + c0;
+      cntw[4u * lane + 2u] = ex + c0 + c1; cntw[4u * lane + 3u] = ex + c0 + c1 + c2;
+      wave_sync();
+    }
+    for (u32 j0 = cs; j0 < ce; j0 += 64u) {
+      const u32 j = j0 + lane;
+      if (j < ce) {
+        const u64 k = kin[j];
+        const u32 dst = cs + cntw[(u32)(k >> shift) & 255u] + B->ghn[j];
+        kout[dst] = k;
+        vout[dst] = vin[j];
+      }
+    }
+    wave_sync();
+    cur ^= 1u;
+  }
+  if (cur) {
+    for (u32 j = cs + lane; j < ce; j += 64u) { B->kA[j] = B->kB[j]; B->vA[j] = B->vB[j]; }
+    wave_sync();
+  }
+}
+
+/* Order the rows of chunk [cs, ce) (whole groups of equal top MSD_BITS, data in A) by their
+ * full keys.  Rows of short groups are placed by counting the smaller keys of their group;
+ * each long group is radix-sorted on its own.                                              */
+__device__ void wave_sort_chunk(batch_lds *B, u32 cs, u32 ce)
+{
+  const u32 lane = lane_id();
+  for (u32 j0 = cs; j0 < ce; j0 += 64u) {
+    const u32 j = j0 + lane;
+    if (j < ce) {
+      const u32 gs = B->gh[j], ge = B->gend[gs];
+      const u64 nk = B->kA[j];
+      u32 dst = j;
+      if (ge - gs <= COUNT_GROUP) {
+        dst = gs;
+        for (u32 q = gs; q < ge; q++) {
+          const u64 k = B->kA[q];
+          dst += (k < nk) || (k == nk && q < j);
+        }
+      }
+      B->kB[dst] = nk;
+      B->vB[dst] = B->vA[j];
+    }
+  }
+  wave_sync();
+  for (u32 j = cs + lane; j < ce; j += 64u) {
+    B->kA[j] = B->kB[j]; B->vA[j] = B->vB[j];
+    /* long groups go on the batch's work list; any wave may take them */
+    if (B->gh[j] == j && ((u32)B->gend[j] - j) > COUNT_GROUP) B->lgroup[atomicAdd(&B->nlong, 1u)] = (u16)j;
+  }
+  wave_sync();
+}
+
+/* Runs of rows whose keys agree after `>> sh`: fills gh (first row of the run), tied (run longer
+ * than one row) and gend (indexed by first row).  Returns via *maxrun the longest run and the
+ * number of tied rows of this thread.                                                      */
+__device__ u32 batch_runs(batch_lds *B, const u64 *kR, u32 cnt, u32 sh, u32 *maxrun, bwt_lds *S)
+{
+  const u32 j0 = threadIdx.x * SORT_IPT;
+  u32 headmask = 0, lasthead = 0, ntied = 0;
+#pragma unroll
+  for (u32 i = 0; i < SORT_IPT; i++) {
+    const u32 j = j0 + i;
+    if (j < cnt && (j == 0u || (kR[j] >> sh) != (kR[j - 1u] >> sh))) { headmask |= 1u << i; lasthead = j + 1u; }
+  }
+  u32 eh, d0, th, d1;
+  wg_excl_max_add(lasthead, 0u, &eh, &d0, &th, &d1, &S->sc);
+  u32 h1 = eh, longest = 0;
+#pragma unroll
+  for (u32 i = 0; i < SORT_IPT; i++) {
+    const u32 j = j0 + i;
+    if (j < cnt) {
+      const bool hd = (headmask >> i) & 1u;
+      if (hd) h1 = j + 1u;
+      const bool hn = (j + 1u >= cnt) || ((kR[j + 1u] >> sh) != (kR[j] >> sh));
+      const bool td = !(hd && hn);
+      B->gh[j] = (u16)(h1 - 1u);
+      B->tied[j] = td ? 1 : 0;
+      ntied += td;
+      if (hn) { B->gend[h1 - 1u] = (u16)(j + 1u); longest = (j + 2u - h1) > longest ? (j + 2u - h1) : longest; }
+    }
+  }
+  *maxrun = wg_max(longest, &S->sc);
+  return ntied;
+}
+
+/* Rank every tied row inside its run by keyarr (ties keep their current order), permute the
+ * values accordingly and split the runs at key changes.  Returns this thread's count of rows
+ * that are still tied.                                                                     */
+__device__ u32 batch_rank_round(batch_lds *B, const u64 *keyarr, u32 *vR, u32 *vX, u32 cnt)
+{
+  const u32 j0 = threadIdx.x * SORT_IPT;
+  u32 ntied = 0;
+#pragma unroll
+  for (u32 i = 0; i < SORT_IPT; i++) {
+    const u32 j = j0 + i;
+    if (j < cnt && B->tied[j]) {
+      const u32 gs = B->gh[j], ge = B->gend[gs];
+      const u64 nk = keyarr[j];
+      u32 less = 0, eqb = 0, eqt = 0;
+#pragma unroll 4
+      for (u32 q = gs; q < ge; q++) {
+        const u64 k = keyarr[q];
+        less += k < nk;
+        eqt += k == nk;
+        eqb += (k == nk) && (q < j);
+      }
+      const u32 dst = gs + less + eqb;
+      vX[dst] = vR[j];
+      B->ghn[dst] = (u16)(gs + less);
+      B->tiedn[dst] = eqt > 1u ? 1 : 0;
+      ntied += eqt > 1u;
+    }
+  }
+  __syncthreads();
+  u32 was = 0;
+#pragma unroll
+  for (u32 i = 0; i < SORT_IPT; i++) {
+    const u32 j = j0 + i;
+    if (j < cnt && B->tied[j]) { was |= 1u << i; vR[j] = vX[j]; B->gh[j] = B->ghn[j]; B->tied[j] = B->tiedn[j]; }
+  }
+  __syncthreads();
+#pragma unroll
+  for (u32 i = 0; i < SORT_IPT; i++) {
+    const u32 j = j0 + i;
+    if ((was >> i) & 1u) {
+      const u32 g = B->gh[j];
+      if (j + 1u >= cnt || B->gh[j + 1u] != g) B->gend[g] = (u16)(j + 1u);
+    }
+  }
+  __syncthreads();
+  return ntied;
+}
+
+/* Order rows [lo, lo+cnt) completely (as far as REFINE_ROUNDS reach) and emit them.
+ * presorted: rows already sorted by the full key (cut at key boundaries); otherwise they are
+ * only grouped by the partition's top MSD_BITS.  preloaded: the batch already sits in (kA,vA).
+ * Sets S->bc[8] if ties are left over.                                                      */
+__device__ void batch_process(const u8 *T, u32 n, u8 *bwt, lbz_block_meta *meta, bwt_slot s,
+                              bwt_lds *S, keycfg c, u32 lo, u32 cnt, bool presorted, bool preloaded)
+{
+  batch_lds *B = &S->u.B;
+  const u32 tid = threadIdx.x;
+  const u64 tb0 = wall_clock64();
+  if (!preloaded) {
+    for (u32 i = tid; i < cnt; i += LBZ_WG) { B->kA[i] = s.k0[lo + i]; B->vA[i] = s.v0[lo + i]; }
+    __syncthreads();
+  }
+  const u64 tb1 = wall_clock64();
+  u32 cur = 0, maxrun, ntied;
+  if (!presorted) {
+    if (preloaded) {                     /* a whole small block, in text order */
+      cur = lds_radix_sort(B, cnt, S);
+    } else {
+      /* groups of equal top MSD_BITS: wave w sorts the groups that start in its 256-row window */
+      ntied = batch_runs(B, B->kA, cnt, MSD_SHIFT, &maxrun, S);
+      const u64 tx1 = wall_clock64();
+      if (tid == 0) S->bc[14] += (u32)(tx1 - tb1);
+      if (maxrun > WAVE_GROUP) {
+        cur = lds_radix_sort(B, cnt, S);
+      } else {
+        const u32 w0 = wave_id() * 256u, w1 = w0 + 256u;
+        if (tid == 0) { B->nlong = 0; B->next_long = 0; }
+        __syncthreads();
+        if (w0 < cnt) {
+          const u32 cs = (B->gh[w0] == w0) ? w0 : B->gend[B->gh[w0]];
+          const u32 ce = (w1 >= cnt) ? cnt : ((B->gh[w1] == w1) ? w1 : B->gend[B->gh[w1]]);
+          if (cs < ce) wave_sort_chunk(B, cs, ce);
+        }
+        __syncthreads();
+        for (;;) {                                         /* long groups, one wave each */
+          u32 it = 0;
+          if (lane_id() == 0) it = atomicAdd(&B->next_long, 1u);
+          it = (u32)__shfl((int)it, 0);
+          if (it >= B->nlong) break;
+          const u32 gs = B->lgroup[it];
+          wave_radix_range(B, gs, B->gend[gs]);
+        }
+        __syncthreads();
+        if (tid == 0) S->bc[15] += (u32)(wall_clock64() - tx1);
+      }
+    }
+  }
+  ntied = batch_runs(B, cur ? B->kB : B->kA, cnt, 0u, &maxrun, S);
+  u64 *kX = cur ? B->kA : B->kB;
+  u32 *vR = cur ? B->vB : B->vA, *vX = cur ? B->vA : B->vB;
+  u32 anytied = wg_sum(ntied, &S->sc);
+  const u64 tb2 = wall_clock64();
+
+  const u32 j0 = tid * SORT_IPT;
+  u32 depth = c.sy;
+  for (u32 r = 0; r < REFINE_ROUNDS && anytied; r++) {
+    /* next sy symbols of every tied rotation */
+#pragma unroll
+    for (u32 i = 0; i < SORT_IPT; i++) {
+      const u32 j = j0 + i;
+      if (j < cnt && B->tied[j]) {
+        const u32 idx = vR[j] & 0x00FFFFFFu;
+        kX[j] = key_from_text(T, n, (idx + depth % n) % n, S->cmap, c);
+      }
+    }
+    __syncthreads();
+    ntied = batch_rank_round(B, kX, vR, vX, cnt);
+    anytied = wg_sum(ntied, &S->sc);
+    depth += c.sy;
+  }
+
+  const u64 tb3 = wall_clock64();
+#pragma unroll
+  for (u32 i = 0; i < SORT_IPT; i++) {
+    const u32 j = j0 + i;
+    if (j < cnt) {
+      const u32 v = vR[j];
+      const u32 idx = v & 0x00FFFFFFu;
+      const bool flagged = B->tied[j] && B->gh[j] != j;
+      bwt[lo + j] = (u8)(v >> 24);
+      s.sa[lo + j] = idx | (flagged ? TIE_FLAG : 0u);
+      if (idx == 0u) meta->bwt_idx = lo + j;
+    }
+  }
+  if (anytied && tid == 0) S->bc[8] = 1u;
+  __syncthreads();
+  if (tid == 0) {
+    S->bc[10] += (u32)(tb1 - tb0); S->bc[11] += (u32)(tb2 - tb1);
+    S->bc[12] += (u32)(tb3 - tb2); S->bc[13] += (u32)(wall_clock64() - tb3);
+  }
+}
+
+/* rows [lo,hi) share one 64-bit key: nothing an LDS batch can do for them */
+__device__ void emit_tied_rows(u8 *bwt, bwt_slot s, bwt_lds *S, u32 lo, u32 hi)
+{
+  for (u32 j = lo + threadIdx.x; j < hi; j += LBZ_WG) {
+    const u32 v = s.v0[j];
+    bwt[j] = (u8)(v >> 24);
+    s.sa[j] = (v & 0x00FFFFFFu) | (j > lo ? TIE_FLAG : 0u);
+  }
+  if (threadIdx.x == 0) S->bc[8] = 1u;
+  __syncthreads();
+}
+
+/* last q in (pos, e] with a key change after `>> sh` between rows q-1 and q; 0 if none */
+__device__ u32 find_cut(const u64 *keys, u32 pos, u32 e, u32 sh, bwt_lds *S)
+{
+  const u32 tid = threadIdx.x;
+  u32 found = 0;
+  for (u32 back = 0; back < BATCH_CAP && !found; back += LBZ_WG) {
+    u32 cand = 0;
+    if (e >= back + tid) {
+      const u32 q = e - back - tid;
+      if (q > pos && (keys[q] >> sh) != (keys[q - 1u] >> sh)) cand = q;
+    }
+    found = wg_max(cand, &S->sc);
+  }
+  return found;
+}
+
+/* first q in [from, hi) whose key differs from row pos after `>> sh`; hi if none */
+__device__ u32 find_run_end(const u64 *keys, u32 pos, u32 from, u32 hi, u32 sh, bwt_lds *S)
+{
+  const u64 k = keys[pos] >> sh;
+  for (u32 base = from; base < hi; base += LBZ_WG) {
+    const u32 q = base + threadIdx.x;
+    const u32 cand = (q < hi && (keys[q] >> sh) != k) ? q : 0xFFFFFFFFu;
+    const u32 f = wg_min(cand, &S->sc);
+    if (f != 0xFFFFFFFFu) return f;
+  }
+  return hi;
+}
+
+/* An oversized group [lo,hi) (> BATCH_CAP rows with equal top MSD_BITS): HBM radix sort on the
+ * remaining key bits, then batches cut at key boundaries (only ties are refined).           */
+__device__ void big_group(const u8 *T, u32 n, u8 *bwt, lbz_block_meta *meta, bwt_slot s,
+                          bwt_lds *S, keycfg c, u32 lo, u32 hi)
+{
+  const u32 tid = threadIdx.x;
+  const u32 m = hi - lo;
+  const u32 which = wg_radix_sort(s.k0 + lo, s.v0 + lo, s.k1 + lo, s.v1 + lo, m, MSD_SHIFT, S);
+  if (which) {
+    for (u32 i = tid; i < m; i += LBZ_WG) { s.k0[lo + i] = s.k1[lo + i]; s.v0[lo + i] = s.v1[lo + i]; }
+    __syncthreads();
+  }
+  u32 pos = lo;
+  while (pos < hi) {
+    u32 e = pos + BATCH_CAP < hi ? pos + BATCH_CAP : hi;
+    if (e < hi) {
+      const u32 cut = find_cut(s.k0, pos, e, 0u, S);
+      if (!cut) {
+        /* a run of > BATCH_CAP equal keys: leave it to the doubling */
+        const u32 end = find_run_end(s.k0, pos, e, hi, 0u, S);
+        emit_tied_rows(bwt, s, S, pos, end);
+        pos = end;
+        continue;
+      }
+      e = cut;
+    }
+    batch_process(T, n, bwt, meta, s, S, c, pos, e - pos, true, false);
+    pos = e;
+  }
+}
+
+__device__ void bwt_block(const u8 *T, u32 n, u8 *bwt, lbz_block_meta *meta, bwt_slot s, bwt_lds *S)
+{
+  const u32 tid = threadIdx.x;
+  if (n == 1u) {                              /* divbwt.c:1712 */
+    if (tid == 0) { bwt[0] = T[0]; meta->bwt_idx = 0; meta->periodic = 0; meta->rounds = 0; meta->sort_elems = 0; }
+    __syncthreads();
+    return;
+  }
+  const u64 tk0 = wall_clock64();
+
+  /* dense symbol codes and the key geometry */
+  u32 ninuse;
+  {
+    const u32 f = (tid < 256u && meta->inuse[tid]) ? 1u : 0u;
+    const u32 ex = wg_excl_add(f, &ninuse, &S->sc);
+    if (tid < 256u) S->cmap[tid] = (u8)ex;
+  }
+  keycfg c;
+  c.b = 1u;
+  while ((1u << c.b) < ninuse) c.b++;
+  c.sy = 64u / c.b;
+  if (c.sy > MAX_SYMS) c.sy = MAX_SYMS;
+  c.pad = 64u - c.b * c.sy;
+  if (tid == 0) { S->bc[8] = 0; meta->periodic = 0; for (u32 i = 9; i < 16; i++) S->bc[i] = 0; }
+  __syncthreads();
+
+  if (n <= BATCH_CAP) {
+    batch_lds *B = &S->u.B;
+    for (u32 i = tid; i < n; i += LBZ_WG) {
+      B->kA[i] = key_from_text(T, n, i, S->cmap, c);
+      B->vA[i] = ((u32)T[i ? i - 1u : n - 1u] << 24) | i;
+    }
+    __syncthreads();
+    batch_process(T, n, bwt, meta, s, S, c, 0u, n, false, true);
+  } else {
+    /* ---- partition on the key's top 24 bits: k0 <- text, k1 <- k0, k0 <- k1 ---- */
+    part_lds *P = &S->u.P;
+    for (u32 i = tid; i < 3u * 256u; i += LBZ_WG) (&P->hist[0][0])[i] = 0;
+    __syncthreads();
+    msd_text_pass<false>(T, n, c, 0u, nullptr, nullptr, S);
+    load_digit_offsets(P->hist[0], P->dbase, S);
+    msd_text_pass<true>(T, n, c, MSD_SHIFT, s.k0, s.v0, S);
+    load_digit_offsets(P->hist[1], P->dbase, S);
+    msd_array_pass(s.k0, s.v0, n, MSD_SHIFT + 8u, s.k1, s.v1, S);
+    load_digit_offsets(P->hist[2], P->dbase, S);
+    msd_array_pass(s.k1, s.v1, n, MSD_SHIFT + 16u, s.k0, s.v0, S);
+    if (tid == 0) S->bc[9] = (u32)(wall_clock64() - tk0);
+    __syncthreads();
+
+    /* ---- batches of whole groups ---- */
+    u32 pos = 0;
+    while (pos < n) {
+      u32 e = pos + BATCH_CAP < n ? pos + BATCH_CAP : n;
+      if (e < n) {
+        const u32 cut = find_cut(s.k0, pos, e, MSD_SHIFT, S);
+        if (!cut) {
+          const u32 end = find_run_end(s.k0, pos, e, n, MSD_SHIFT, S);
+          big_group(T, n, bwt, meta, s, S, c, pos, end);
+          pos = end;
+          continue;
+        }
+        e = cut;
+      }
+      batch_process(T, n, bwt, meta, s, S, c, pos, e - pos, false, false);
+      pos = e;
+    }
+  }
+  const u64 tk1 = wall_clock64();
+  __syncthreads();
+  u32 rounds = 0, work = 0;
+  if (S->bc[8]) finish_by_doubling(T, n, bwt, meta, s, S, c.sy, &rounds, &work);
+  if (tid == 0) {
     meta->rounds = rounds;
-    meta->sort_elems = work;
+    meta->sort_elems = n + work;
+    meta->ticks[0] = (u32)(tk1 - tk0);
+    meta->ticks[1] = (u32)(wall_clock64() - tk1);
+    for (u32 i = 0; i < 5; i++) meta->ticks[2 + i] = S->bc[9 + i];   /* partition, load, sort, refine, emit */
+    meta->ticks[7] = S->bc[15]; meta->ticks[1] = S->bc[14];              /* wave chunk sort; first batch_runs */
   }
   __syncthreads();
 }
 
 /* grid = number of workspace slots (persistent workgroups).  Queue order: all primary
  * blocks first (the big ones), then the spill blocks.                                    */
-__global__ void __launch_bounds__(LBZ_WG)
+__global__ void __launch_bounds__(LBZ_WG, 4)   /* 4 waves per SIMD = two workgroups per CU */
 k_bwt(const u8 *Tbase, u8 *Bbase, lbz_block_meta *meta, lbz_layout L,
       u32 nslabs, u32 *queue, u8 *ws, u64 slot_bytes)
 {

@@ -38,6 +38,62 @@ __device__ __forceinline__ u32 zrun_digits(u32 z)          /* floor(log2(z+1)) *
   return 31u - (u32)__clz(z + 1u);
 }
 
+/* MTF ranks of one wave's slice [lo, hi).  Lane l holds the "last seen at" position of
+ * symbols l, l+64, ... in NQ registers.  Per run head: two scalar lane reads (symbol, its
+ * last position), NQ ballots + popcounts, one predicated update -- everything but the
+ * compares stays on the scalar unit.  Loads of the next 64 positions are issued before the
+ * current 64 are walked.                                                                  */
+template <int NQ>
+__device__ __forceinline__ void mtf_ranks(const u8 *bwt, u8 *rk, u32 lo, u32 hi, mtf_lds *S)
+{
+  const u32 lane = lane_id(), w = wave_id();
+  int Lq[NQ];
+#pragma unroll
+  for (int q = 0; q < NQ; q++) Lq[q] = S->last[w][lane + 64u * q];
+
+  u32 nb = (lo + lane < hi) ? bwt[lo + lane] : 0u;
+  u32 nbp = (lo + lane < hi && lo + lane > 0u) ? bwt[lo + lane - 1u] : 0u;
+  for (u32 b0 = lo; b0 < hi; b0 += 64u) {
+    const u32 p = b0 + lane;
+    const bool ok = p < hi;
+    const u32 byte = nb, bytep = nbp;
+    const u32 pn = p + 64u;                               /* prefetch the next group */
+    nb = (pn < hi) ? bwt[pn] : 0u;
+    nbp = (pn < hi) ? bwt[pn - 1u] : 0u;
+    const int c = ok ? (int)S->cmap[byte] : 0;
+    const int cprev = (ok && p > 0u) ? (int)S->cmap[bytep] : -1;
+    u64 heads = __ballot(ok && c != cprev);
+    u32 myrank = 0;
+    while (heads) {
+      const int l = (int)__ffsll((long long)heads) - 1;
+      heads &= heads - 1ull;
+      const int s = __builtin_amdgcn_readlane(c, l);
+      const int owner = s & 63;
+      int pv;
+      if (NQ == 1) pv = __builtin_amdgcn_readlane(Lq[0], owner);
+      else {
+        const int q = s >> 6;
+        int mine = Lq[0];
+#pragma unroll
+        for (int j = 1; j < NQ; j++) mine = (q == j) ? Lq[j] : mine;
+        pv = __builtin_amdgcn_readlane(mine, owner);
+      }
+      u32 cnt = 0;
+#pragma unroll
+      for (int j = 0; j < NQ; j++) cnt += (u32)__popcll(__ballot(Lq[j] > pv));
+      if ((int)lane == l) myrank = cnt;
+      const int np = (int)b0 + l;
+      if (NQ == 1) { if ((int)lane == owner) Lq[0] = np; }
+      else {
+        const int q = s >> 6;
+#pragma unroll
+        for (int j = 0; j < NQ; j++) if ((int)lane == owner && q == j) Lq[j] = np;
+      }
+    }
+    if (ok) rk[p] = (u8)myrank;
+  }
+}
+
 __global__ void __launch_bounds__(LBZ_WG)
 k_mtf(const u8 *Bbase, u8 *Rbase, u16 *Vbase, u32 *freq_out, lbz_block_meta *meta, lbz_layout L)
 {
@@ -69,9 +125,15 @@ k_mtf(const u8 *Bbase, u8 *Rbase, u16 *Vbase, u32 *freq_out, lbz_block_meta *met
   const u32 lo = w * cs < n ? w * cs : n;
   const u32 hi = lo + cs < n ? lo + cs : n;
 
-  for (u32 b0 = lo; b0 < hi; b0 += 64u) {
-    const u32 p = b0 + lane;
-    if (p < hi) atomicMax(&S.last[w][S.cmap[bwt[p]]], (int)p);
+  for (u32 b0 = lo; b0 < hi; b0 += 256u) {
+    u32 by[4];
+#pragma unroll
+    for (u32 k = 0; k < 4u; k++) { const u32 p = b0 + 64u * k + lane; by[k] = p < hi ? bwt[p] : 0u; }
+#pragma unroll
+    for (u32 k = 0; k < 4u; k++) {
+      const u32 p = b0 + 64u * k + lane;
+      if (p < hi) atomicMax(&S.last[w][S.cmap[by[k]]], (int)p);
+    }
   }
   __syncthreads();
   if (tid < 256u) {
@@ -85,35 +147,10 @@ k_mtf(const u8 *Bbase, u8 *Rbase, u16 *Vbase, u32 *freq_out, lbz_block_meta *met
   }
   __syncthreads();
 
-  /* ranks at run heads, wave-serial over heads */
-  {
-    int L0 = S.last[w][lane], L1 = S.last[w][lane + 64u];
-    int L2 = S.last[w][lane + 128u], L3 = S.last[w][lane + 192u];
-    for (u32 b0 = lo; b0 < hi; b0 += 64u) {
-      const u32 p = b0 + lane;
-      const bool ok = p < hi;
-      const int c = ok ? (int)S.cmap[bwt[p]] : 0;
-      const int cprev = (ok && p > 0u) ? (int)S.cmap[bwt[p - 1u]] : -1;
-      u64 heads = __ballot(ok && c != cprev);
-      u32 myrank = 0;
-      while (heads) {
-        const u32 l = (u32)__ffsll((long long)heads) - 1u;
-        heads &= heads - 1ull;
-        const int s = __shfl(c, (int)l);
-        const u32 q = (u32)s >> 6, owner = (u32)s & 63u;
-        const int mine = q == 0u ? L0 : q == 1u ? L1 : q == 2u ? L2 : L3;
-        const int pv = __shfl(mine, (int)owner);
-        const u32 cnt = (u32)__popcll(__ballot(L0 > pv)) + (u32)__popcll(__ballot(L1 > pv))
-                      + (u32)__popcll(__ballot(L2 > pv)) + (u32)__popcll(__ballot(L3 > pv));
-        if (lane == l) myrank = cnt;
-        if (lane == owner) {
-          const int np = (int)(b0 + l);
-          if (q == 0u) L0 = np; else if (q == 1u) L1 = np; else if (q == 2u) L2 = np; else L3 = np;
-        }
-      }
-      if (ok) rk[p] = (u8)myrank;
-    }
-  }
+  /* ranks at run heads, wave-serial over heads; NQ = registers needed for the alphabet */
+  if (tot_inuse <= 64u) mtf_ranks<1>(bwt, rk, lo, hi, &S);
+  else if (tot_inuse <= 128u) mtf_ranks<2>(bwt, rk, lo, hi, &S);
+  else mtf_ranks<4>(bwt, rk, lo, hi, &S);
   __syncthreads();
 
   /* zero-run coding + histogram */

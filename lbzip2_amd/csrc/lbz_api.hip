@@ -62,11 +62,11 @@ struct lbzamd_ctx {
 static int ctx_free(lbzamd_ctx *c)
 {
   if (!c) return 0;
-  hipFree(c->T); hipFree(c->B); hipFree(c->R); hipFree(c->O); hipFree(c->ws); hipFree(c->V);
-  hipFree(c->freq); hipFree(c->queue); hipFree(c->offs); hipFree(c->meta); hipFree(c->st);
-  hipFree(c->d_in); hipFree(c->d_out);
-  for (auto &e : c->ev) if (e) hipEventDestroy(e);
-  if (c->stream) hipStreamDestroy(c->stream);
+  (void)hipFree(c->T); (void)hipFree(c->B); (void)hipFree(c->R); (void)hipFree(c->O); (void)hipFree(c->ws); (void)hipFree(c->V);
+  (void)hipFree(c->freq); (void)hipFree(c->queue); (void)hipFree(c->offs); (void)hipFree(c->meta); (void)hipFree(c->st);
+  (void)hipFree(c->d_in); (void)hipFree(c->d_out);
+  for (auto &e : c->ev) if (e) (void)hipEventDestroy(e);
+  if (c->stream) (void)hipStreamDestroy(c->stream);
   delete c;
   return 0;
 }
@@ -96,7 +96,7 @@ extern "C" int lbzamd_create(lbzamd_ctx **out, int device, unsigned bs100k, unsi
   c->L.out_b = round_up(c->L.cap_b + c->L.cap_b / 8u + 4096u, 256u);
   if (nslots == 0) {
     const char *env = getenv("LBZAMD_SLOTS");
-    nslots = env ? (unsigned)atoi(env) : (unsigned)prop.multiProcessorCount;
+    nslots = env ? (unsigned)atoi(env) : 2u * (unsigned)prop.multiProcessorCount;
     if (nslots == 0) nslots = 1;
   }
   if (nslots > 2u * max_slabs) nslots = 2u * max_slabs;
@@ -149,7 +149,7 @@ static int run_chunk(lbzamd_ctx *c, const u8 *d_in, size_t len, uint32_t nsl, in
   if (upto >= 1) {
     HIPCHK(hipMemsetAsync(c->queue, 0, 256, s));
     const uint32_t grid = c->nslots < nblk ? c->nslots : nblk;
-    hipLaunchKernelGGL(k_bwt, dim3(grid), dim3(LBZ_WG), 0, s, (const u8 *)c->T, c->B, c->meta, c->L,
+    hipLaunchKernelGGL(k_bwt, dim3(grid), dim3(LBZ_BWT_WG), 0, s, (const u8 *)c->T, c->B, c->meta, c->L,
                        nsl, c->queue, c->ws, (u64)c->slot_bytes);
   }
   HIPCHK(hipEventRecord(c->ev[2], s));
@@ -234,12 +234,12 @@ extern "C" int lbzamd_compress_device(lbzamd_ctx *c, const void *d_in_v, size_t 
 static int ensure_staging(lbzamd_ctx *c, size_t in_bytes, size_t out_bytes)
 {
   if (in_bytes > c->d_in_cap) {
-    hipFree(c->d_in); c->d_in = nullptr; c->d_in_cap = 0;
+    (void)hipFree(c->d_in); c->d_in = nullptr; c->d_in_cap = 0;
     HIPCHK(hipMalloc((void **)&c->d_in, in_bytes + 256));
     c->d_in_cap = in_bytes;
   }
   if (out_bytes > c->d_out_cap) {
-    hipFree(c->d_out); c->d_out = nullptr; c->d_out_cap = 0;
+    (void)hipFree(c->d_out); c->d_out = nullptr; c->d_out_cap = 0;
     HIPCHK(hipMalloc((void **)&c->d_out, out_bytes + 256));
     c->d_out_cap = out_bytes;
   }
@@ -296,6 +296,7 @@ extern "C" int lbzamd_block_info_get(lbzamd_ctx *c, uint32_t blk, lbzamd_block_i
   info->n = m.n; info->crc = m.crc; info->consumed = m.consumed; info->bwt_idx = m.bwt_idx;
   info->periodic = m.periodic; info->nmtf = m.nmtf; info->alpha = m.alpha; info->num_trees = m.num_trees;
   info->num_sel = m.num_sel; info->out_len = m.out_len; info->err = m.err; info->rounds = m.rounds;
+  info->sort_elems = m.sort_elems; for (int i = 0; i < 8; i++) info->ticks[i] = m.ticks[i];
   memcpy(info->inuse, m.inuse, 256);
   return 0;
 }
@@ -402,8 +403,8 @@ extern "C" size_t lbzamd_encode(encoder_state *e, uint32_t *crc)
   hipStream_t s = c->stream;
   /* the slab is resident and collected; run the remaining stages on its primary block only */
   if (hipSetDevice(c->device) != hipSuccess) die("encode");
-  hipMemsetAsync(c->queue, 0, 256, s);
-  hipLaunchKernelGGL(k_bwt, dim3(1), dim3(LBZ_WG), 0, s, (const u8 *)c->T, c->B, c->meta, c->L, 1u, c->queue, c->ws, (u64)c->slot_bytes);
+  (void)hipMemsetAsync(c->queue, 0, 256, s);
+  hipLaunchKernelGGL(k_bwt, dim3(1), dim3(LBZ_BWT_WG), 0, s, (const u8 *)c->T, c->B, c->meta, c->L, 1u, c->queue, c->ws, (u64)c->slot_bytes);
   hipLaunchKernelGGL(k_mtf, dim3(1), dim3(LBZ_WG), 0, s, (const u8 *)c->B, c->R, c->V, c->freq, c->meta, c->L);
   hipLaunchKernelGGL(k_encode, dim3(1), dim3(LBZ_WG), 0, s, (const u16 *)c->V, (const u32 *)c->freq, c->O, c->meta, c->L);
   if (hipStreamSynchronize(s) != hipSuccess || hipGetLastError() != hipSuccess) { g_err = "kernel failure"; die("encode"); }

@@ -28,6 +28,7 @@
 #define LBZ_WG 1024
 #endif
 #define LBZ_NW (LBZ_WG / 64)
+#define LBZ_BWT_WG 512       /* the BWT kernel's own geometry: 8 waves, two workgroups per CU */
 
 /* Per-block record in HBM.  Blocks are numbered 2*slab (primary) and 2*slab+1 (spill). */
 typedef struct lbz_block_meta {
@@ -44,7 +45,7 @@ typedef struct lbz_block_meta {
   uint32_t err;        /* non-zero: internal capacity problem */
   uint32_t rounds;     /* prefix-doubling rounds run (diagnostic) */
   uint32_t sort_elems; /* sum of elements passed through the radix sorter (diagnostic) */
-  uint32_t pad_[3];
+  uint32_t ticks[8];   /* wall_clock64 ticks: first sort, first regroup, doubling rounds (diagnostic) */
   uint8_t  inuse[256]; /* used-byte map (encode.c:63) */
 } lbz_block_meta;
 
@@ -79,7 +80,8 @@ size_t lbz_out_off(const lbz_layout L, uint32_t blk)
 
 /* BWT workspace of one resident workgroup ("slot"), elements of capacity cap_a:
  *   k0,k1 : u64 sort keys (ping-pong)      v0,v1 : u32 sort values (ping-pong)
- *   sufx,grp,pos : u32 active-list columns  sa,isa : u32 suffix array and ranks      */
-#define LBZ_BWT_SLOT_BYTES(cap) ((size_t)(cap) * (8u * 2u + 4u * 2u + 4u * 5u))
+ *   sufx,grp,pos : u32 active-list columns  sa,isa : u32 suffix array and ranks
+ *   gb : 32769 u32 bucket starts                                                      */
+#define LBZ_BWT_SLOT_BYTES(cap) ((size_t)(cap) * (8u * 2u + 4u * 2u + 4u * 5u) + 33024u * 4u)
 
 #endif

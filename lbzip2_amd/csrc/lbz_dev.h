@@ -138,6 +138,44 @@ __device__ __forceinline__ u32 wg_min(u32 v, wg_scratch *sc)
   return r;
 }
 
+__device__ __forceinline__ u32 wg_max(u32 v, wg_scratch *sc)
+{
+  const u32 l = lane_id(), w = wave_id();
+  v = wave_max(v);
+  if (l == 0) sc->a[w] = v;
+  __syncthreads();
+  u32 r = sc->a[0];
+#pragma unroll
+  for (u32 i = 1; i < LBZ_NW; i++) { u32 o = sc->a[i]; if (o > r) r = o; }
+  __syncthreads();
+  return r;
+}
+
+/* OR and AND of a 64-bit value over the workgroup (which key bytes vary at all?) */
+__device__ __forceinline__ void wg_or_and64(u64 v_or, u64 v_and, u64 *r_or, u64 *r_and, wg_scratch *sc)
+{
+  const u32 l = lane_id(), w = wave_id();
+#pragma unroll
+  for (u32 d = 32; d >= 1; d >>= 1) {
+    v_or |= __shfl_xor(v_or, (int)d);
+    v_and &= __shfl_xor(v_and, (int)d);
+  }
+  if (l == 0) { sc->a[w] = (u32)v_or; sc->b[w] = (u32)(v_or >> 32); }
+  __syncthreads();
+  u64 o = 0;
+#pragma unroll
+  for (u32 i = 0; i < LBZ_NW; i++) o |= (u64)sc->a[i] | ((u64)sc->b[i] << 32);
+  __syncthreads();
+  if (l == 0) { sc->a[w] = (u32)v_and; sc->b[w] = (u32)(v_and >> 32); }
+  __syncthreads();
+  u64 a = ~0ull;
+#pragma unroll
+  for (u32 i = 0; i < LBZ_NW; i++) a &= (u64)sc->a[i] | ((u64)sc->b[i] << 32);
+  __syncthreads();
+  *r_or = o;
+  *r_and = a;
+}
+
 __device__ __forceinline__ u32 wg_sum(u32 v, wg_scratch *sc)
 {
   const u32 l = lane_id(), w = wave_id();

@@ -67,6 +67,7 @@ static inline void __builtin_amdgcn_s_barrier() { emu::sync_block(); }
 static inline void __threadfence() { std::atomic_thread_fence(std::memory_order_seq_cst); }
 static inline void __threadfence_block() {}
 static inline void __builtin_amdgcn_s_sleep(int) {}
+static inline unsigned long long wall_clock64() { return 0; }
 
 static inline unsigned long long __ballot(int pred) { return emu::wave_ballot(pred); }
 static inline int __any(int pred) { return emu::wave_ballot(pred) != 0; }

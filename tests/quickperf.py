@@ -1,23 +1,35 @@
+"""Ad-hoc GPU timing helper (not a test): per-kernel ms and BWT phase ticks."""
 import sys, time
 sys.path.insert(0, "/root/repo"); sys.path.insert(0, "/root/repo/tests")
 import torch, lbzip2_amd
-import oracle_lib as L
+import ctypes as C
 lib = lbzip2_amd.library()
-for kind, n in (("text", 115_200_000), ("rand", 57_600_000)):
-    data = (L.gen_text if kind == "text" else L.gen_rand)(n, 2)
-    src = torch.frombuffer(bytearray(data), dtype=torch.uint8).cuda()
+g = C.CDLL("/root/repo/lbzip2_amd/host/libgen_inputs.so")
+def gen(kind, n, seed):
+    buf = bytearray(n); cb = (C.c_uint8 * n).from_buffer(buf)
+    f = g.lbzgen_text if kind == "text" else g.lbzgen_rand
+    f.argtypes = [C.c_void_p, C.c_size_t, C.c_uint32]; f(cb, n, seed); del cb
+    return buf
+slabs = int(sys.argv[1]) if len(sys.argv) > 1 else 512
+for kind in ("text", "rand"):
+    n = slabs * 900000
+    data = gen(kind, n, 2)
+    src = torch.frombuffer(data, dtype=torch.uint8).cuda()
     dst = torch.empty(lib.bound(n), dtype=torch.uint8, device="cuda")
     for slots in (256, 512):
-        try:
-            ctx = lib.context(9, 128, slots)
-        except Exception as e:
-            print("slots", slots, e); continue
+        ctx = lib.context(9, slabs, slots)
         for it in range(2):
             t = time.time()
             m = ctx.compress_device(src.data_ptr(), n, dst.data_ptr(), dst.numel())
             dt = time.time() - t
             s = ctx.stats()
-            print(f"{kind} n={n} slots={slots} it={it}: {n/dt/1e6:.1f} MB/s out={m} blocks={s.nblocks} "
-                  f"ms: collect={s.ms_collect:.1f} bwt={s.ms_bwt:.1f} mtf={s.ms_mtf:.1f} enc={s.ms_encode:.1f} fin={s.ms_finish:.1f} "
-                  f"sort_elems/n_rle={s.sort_elems/max(1,s.n_rle):.2f}", flush=True)
+        print(f"{kind} slabs={slabs} slots={slots}: {n/dt/1e6:.1f} MB/s ms: collect={s.ms_collect:.1f} bwt={s.ms_bwt:.1f} "
+              f"mtf={s.ms_mtf:.1f} enc={s.ms_encode:.1f} fin={s.ms_finish:.1f} sort/n={s.sort_elems/max(1,s.n_rle):.2f}", flush=True)
+        tk = [0] * 8; cnt = 0
+        for b in range(0, min(2 * slabs, 64), 2):
+            bi = ctx.block_info(b)
+            for i in range(8): tk[i] += bi.ticks[i]
+            cnt += 1
+        print("   mean ms/blk: msd=%.2f runs1=%.2f | partition=%.2f load=%.2f ldssort=%.2f refine=%.2f emit=%.2f chunksort=%.2f (rounds=%d)"
+              % tuple([t / cnt / 1e5 for t in tk[:8]] + [bi.rounds]), flush=True)
         ctx.close()
