@@ -80,6 +80,7 @@ typedef struct lbzamd_stats {
   uint32_t nblocks;
   uint32_t nperiodic;   /* exactly periodic blocks (origin pointer = smallest equal row) */
   float ms_collect, ms_bwt, ms_mtf, ms_encode, ms_finish, ms_total;  /* device time, HIP events */
+  float ms_bwt_part, ms_bwt_batch, ms_bwt_fix;   /* the BWT stage's three kernels (sum = ms_bwt) */
 } lbzamd_stats;
 
 /* device < 0: current device.  max_slabs: slabs resident at once (input beyond that is

@@ -34,7 +34,8 @@ class Stats(C.Structure):
                 ("n_out", C.c_uint64), ("sort_elems", C.c_uint64),
                 ("nblocks", C.c_uint32), ("nperiodic", C.c_uint32),
                 ("ms_collect", C.c_float), ("ms_bwt", C.c_float), ("ms_mtf", C.c_float),
-                ("ms_encode", C.c_float), ("ms_finish", C.c_float), ("ms_total", C.c_float)]
+                ("ms_encode", C.c_float), ("ms_finish", C.c_float), ("ms_total", C.c_float),
+                ("ms_bwt_part", C.c_float), ("ms_bwt_batch", C.c_float), ("ms_bwt_fix", C.c_float)]
 
 
 class BlockInfo(C.Structure):

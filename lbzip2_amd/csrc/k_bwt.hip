@@ -34,8 +34,9 @@
  * Algorithmic traffic of the stage as priced in SURVEY.md 8(d): read T (1) + write SA (4) +
  * read SA (4) + gather T (1) + write BWT (1) = 11 B per block byte.
  */
-/* This kernel runs 512-thread workgroups (8 waves) with 2048-row batches: 73 KB of LDS, so
- * two blocks share a CU and cover each other's barrier and LDS latencies.                */
+/* The kernel's geometry is its own constant: with LBZ_BWT_WG = 512 (8 waves, 2048-row batches,
+ * 73 KB of LDS) two blocks share a CU; measured throughput is the same as one 1024-thread
+ * workgroup per CU (the stage is bound by LDS instruction throughput, not by latency).    */
 #include "lbz_common.h"
 #undef LBZ_WG
 #define LBZ_WG LBZ_BWT_WG
@@ -57,16 +58,16 @@
 #define TIE_FLAG 0x80000000u
 static_assert(BATCH_CAP == LBZ_WG * 4u, "a batch is one 4-rows-per-thread tile");
 
-struct glb_sort_lds {                   /* HBM radix sorter */
+struct sort_lds {                       /* HBM radix passes (partition, oversized groups, doubling) */
   u32 hist[8][256];
   u32 wcnt[LBZ_NW][256];
-  u32 dbase[256];
-};
-struct part_lds {                       /* MSD partition passes */
-  u32 hist[3][256];
-  u32 wcnt[LBZ_NW][256];
-  u32 dbase[256];
-  u8 tile[SORT_TILE + PART_HALO + 16u];
+  u32 dbase[256];                       /* running global offset of every digit */
+  u32 toff[256];                        /* digit offsets inside the current tile */
+  u32 gdelta[256];                      /* global offset minus tile offset */
+  u32 wtot[8];
+  u64 stage_k[SORT_TILE];               /* the tile, regrouped by digit, before it is written */
+  u32 stage_v[SORT_TILE];
+  u32 tile[(SORT_TILE + PART_HALO + 16u) / 4u];
 };
 struct batch_lds {                      /* one batch resident in LDS */
   u64 kA[BATCH_CAP], kB[BATCH_CAP];
@@ -82,10 +83,10 @@ struct batch_lds {                      /* one batch resident in LDS */
 struct bwt_lds {
   wg_scratch sc;
   u32 bc[16];
-  u8 cmap[256];
+  u8 cmap[256];                       /* byte -> dense code */
+  u8 inv[256];                        /* dense code -> byte */
   union {
-    glb_sort_lds G;
-    part_lds P;
+    sort_lds X;
     batch_lds B;
   } u;
 };
@@ -134,12 +135,17 @@ __device__ __forceinline__ u64 match_digit(u32 d, bool ok)
   return ((u64)hi << 32) | lo;
 }
 
+struct sort_lds;
+__device__ __forceinline__ void radix_tile_scatter_hbm(sort_lds *X, const unsigned long long (&key)[4], const unsigned int (&val)[4],
+                                                       unsigned int okmask, unsigned int shift,
+                                                       unsigned long long *kout, unsigned int *vout);
+
 /* ======================================================================= HBM radix sorter
  * Stable LSD radix sort of m (key,value) pairs on key bits [0, nbits).  Input in (k0,v0);
  * returns 0 if the sorted result is in (k0,v0), 1 if in (k1,v1).                        */
 __device__ u32 wg_radix_sort(u64 *k0, u32 *v0, u64 *k1, u32 *v1, u32 m, u32 nbits, bwt_lds *S)
 {
-  glb_sort_lds *G = &S->u.G;
+  sort_lds *G = &S->u.X;
   const u32 tid = threadIdx.x, lane = lane_id(), w = wave_id();
   const u32 npass = (nbits + 7u) / 8u;
 
@@ -171,54 +177,19 @@ __device__ u32 wg_radix_sort(u64 *k0, u32 *v0, u64 *k1, u32 *v1, u32 m, u32 nbit
     u32 *vout = cur ? v0 : v1;
 
     for (u32 t0 = 0; t0 < m; t0 += SORT_TILE) {
-      for (u32 i = tid; i < LBZ_NW * 256u; i += LBZ_WG) (&G->wcnt[0][0])[i] = 0;
-      __syncthreads();
       u64 key[SORT_IPT];
-      u32 val[SORT_IPT], rnk[SORT_IPT];
+      u32 val[SORT_IPT], okmask = 0;
       const u32 wbase = t0 + w * 64u * SORT_IPT;
 #pragma unroll
       for (u32 k = 0; k < SORT_IPT; k++) {
         const u32 i = wbase + k * 64u + lane;
         key[k] = i < m ? kin[i] : 0ull;
         val[k] = i < m ? vin[i] : 0u;
+        if (i < m) okmask |= 1u << k;
       }
-#pragma unroll
-      for (u32 k = 0; k < SORT_IPT; k++) {
-        const u32 i = wbase + k * 64u + lane;
-        const bool ok = i < m;
-        const u32 d = (u32)(key[k] >> shift) & 255u;
-        const u64 mask = match_digit(d, ok);
-        const u32 below = (u32)__popcll(mask & lanes_below());
-        const u32 prev = ok ? G->wcnt[w][d] : 0u;
-        wave_sync();
-        if (ok && below == 0u) G->wcnt[w][d] = prev + (u32)__popcll(mask);
-        wave_sync();
-        rnk[k] = prev + below;
-      }
-      __syncthreads();
-      if (tid < 256u) {
-        u32 run = G->dbase[tid];
-#pragma unroll
-        for (u32 w2 = 0; w2 < LBZ_NW; w2++) {
-          const u32 t = G->wcnt[w2][tid];
-          G->wcnt[w2][tid] = run;
-          run += t;
-        }
-        G->dbase[tid] = run;
-      }
-      __syncthreads();
-#pragma unroll
-      for (u32 k = 0; k < SORT_IPT; k++) {
-        const u32 i = wbase + k * 64u + lane;
-        if (i < m) {
-          const u32 d = (u32)(key[k] >> shift) & 255u;
-          const u32 dst = G->wcnt[w][d] + rnk[k];
-          kout[dst] = key[k];
-          vout[dst] = val[k];
-        }
-      }
-      __syncthreads();
+      radix_tile_scatter_hbm(G, key, val, okmask, shift, kout, vout);
     }
+    __syncthreads();
     cur ^= 1u;
   }
   return cur;
@@ -377,7 +348,8 @@ __device__ __forceinline__ u64 key_from_text(const u8 *T, u32 n, u32 start, cons
 
 /* One stable counting-sort step of a 4096-row tile on digit (key >> shift) & 255: rows are
  * held wave-striped (row = wbase + k*64 + lane), ranks inside a wave come from ballots, the
- * per-wave counters and the running digit offsets (dbase) live in LDS.                     */
+ * per-wave counters and the running digit offsets (dbase) live in LDS.  Its barriers order
+ * LDS only: the scattered rows are not read again before the next full barrier.          */
 __device__ __forceinline__ void radix_tile_scatter(u32 (*wcnt)[256], u32 *dbase, const u64 (&key)[SORT_IPT],
                                                    const u32 (&val)[SORT_IPT], u32 okmask, u32 shift,
                                                    u64 *kout, u32 *vout)
@@ -385,7 +357,7 @@ __device__ __forceinline__ void radix_tile_scatter(u32 (*wcnt)[256], u32 *dbase,
   const u32 tid = threadIdx.x, w = wave_id();
   u32 rnk[SORT_IPT];
   for (u32 i = tid; i < LBZ_NW * 256u; i += LBZ_WG) (&wcnt[0][0])[i] = 0;
-  __syncthreads();
+  wg_lds_barrier();
 #pragma unroll
   for (u32 k = 0; k < SORT_IPT; k++) {
     const bool ok = (okmask >> k) & 1u;
@@ -398,7 +370,7 @@ __device__ __forceinline__ void radix_tile_scatter(u32 (*wcnt)[256], u32 *dbase,
     wave_sync();
     rnk[k] = prev + below;
   }
-  __syncthreads();
+  wg_lds_barrier();
   if (tid < 256u) {
     u32 run = dbase[tid];
 #pragma unroll
@@ -409,7 +381,7 @@ __device__ __forceinline__ void radix_tile_scatter(u32 (*wcnt)[256], u32 *dbase,
     }
     dbase[tid] = run;
   }
-  __syncthreads();
+  wg_lds_barrier();
 #pragma unroll
   for (u32 k = 0; k < SORT_IPT; k++) {
     if ((okmask >> k) & 1u) {
@@ -419,76 +391,186 @@ __device__ __forceinline__ void radix_tile_scatter(u32 (*wcnt)[256], u32 *dbase,
       vout[dst] = val[k];
     }
   }
-  __syncthreads();
+  wg_lds_barrier();
 }
 
-/* A pass over the block text through the LDS tile, keys built on the fly.
- * SCATTER = false: histogram the three partition digits of every rotation;
- * SCATTER = true : first partition pass (digit at `shift`) straight from the text.          */
-template <bool SCATTER>
-__device__ void msd_text_pass(const u8 *T, u32 n, keycfg c, u32 shift, u64 *kout, u32 *vout, bwt_lds *S)
+/* The same step for an HBM destination: ranks as above, then the tile is regrouped by digit
+ * in LDS and written out by consecutive threads, so that each wave store covers a few runs of
+ * consecutive addresses instead of 64 scattered rows.                                      */
+__device__ __forceinline__ void radix_tile_scatter_hbm(sort_lds *X, const u64 (&key)[SORT_IPT],
+                                                       const u32 (&val)[SORT_IPT], u32 okmask, u32 shift,
+                                                       u64 *kout, u32 *vout)
 {
-  part_lds *P = &S->u.P;
   const u32 tid = threadIdx.x, lane = lane_id(), w = wave_id();
-  for (u32 t0 = 0; t0 < n; t0 += SORT_TILE) {
-    /* tile[1 + j] = T[(t0 + j) mod n] for j in [-1, SORT_TILE + PART_HALO) */
-    const u32 q0 = t0 + 4u * tid;
-    if (q0 + 4u <= n) {
-      const u32 v = *reinterpret_cast<const u32 *>(T + q0);
-      P->tile[1u + 4u * tid] = (u8)v; P->tile[2u + 4u * tid] = (u8)(v >> 8);
-      P->tile[3u + 4u * tid] = (u8)(v >> 16); P->tile[4u + 4u * tid] = (u8)(v >> 24);
-    } else {
+  u32 rnk[SORT_IPT];
+  for (u32 i = tid; i < LBZ_NW * 256u; i += LBZ_WG) (&X->wcnt[0][0])[i] = 0;
+  wg_lds_barrier();
 #pragma unroll
-      for (u32 i = 0; i < 4u; i++) P->tile[1u + 4u * tid + i] = T[(q0 + i) % n];
+  for (u32 k = 0; k < SORT_IPT; k++) {
+    const bool ok = (okmask >> k) & 1u;
+    const u32 d = (u32)(key[k] >> shift) & 255u;
+    const u64 mask = match_digit(d, ok);
+    const u32 below = (u32)__popcll(mask & lanes_below());
+    const u32 prev = ok ? X->wcnt[w][d] : 0u;
+    wave_sync();
+    if (ok && below == 0u) X->wcnt[w][d] = prev + (u32)__popcll(mask);
+    wave_sync();
+    rnk[k] = prev + below;
+  }
+  wg_lds_barrier();
+  u32 tot = 0, inc = 0;
+  if (tid < 256u) {
+#pragma unroll
+    for (u32 w2 = 0; w2 < LBZ_NW; w2++) {
+      const u32 t = X->wcnt[w2][tid];
+      X->wcnt[w2][tid] = tot;
+      tot += t;
     }
-    if (tid < PART_HALO) P->tile[1u + SORT_TILE + tid] = T[(t0 + SORT_TILE + tid) % n];
-    if (tid == PART_HALO) P->tile[0] = T[(t0 + n - 1u) % n];
+    inc = wave_incl_add(tot);
+    if (lane == 63u) X->wtot[w] = inc;
+  }
+  wg_lds_barrier();
+  if (tid < 256u) {
+    u32 base = 0;
+    for (u32 w2 = 0; w2 < w; w2++) base += X->wtot[w2];
+    const u32 toff = base + inc - tot;
+    const u32 g = X->dbase[tid];
+    X->toff[tid] = toff;
+    X->gdelta[tid] = g - toff;
+    X->dbase[tid] = g + tot;
+  }
+  wg_lds_barrier();
+#pragma unroll
+  for (u32 k = 0; k < SORT_IPT; k++) {
+    if ((okmask >> k) & 1u) {
+      const u32 d = (u32)(key[k] >> shift) & 255u;
+      const u32 lpos = X->toff[d] + X->wcnt[w][d] + rnk[k];
+      X->stage_k[lpos] = key[k];
+      X->stage_v[lpos] = val[k];
+    }
+  }
+  wg_lds_barrier();
+  const u32 rows = X->wtot[0] + X->wtot[1] + X->wtot[2] + X->wtot[3];
+#pragma unroll
+  for (u32 k = 0; k < SORT_IPT; k++) {
+    const u32 i = tid + k * LBZ_WG;
+    if (i < rows) {
+      const u64 kk = X->stage_k[i];
+      const u32 dst = X->gdelta[(u32)(kk >> shift) & 255u] + i;
+      kout[dst] = kk;
+      vout[dst] = X->stage_v[i];
+    }
+  }
+  wg_lds_barrier();
+}
+
+/* A pass over the block text through the LDS tile, keys built on the fly.  The tile holds
+ * dense symbol CODES (one table lookup per text byte); a thread owns 4 consecutive rotations,
+ * reads their 4+sy-1 codes as five dwords and slides a window over them.
+ * SCATTER = false: histogram the first partition digit of every rotation;
+ * SCATTER = true : first partition pass (digit at MSD_SHIFT) straight from the text, counting
+ *                  the other two digits on the way.  Values carry the CODE of the preceding
+ *                  byte; the emitters map it back.                                          */
+template <bool SCATTER>
+__device__ void msd_text_pass(const u8 *T, u32 n, keycfg c, u64 *kout, u32 *vout, bwt_lds *S)
+{
+  sort_lds *P = &S->u.X;
+  const u32 tid = threadIdx.x;
+  u32 *tile32 = P->tile;        /* code of position t0 + j at byte 4 + j */
+  const u64 keep = (c.b * c.sy >= 64u) ? ~0ull : ((1ull << (c.b * c.sy)) - 1ull);
+  for (u32 t0 = 0; t0 < n; t0 += SORT_TILE) {
+    const u32 q0 = t0 + 4u * tid;
+    {
+      u32 raw;
+      if (q0 + 4u <= n) raw = *reinterpret_cast<const u32 *>(T + q0);
+      else raw = (u32)T[q0 % n] | ((u32)T[(q0 + 1u) % n] << 8) | ((u32)T[(q0 + 2u) % n] << 16) | ((u32)T[(q0 + 3u) % n] << 24);
+      tile32[1u + tid] = (u32)S->cmap[raw & 255u] | ((u32)S->cmap[(raw >> 8) & 255u] << 8)
+                       | ((u32)S->cmap[(raw >> 16) & 255u] << 16) | ((u32)S->cmap[raw >> 24] << 24);
+      if (tid < PART_HALO / 4u) {
+        const u32 h0 = t0 + SORT_TILE + 4u * tid;
+        tile32[1u + LBZ_WG + tid] = (u32)S->cmap[T[h0 % n]] | ((u32)S->cmap[T[(h0 + 1u) % n]] << 8)
+                                  | ((u32)S->cmap[T[(h0 + 2u) % n]] << 16) | ((u32)S->cmap[T[(h0 + 3u) % n]] << 24);
+      }
+      if (tid == PART_HALO / 4u) tile32[0] = (u32)S->cmap[T[(t0 + n - 1u) % n]] << 24;
+    }
     __syncthreads();
     u64 key[SORT_IPT];
     u32 val[SORT_IPT], okmask = 0;
-    const u32 wbase = w * 64u * SORT_IPT;
+    if (c.sy <= 16u) {
+      const u32 w0 = tile32[1u + tid], w1 = tile32[2u + tid], w2 = tile32[3u + tid], w3 = tile32[4u + tid], w4 = tile32[5u + tid];
+      const u64 x0 = (u64)w0 | ((u64)w1 << 32), x1 = (u64)w2 | ((u64)w3 << 32), x2 = (u64)w4;
+      u64 win = 0;
+      for (u32 q = 0; q < c.sy; q++)
+        win = (win << c.b) | (u32)(((q < 8u ? x0 : x1) >> (8u * (q & 7u))) & 255ull);
+      u32 prev = tile32[tid] >> 24;
 #pragma unroll
-    for (u32 k = 0; k < SORT_IPT; k++) {
-      const u32 j = wbase + k * 64u + lane;            /* position inside the tile */
-      const u32 p = t0 + j;
-      u64 kk = 0;
-      for (u32 q = 0; q < c.sy; q++) kk = (kk << c.b) | S->cmap[P->tile[1u + j + q]];
-      key[k] = kk << c.pad;
-      val[k] = ((u32)P->tile[j] << 24) | p;
-      if (p < n) okmask |= 1u << k;
+      for (u32 k = 0; k < SORT_IPT; k++) {
+        if (k) {
+          const u32 q = k + c.sy - 1u;                   /* <= 18 */
+          const u32 code = (u32)(((q < 8u ? x0 : (q < 16u ? x1 : x2)) >> (8u * (q & 7u))) & 255ull);
+          win = ((win << c.b) | code) & keep;
+        }
+        key[k] = win << c.pad;
+        val[k] = (prev << 24) | (q0 + k);
+        prev = (w0 >> (8u * k)) & 255u;
+        if (q0 + k < n) okmask |= 1u << k;
+      }
+    } else {
+#pragma unroll
+      for (u32 k = 0; k < SORT_IPT; k++) {
+        const u32 j = 4u * tid + k;
+        u64 kk = 0;
+        for (u32 q = 0; q < c.sy; q++) kk = (kk << c.b) | reinterpret_cast<const u8 *>(P->tile)[4u + j + q];
+        key[k] = kk << c.pad;
+        val[k] = ((u32)reinterpret_cast<const u8 *>(P->tile)[3u + j] << 24) | (q0 + k);
+        if (q0 + k < n) okmask |= 1u << k;
+      }
     }
     if (SCATTER) {
-      radix_tile_scatter(P->wcnt, P->dbase, key, val, okmask, shift, kout, vout);
-    } else {
 #pragma unroll
       for (u32 k = 0; k < SORT_IPT; k++)
         if ((okmask >> k) & 1u) {
-          atomicAdd(&P->hist[0][(u32)(key[k] >> MSD_SHIFT) & 255u], 1u);
           atomicAdd(&P->hist[1][(u32)(key[k] >> (MSD_SHIFT + 8u)) & 255u], 1u);
           atomicAdd(&P->hist[2][(u32)(key[k] >> (MSD_SHIFT + 16u)) & 255u], 1u);
         }
+      radix_tile_scatter_hbm(P, key, val, okmask, MSD_SHIFT, kout, vout);
+    } else {
+#pragma unroll
+      for (u32 k = 0; k < SORT_IPT; k++)
+        if ((okmask >> k) & 1u) atomicAdd(&P->hist[0][(u32)(key[k] >> MSD_SHIFT) & 255u], 1u);
       __syncthreads();
     }
   }
 }
 
-/* A partition pass from (kin,vin) to (kout,vout) on the digit at `shift`. */
+/* A partition pass from (kin,vin) to (kout,vout) on the digit at `shift`; the next tile's rows
+ * are requested before the current tile is ranked.                                        */
 __device__ void msd_array_pass(const u64 *kin, const u32 *vin, u32 n, u32 shift, u64 *kout, u32 *vout, bwt_lds *S)
 {
-  part_lds *P = &S->u.P;
+  sort_lds *P = &S->u.X;
   const u32 lane = lane_id(), w = wave_id();
+  u64 nkey[SORT_IPT];
+  u32 nval[SORT_IPT];
+#pragma unroll
+  for (u32 k = 0; k < SORT_IPT; k++) {
+    const u32 i = w * 64u * SORT_IPT + k * 64u + lane;
+    nkey[k] = i < n ? kin[i] : 0ull;
+    nval[k] = i < n ? vin[i] : 0u;
+  }
   for (u32 t0 = 0; t0 < n; t0 += SORT_TILE) {
     u64 key[SORT_IPT];
     u32 val[SORT_IPT], okmask = 0;
     const u32 wbase = t0 + w * 64u * SORT_IPT;
 #pragma unroll
     for (u32 k = 0; k < SORT_IPT; k++) {
-      const u32 i = wbase + k * 64u + lane;
-      key[k] = i < n ? kin[i] : 0ull;
-      val[k] = i < n ? vin[i] : 0u;
-      if (i < n) okmask |= 1u << k;
+      key[k] = nkey[k];
+      val[k] = nval[k];
+      if (wbase + k * 64u + lane < n) okmask |= 1u << k;
+      const u32 i = wbase + SORT_TILE + k * 64u + lane;
+      nkey[k] = i < n ? kin[i] : 0ull;
+      nval[k] = i < n ? vin[i] : 0u;
     }
-    radix_tile_scatter(P->wcnt, P->dbase, key, val, okmask, shift, kout, vout);
+    radix_tile_scatter_hbm(P, key, val, okmask, shift, kout, vout);
   }
 }
 
@@ -800,7 +882,7 @@ __device__ void batch_process(const u8 *T, u32 n, u8 *bwt, lbz_block_meta *meta,
       const u32 v = vR[j];
       const u32 idx = v & 0x00FFFFFFu;
       const bool flagged = B->tied[j] && B->gh[j] != j;
-      bwt[lo + j] = (u8)(v >> 24);
+      bwt[lo + j] = S->inv[v >> 24];
       s.sa[lo + j] = idx | (flagged ? TIE_FLAG : 0u);
       if (idx == 0u) meta->bwt_idx = lo + j;
     }
@@ -818,7 +900,7 @@ __device__ void emit_tied_rows(u8 *bwt, bwt_slot s, bwt_lds *S, u32 lo, u32 hi)
 {
   for (u32 j = lo + threadIdx.x; j < hi; j += LBZ_WG) {
     const u32 v = s.v0[j];
-    bwt[j] = (u8)(v >> 24);
+    bwt[j] = S->inv[v >> 24];
     s.sa[j] = (v & 0x00FFFFFFu) | (j > lo ? TIE_FLAG : 0u);
   }
   if (threadIdx.x == 0) S->bc[8] = 1u;
@@ -885,106 +967,130 @@ __device__ void big_group(const u8 *T, u32 n, u8 *bwt, lbz_block_meta *meta, bwt
   }
 }
 
-__device__ void bwt_block(const u8 *T, u32 n, u8 *bwt, lbz_block_meta *meta, bwt_slot s, bwt_lds *S)
+/* dense symbol codes of the used bytes and the key geometry they allow (every kernel) */
+__device__ keycfg bwt_setup(const lbz_block_meta *meta, bwt_lds *S)
 {
   const u32 tid = threadIdx.x;
-  if (n == 1u) {                              /* divbwt.c:1712 */
-    if (tid == 0) { bwt[0] = T[0]; meta->bwt_idx = 0; meta->periodic = 0; meta->rounds = 0; meta->sort_elems = 0; }
-    __syncthreads();
-    return;
-  }
-  const u64 tk0 = wall_clock64();
-
-  /* dense symbol codes and the key geometry */
   u32 ninuse;
-  {
-    const u32 f = (tid < 256u && meta->inuse[tid]) ? 1u : 0u;
-    const u32 ex = wg_excl_add(f, &ninuse, &S->sc);
-    if (tid < 256u) S->cmap[tid] = (u8)ex;
-  }
+  const u32 f = (tid < 256u && meta->inuse[tid]) ? 1u : 0u;
+  const u32 ex = wg_excl_add(f, &ninuse, &S->sc);
+  if (tid < 256u) S->cmap[tid] = (u8)ex;
+  if (f) S->inv[ex] = (u8)tid;
   keycfg c;
   c.b = 1u;
   while ((1u << c.b) < ninuse) c.b++;
   c.sy = 64u / c.b;
   if (c.sy > MAX_SYMS) c.sy = MAX_SYMS;
   c.pad = 64u - c.b * c.sy;
-  if (tid == 0) { S->bc[8] = 0; meta->periodic = 0; for (u32 i = 9; i < 16; i++) S->bc[i] = 0; }
+  if (tid == 0) for (u32 i = 8; i < 16; i++) S->bc[i] = 0;
   __syncthreads();
+  return c;
+}
 
+/* queue order: all primary blocks first (the big ones), then the spill blocks */
+__device__ __forceinline__ u32 bwt_queue_block(u32 q, u32 nslabs)
+{
+  return q < nslabs ? 2u * q : 2u * (q - nslabs) + 1u;
+}
+
+/* ---- kernel 1: partition on the key's top 24 bits: k0 <- text, k1 <- k0, k0 <- k1 ---- */
+__global__ void __launch_bounds__(LBZ_WG)
+k_bwt_part(const u8 *Tbase, lbz_block_meta *meta, lbz_layout L, u32 first_q, u32 nslabs, u8 *ws, u64 slot_bytes)
+{
+  __shared__ bwt_lds S;
+  const u32 tid = threadIdx.x;
+  const u32 blk = bwt_queue_block(first_q + blockIdx.x, nslabs);
+  const u32 n = meta[blk].n;
+  if (n <= BATCH_CAP) return;                 /* small blocks are sorted whole by k_bwt_batch */
+  const bwt_slot s = slot_carve(ws + (u64)blockIdx.x * slot_bytes, L.cap_a);
+  const u8 *T = Tbase + lbz_elem_off(L, blk);
+  const u64 tk0 = wall_clock64();
+  const keycfg c = bwt_setup(&meta[blk], &S);
+  sort_lds *P = &S.u.X;
+  for (u32 i = tid; i < 3u * 256u; i += LBZ_WG) (&P->hist[0][0])[i] = 0;
+  __syncthreads();
+  msd_text_pass<false>(T, n, c, nullptr, nullptr, &S);
+  load_digit_offsets(P->hist[0], P->dbase, &S);
+  msd_text_pass<true>(T, n, c, s.k0, s.v0, &S);
+  load_digit_offsets(P->hist[1], P->dbase, &S);
+  msd_array_pass(s.k0, s.v0, n, MSD_SHIFT + 8u, s.k1, s.v1, &S);
+  load_digit_offsets(P->hist[2], P->dbase, &S);
+  msd_array_pass(s.k1, s.v1, n, MSD_SHIFT + 16u, s.k0, s.v0, &S);
+  if (tid == 0) meta[blk].ticks[2] = (u32)(wall_clock64() - tk0);
+}
+
+/* ---- kernel 2: LDS batches of whole groups; emits BWT bytes + rows; flags deep ties ---- */
+__global__ void __launch_bounds__(LBZ_WG)
+k_bwt_batch(const u8 *Tbase, u8 *Bbase, lbz_block_meta *meta, lbz_layout L, u32 first_q, u32 nslabs,
+            u8 *ws, u64 slot_bytes)
+{
+  __shared__ bwt_lds S;
+  const u32 tid = threadIdx.x;
+  const u32 blk = bwt_queue_block(first_q + blockIdx.x, nslabs);
+  lbz_block_meta *M = &meta[blk];
+  const u32 n = M->n;
+  if (n == 0u) return;
+  const bwt_slot s = slot_carve(ws + (u64)blockIdx.x * slot_bytes, L.cap_a);
+  const size_t off = lbz_elem_off(L, blk);
+  const u8 *T = Tbase + off;
+  u8 *bwt = Bbase + off;
+  if (n == 1u) {                              /* divbwt.c:1712 */
+    if (tid == 0) { bwt[0] = T[0]; M->bwt_idx = 0; M->periodic = 0; M->rounds = 0; M->sort_elems = 0; }
+    return;
+  }
+  const u64 tk0 = wall_clock64();
+  const keycfg c = bwt_setup(M, &S);
   if (n <= BATCH_CAP) {
-    batch_lds *B = &S->u.B;
+    batch_lds *B = &S.u.B;
     for (u32 i = tid; i < n; i += LBZ_WG) {
-      B->kA[i] = key_from_text(T, n, i, S->cmap, c);
-      B->vA[i] = ((u32)T[i ? i - 1u : n - 1u] << 24) | i;
+      B->kA[i] = key_from_text(T, n, i, S.cmap, c);
+      B->vA[i] = ((u32)S.cmap[T[i ? i - 1u : n - 1u]] << 24) | i;
     }
     __syncthreads();
-    batch_process(T, n, bwt, meta, s, S, c, 0u, n, false, true);
+    batch_process(T, n, bwt, M, s, &S, c, 0u, n, false, true);
   } else {
-    /* ---- partition on the key's top 24 bits: k0 <- text, k1 <- k0, k0 <- k1 ---- */
-    part_lds *P = &S->u.P;
-    for (u32 i = tid; i < 3u * 256u; i += LBZ_WG) (&P->hist[0][0])[i] = 0;
-    __syncthreads();
-    msd_text_pass<false>(T, n, c, 0u, nullptr, nullptr, S);
-    load_digit_offsets(P->hist[0], P->dbase, S);
-    msd_text_pass<true>(T, n, c, MSD_SHIFT, s.k0, s.v0, S);
-    load_digit_offsets(P->hist[1], P->dbase, S);
-    msd_array_pass(s.k0, s.v0, n, MSD_SHIFT + 8u, s.k1, s.v1, S);
-    load_digit_offsets(P->hist[2], P->dbase, S);
-    msd_array_pass(s.k1, s.v1, n, MSD_SHIFT + 16u, s.k0, s.v0, S);
-    if (tid == 0) S->bc[9] = (u32)(wall_clock64() - tk0);
-    __syncthreads();
-
-    /* ---- batches of whole groups ---- */
     u32 pos = 0;
     while (pos < n) {
       u32 e = pos + BATCH_CAP < n ? pos + BATCH_CAP : n;
       if (e < n) {
-        const u32 cut = find_cut(s.k0, pos, e, MSD_SHIFT, S);
+        const u32 cut = find_cut(s.k0, pos, e, MSD_SHIFT, &S);
         if (!cut) {
-          const u32 end = find_run_end(s.k0, pos, e, n, MSD_SHIFT, S);
-          big_group(T, n, bwt, meta, s, S, c, pos, end);
+          const u32 end = find_run_end(s.k0, pos, e, n, MSD_SHIFT, &S);
+          big_group(T, n, bwt, M, s, &S, c, pos, end);
           pos = end;
           continue;
         }
         e = cut;
       }
-      batch_process(T, n, bwt, meta, s, S, c, pos, e - pos, false, false);
+      batch_process(T, n, bwt, M, s, &S, c, pos, e - pos, false, false);
       pos = e;
     }
   }
-  const u64 tk1 = wall_clock64();
   __syncthreads();
-  u32 rounds = 0, work = 0;
-  if (S->bc[8]) finish_by_doubling(T, n, bwt, meta, s, S, c.sy, &rounds, &work);
   if (tid == 0) {
-    meta->rounds = rounds;
-    meta->sort_elems = n + work;
-    meta->ticks[0] = (u32)(tk1 - tk0);
-    meta->ticks[1] = (u32)(wall_clock64() - tk1);
-    for (u32 i = 0; i < 5; i++) meta->ticks[2 + i] = S->bc[9 + i];   /* partition, load, sort, refine, emit */
-    meta->ticks[7] = S->bc[15]; meta->ticks[1] = S->bc[14];              /* wave chunk sort; first batch_runs */
+    M->periodic = S.bc[8] ? 2u : 0u;          /* 2 = ties left for k_bwt_fix */
+    M->rounds = 0;
+    M->sort_elems = n;
+    M->ticks[0] = (u32)(wall_clock64() - tk0);
+    for (u32 i = 0; i < 4; i++) M->ticks[3 + i] = S.bc[10 + i];   /* load, sort, refine, emit */
+    M->ticks[7] = S.bc[15]; M->ticks[1] = S.bc[14];               /* wave chunk sort; first batch_runs */
   }
-  __syncthreads();
 }
 
-/* grid = number of workspace slots (persistent workgroups).  Queue order: all primary
- * blocks first (the big ones), then the spill blocks.                                    */
-__global__ void __launch_bounds__(LBZ_WG, 4)   /* 4 waves per SIMD = two workgroups per CU */
-k_bwt(const u8 *Tbase, u8 *Bbase, lbz_block_meta *meta, lbz_layout L,
-      u32 nslabs, u32 *queue, u8 *ws, u64 slot_bytes)
+/* ---- kernel 3: blocks with ties deeper than the LDS refinements: prefix doubling ---- */
+__global__ void __launch_bounds__(LBZ_WG)
+k_bwt_fix(const u8 *Tbase, u8 *Bbase, lbz_block_meta *meta, lbz_layout L, u32 first_q, u32 nslabs,
+          u8 *ws, u64 slot_bytes)
 {
   __shared__ bwt_lds S;
+  const u32 blk = bwt_queue_block(first_q + blockIdx.x, nslabs);
+  lbz_block_meta *M = &meta[blk];
+  const u32 n = M->n;
+  if (n < 2u || M->periodic != 2u) return;
   const bwt_slot s = slot_carve(ws + (u64)blockIdx.x * slot_bytes, L.cap_a);
-  for (;;) {
-    if (threadIdx.x == 0) S.bc[1] = atomicAdd(queue, 1u);
-    __syncthreads();
-    const u32 q = S.bc[1];
-    __syncthreads();
-    if (q >= 2u * nslabs) break;
-    const u32 blk = q < nslabs ? 2u * q : 2u * (q - nslabs) + 1u;
-    const u32 n = meta[blk].n;
-    if (n == 0u) continue;
-    const size_t off = lbz_elem_off(L, blk);
-    bwt_block(Tbase + off, n, Bbase + off, &meta[blk], s, &S);
-  }
+  const size_t off = lbz_elem_off(L, blk);
+  const keycfg c = bwt_setup(M, &S);
+  u32 rounds = 0, work = 0;
+  finish_by_doubling(Tbase + off, n, Bbase + off, M, s, &S, c.sy, &rounds, &work);
+  if (threadIdx.x == 0) { M->rounds = rounds; M->sort_elems = n + work; }
 }

@@ -44,6 +44,8 @@ struct lbzamd_ctx {
   uint64_t slot_bytes = 0;
   hipStream_t stream = nullptr;
   hipEvent_t ev[8] = {};
+  std::vector<hipEvent_t> bev;                /* events around the BWT launches of a chunk */
+  float bwt_ms[3] = { 0, 0, 0 };             /* partition, batch, fix: accumulated per call */
   /* device */
   u8 *T = nullptr, *B = nullptr, *R = nullptr, *O = nullptr, *ws = nullptr;
   u16 *V = nullptr;
@@ -56,6 +58,7 @@ struct lbzamd_ctx {
   /* host */
   std::vector<lbz_block_meta> h_meta;
   uint32_t last_nslabs = 0;
+  size_t nbev_used = 0;
   lbzamd_stats stats{};
 };
 
@@ -66,6 +69,7 @@ static int ctx_free(lbzamd_ctx *c)
   (void)hipFree(c->freq); (void)hipFree(c->queue); (void)hipFree(c->offs); (void)hipFree(c->meta); (void)hipFree(c->st);
   (void)hipFree(c->d_in); (void)hipFree(c->d_out);
   for (auto &e : c->ev) if (e) (void)hipEventDestroy(e);
+  for (auto &e : c->bev) if (e) (void)hipEventDestroy(e);
   if (c->stream) (void)hipStreamDestroy(c->stream);
   delete c;
   return 0;
@@ -96,7 +100,7 @@ extern "C" int lbzamd_create(lbzamd_ctx **out, int device, unsigned bs100k, unsi
   c->L.out_b = round_up(c->L.cap_b + c->L.cap_b / 8u + 4096u, 256u);
   if (nslots == 0) {
     const char *env = getenv("LBZAMD_SLOTS");
-    nslots = env ? (unsigned)atoi(env) : 2u * (unsigned)prop.multiProcessorCount;
+    nslots = env ? (unsigned)atoi(env) : (unsigned)prop.multiProcessorCount * (1024u / LBZ_BWT_WG);
     if (nslots == 0) nslots = 1;
   }
   if (nslots > 2u * max_slabs) nslots = 2u * max_slabs;
@@ -146,12 +150,31 @@ static int run_chunk(lbzamd_ctx *c, const u8 *d_in, size_t len, uint32_t nsl, in
   HIPCHK(hipEventRecord(c->ev[0], s));
   hipLaunchKernelGGL(k_collect, dim3(nsl), dim3(LBZ_WG), 0, s, d_in, (u64)len, c->L, c->T, c->meta);
   HIPCHK(hipEventRecord(c->ev[1], s));
+  size_t nbev = 0;
   if (upto >= 1) {
-    HIPCHK(hipMemsetAsync(c->queue, 0, 256, s));
-    const uint32_t grid = c->nslots < nblk ? c->nslots : nblk;
-    hipLaunchKernelGGL(k_bwt, dim3(grid), dim3(LBZ_BWT_WG), 0, s, (const u8 *)c->T, c->B, c->meta, c->L,
-                       nsl, c->queue, c->ws, (u64)c->slot_bytes);
+    /* rounds of nslots queue entries (primaries first, then the small spill blocks); within a
+       round every workgroup owns one workspace slot through the three kernels */
+    for (uint32_t first = 0; first < nblk; first += c->nslots) {
+      const uint32_t grid = nblk - first < c->nslots ? nblk - first : c->nslots;
+      while (c->bev.size() < nbev + 4) {
+        hipEvent_t e;
+        HIPCHK(hipEventCreate(&e));
+        c->bev.push_back(e);
+      }
+      HIPCHK(hipEventRecord(c->bev[nbev + 0], s));
+      hipLaunchKernelGGL(k_bwt_part, dim3(grid), dim3(LBZ_BWT_WG), 0, s, (const u8 *)c->T, c->meta, c->L,
+                         first, nsl, c->ws, (u64)c->slot_bytes);
+      HIPCHK(hipEventRecord(c->bev[nbev + 1], s));
+      hipLaunchKernelGGL(k_bwt_batch, dim3(grid), dim3(LBZ_BWT_WG), 0, s, (const u8 *)c->T, c->B, c->meta, c->L,
+                         first, nsl, c->ws, (u64)c->slot_bytes);
+      HIPCHK(hipEventRecord(c->bev[nbev + 2], s));
+      hipLaunchKernelGGL(k_bwt_fix, dim3(grid), dim3(LBZ_BWT_WG), 0, s, (const u8 *)c->T, c->B, c->meta, c->L,
+                         first, nsl, c->ws, (u64)c->slot_bytes);
+      HIPCHK(hipEventRecord(c->bev[nbev + 3], s));
+      nbev += 4;
+    }
   }
+  c->nbev_used = nbev;
   HIPCHK(hipEventRecord(c->ev[2], s));
   if (upto >= 2)
     hipLaunchKernelGGL(k_mtf, dim3(nblk), dim3(LBZ_WG), 0, s, (const u8 *)c->B, c->R, c->V, c->freq, c->meta, c->L);
@@ -172,6 +195,12 @@ static int add_times(lbzamd_ctx *c, int nev, float *acc)
     HIPCHK(hipEventElapsedTime(&t, c->ev[i], c->ev[i + 1]));
     acc[i] += t;
   }
+  for (size_t r = 0; r + 3 < c->nbev_used + 0 && r < c->nbev_used; r += 4)
+    for (int k = 0; k < 3; k++) {
+      float t = 0;
+      HIPCHK(hipEventElapsedTime(&t, c->bev[r + k], c->bev[r + k + 1]));
+      c->bwt_ms[k] += t;
+    }
   return 0;
 }
 
@@ -186,6 +215,7 @@ extern "C" int lbzamd_compress_device(lbzamd_ctx *c, const void *d_in_v, size_t 
   const size_t nslabs = (len + M - 1u) / M;
   float acc[6] = { 0, 0, 0, 0, 0, 0 };
   hipStream_t s = c->stream;
+  c->bwt_ms[0] = c->bwt_ms[1] = c->bwt_ms[2] = 0;
 
   size_t done = 0;
   bool first = true;
@@ -219,6 +249,7 @@ extern "C" int lbzamd_compress_device(lbzamd_ctx *c, const void *d_in_v, size_t 
   c->stats.n_in = len; c->stats.n_rle = st.n_rle; c->stats.n_mtf = st.n_mtf; c->stats.n_out = st.pos;
   c->stats.sort_elems = st.sort_elems; c->stats.nblocks = st.nblocks; c->stats.nperiodic = st.nperiodic;
   c->stats.ms_collect = acc[0]; c->stats.ms_bwt = acc[1]; c->stats.ms_mtf = acc[2];
+  c->stats.ms_bwt_part = c->bwt_ms[0]; c->stats.ms_bwt_batch = c->bwt_ms[1]; c->stats.ms_bwt_fix = c->bwt_ms[2];
   c->stats.ms_encode = acc[3]; c->stats.ms_finish = acc[4];
   c->stats.ms_total = acc[0] + acc[1] + acc[2] + acc[3] + acc[4];
   if (st.err) {
@@ -403,8 +434,9 @@ extern "C" size_t lbzamd_encode(encoder_state *e, uint32_t *crc)
   hipStream_t s = c->stream;
   /* the slab is resident and collected; run the remaining stages on its primary block only */
   if (hipSetDevice(c->device) != hipSuccess) die("encode");
-  (void)hipMemsetAsync(c->queue, 0, 256, s);
-  hipLaunchKernelGGL(k_bwt, dim3(1), dim3(LBZ_BWT_WG), 0, s, (const u8 *)c->T, c->B, c->meta, c->L, 1u, c->queue, c->ws, (u64)c->slot_bytes);
+  hipLaunchKernelGGL(k_bwt_part, dim3(1), dim3(LBZ_BWT_WG), 0, s, (const u8 *)c->T, c->meta, c->L, 0u, 1u, c->ws, (u64)c->slot_bytes);
+  hipLaunchKernelGGL(k_bwt_batch, dim3(1), dim3(LBZ_BWT_WG), 0, s, (const u8 *)c->T, c->B, c->meta, c->L, 0u, 1u, c->ws, (u64)c->slot_bytes);
+  hipLaunchKernelGGL(k_bwt_fix, dim3(1), dim3(LBZ_BWT_WG), 0, s, (const u8 *)c->T, c->B, c->meta, c->L, 0u, 1u, c->ws, (u64)c->slot_bytes);
   hipLaunchKernelGGL(k_mtf, dim3(1), dim3(LBZ_WG), 0, s, (const u8 *)c->B, c->R, c->V, c->freq, c->meta, c->L);
   hipLaunchKernelGGL(k_encode, dim3(1), dim3(LBZ_WG), 0, s, (const u16 *)c->V, (const u32 *)c->freq, c->O, c->meta, c->L);
   if (hipStreamSynchronize(s) != hipSuccess || hipGetLastError() != hipSuccess) { g_err = "kernel failure"; die("encode"); }

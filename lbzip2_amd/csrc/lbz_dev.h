@@ -25,6 +25,15 @@ __device__ __forceinline__ u64 lanes_below() { return (1ull << lane_id()) - 1ull
  * ordering of LDS accesses around a wave-private read-modify-write.                  */
 __device__ __forceinline__ void wave_sync() { __builtin_amdgcn_wave_barrier(); }
 
+/* Workgroup barrier that orders LDS traffic only: outstanding global stores keep flying
+ * (a plain __syncthreads() drains vmcnt too, which exposes the full store latency at every
+ * tile boundary of a streaming pass).  0xC07F = s_waitcnt lgkmcnt(0) on gfx9.             */
+__device__ __forceinline__ void wg_lds_barrier()
+{
+  __builtin_amdgcn_s_waitcnt(0xC07F);
+  __builtin_amdgcn_s_barrier();
+}
+
 template <class T> __device__ __forceinline__ T wave_incl_add(T v)
 {
   const u32 l = lane_id();

@@ -16,8 +16,13 @@ struct lbz_stream_state {
 };
 
 __global__ void k_collect(const u8 *in, u64 in_len, lbz_layout L, u8 *Tbase, lbz_block_meta *meta);
-__global__ void k_bwt(const u8 *Tbase, u8 *Bbase, lbz_block_meta *meta, lbz_layout L,
-                      u32 nslabs, u32 *queue, u8 *ws, u64 slot_bytes);
+/* the BWT stage: queue entries [first_q, first_q + gridDim.x) -> workspace slot blockIdx.x */
+__global__ void k_bwt_part(const u8 *Tbase, lbz_block_meta *meta, lbz_layout L, u32 first_q, u32 nslabs,
+                           u8 *ws, u64 slot_bytes);
+__global__ void k_bwt_batch(const u8 *Tbase, u8 *Bbase, lbz_block_meta *meta, lbz_layout L, u32 first_q,
+                            u32 nslabs, u8 *ws, u64 slot_bytes);
+__global__ void k_bwt_fix(const u8 *Tbase, u8 *Bbase, lbz_block_meta *meta, lbz_layout L, u32 first_q,
+                          u32 nslabs, u8 *ws, u64 slot_bytes);
 __global__ void k_mtf(const u8 *Bbase, u8 *Rbase, u16 *Vbase, u32 *freq_out, lbz_block_meta *meta, lbz_layout L);
 __global__ void k_encode(const u16 *Vbase, const u32 *freq_in, u8 *Obase, lbz_block_meta *meta, lbz_layout L);
 __global__ void k_offsets(const lbz_block_meta *meta, u32 nblk, u32 bs100k, u32 first, u32 last,

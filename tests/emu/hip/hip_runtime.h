@@ -64,6 +64,7 @@ typedef struct ihipEvent_t *hipEvent_t;
 static inline void __syncthreads() { emu::sync_block(); }
 static inline void __builtin_amdgcn_wave_barrier() { emu::sync_wave(); }
 static inline void __builtin_amdgcn_s_barrier() { emu::sync_block(); }
+static inline void __builtin_amdgcn_s_waitcnt(int) {}
 static inline void __threadfence() { std::atomic_thread_fence(std::memory_order_seq_cst); }
 static inline void __threadfence_block() {}
 static inline void __builtin_amdgcn_s_sleep(int) {}

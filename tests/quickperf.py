@@ -24,12 +24,12 @@ for kind in ("text", "rand"):
             dt = time.time() - t
             s = ctx.stats()
         print(f"{kind} slabs={slabs} slots={slots}: {n/dt/1e6:.1f} MB/s ms: collect={s.ms_collect:.1f} bwt={s.ms_bwt:.1f} "
-              f"mtf={s.ms_mtf:.1f} enc={s.ms_encode:.1f} fin={s.ms_finish:.1f} sort/n={s.sort_elems/max(1,s.n_rle):.2f}", flush=True)
+              f"(part={s.ms_bwt_part:.1f} batch={s.ms_bwt_batch:.1f} fix={s.ms_bwt_fix:.1f}) mtf={s.ms_mtf:.1f} enc={s.ms_encode:.1f} fin={s.ms_finish:.1f}", flush=True)
         tk = [0] * 8; cnt = 0
         for b in range(0, min(2 * slabs, 64), 2):
             bi = ctx.block_info(b)
             for i in range(8): tk[i] += bi.ticks[i]
             cnt += 1
-        print("   mean ms/blk: msd=%.2f runs1=%.2f | partition=%.2f load=%.2f ldssort=%.2f refine=%.2f emit=%.2f chunksort=%.2f (rounds=%d)"
+        print("   mean ms/blk: batchkernel=%.2f runs1=%.2f | partition=%.2f load=%.2f ldssort=%.2f refine=%.2f emit=%.2f chunksort=%.2f (rounds=%d)"
               % tuple([t / cnt / 1e5 for t in tk[:8]] + [bi.rounds]), flush=True)
         ctx.close()
