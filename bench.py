@@ -14,9 +14,11 @@ concatenated streams are a valid .bz2 file) -> weak scaling; value = all ranks' 
 over the max-over-ranks time.
 
 Prints ONE JSON line on rank 0.  Extra objects:
-  roofline      dominant kernel (k_bwt): SURVEY 8(d) algorithmic bytes of the BWT stage
-                (11 B per RLE1'd byte) per launch / mean launch time from HIP events recorded
-                on the library's own stream; peak 8000 GB/s (MI355X HBM3E)
+  roofline      the kernel with the largest share of device time.  SURVEY 8(d) prices the path at
+                N_in + 13 N_rle + 20 N_mtf + N_out algorithmic bytes; per kernel that is
+                collect N_in+N_rle | bwt_part 5 N_rle | bwt_batch 6 N_rle | mtf N_rle+2 N_mtf |
+                encode 18 N_mtf+N_out.  achieved = bytes per launch / mean launch time from HIP
+                events recorded on the library's own stream; peak 8000 GB/s (MI355X HBM3E)
   cpu_baseline  reference lbzip2's block codec (oracle/_ref, "reference") or the bit-exact
                 restatement (oracle/, "port") on the box's host cores over a bounded sample
 """
@@ -32,7 +34,6 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8 TB/s HBM3E
-BWT_ALG_BYTES_PER_RLE = 11.0   # T read 1 + SA write 4 + SA read 4 + gather 1 + BWT write 1
 
 
 def gen_input(kind, n, seed):
@@ -132,12 +133,17 @@ def main():
         out_len = step()
     barrier()
     t0 = time.perf_counter()
-    bwt_ms = tot_ms = 0.0
+    kms = {"k_collect": 0.0, "k_bwt_part": 0.0, "k_bwt_batch": 0.0, "k_bwt_fix": 0.0, "k_mtf": 0.0,
+           "k_encode": 0.0, "finish": 0.0}
+    tot_ms = 0.0
     st = None
     for _ in range(args.steps):
         out_len = step()
         st = ctx.stats()
-        bwt_ms += st.ms_bwt
+        for k, v in (("k_collect", st.ms_collect), ("k_bwt_part", st.ms_bwt_part), ("k_bwt_batch", st.ms_bwt_batch),
+                     ("k_bwt_fix", st.ms_bwt_fix), ("k_mtf", st.ms_mtf), ("k_encode", st.ms_encode),
+                     ("finish", st.ms_finish)):
+            kms[k] += v
         tot_ms += st.ms_total
     barrier()
     elapsed = time.perf_counter() - t0
@@ -157,9 +163,18 @@ def main():
 
     if rank == 0:
         nchunks = (nslabs + slabs - 1) // slabs
-        launches = args.steps * nchunks
-        bwt_alg = BWT_ALG_BYTES_PER_RLE * st.n_rle * args.steps          # bytes over all launches
-        achieved = bwt_alg / (bwt_ms * 1e-3) / 1e9 if bwt_ms > 0 else 0.0
+        nslots = ctx.nslots
+        rounds = sum(-(-2 * min(slabs, nslabs - i * slabs) // nslots) for i in range(nchunks))   # BWT launches per step
+        alg = {"k_collect": st.n_in + st.n_rle, "k_bwt_part": 5.0 * st.n_rle, "k_bwt_batch": 6.0 * st.n_rle,
+               "k_mtf": st.n_rle + 2.0 * st.n_mtf, "k_encode": 18.0 * st.n_mtf + st.n_out}     # bytes per step
+        nlaunch = {"k_collect": nchunks, "k_bwt_part": rounds, "k_bwt_batch": rounds, "k_mtf": nchunks, "k_encode": nchunks}
+        per_kernel = {k: {"ms_per_step": round(kms[k] / args.steps, 3), "launches_per_step": nlaunch[k],
+                          "alg_GB_per_step": round(alg[k] / 1e9, 3),
+                          "achieved_GBps": round(alg[k] * args.steps / (kms[k] * 1e-3) / 1e9, 2) if kms[k] > 0 else 0.0}
+                      for k in alg}
+        dom = max(alg, key=lambda k: kms[k])
+        launches = nlaunch[dom] * args.steps
+        achieved = per_kernel[dom]["achieved_GBps"]
         pipe_alg = st.n_in + 13.0 * st.n_rle + 20.0 * st.n_mtf + st.n_out  # SURVEY 8(d), per step
         res = {
             "metric": "compress MB/s (whole node), enwik9-style text -9", "value": round(total_in * args.steps / elapsed / 1e6, 1),
@@ -171,15 +186,14 @@ def main():
                        "bytes_per_gpu": n, "level": args.level, "parallelism": f"{world} independent shard(s)"},
             "ratio": round(total_in / total_out, 4), "out_bytes": total_out,
             "bit_exact": "vs reference lbzip2 (tests/test_gpu_parity.py); periodic blocks: origin pointer only",
-            "roofline": {"bound": "hbm", "kernel": "k_bwt", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
+            "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
-                         "alg_bytes_per_launch": round(bwt_alg / launches), "launches": launches,
-                         "avg_launch_ms": round(bwt_ms / launches, 3),
+                         "alg_bytes_per_launch": round(alg[dom] * args.steps / launches), "launches": launches,
+                         "avg_launch_ms": round(kms[dom] / launches, 3), "per_kernel": per_kernel,
                          "pipeline_alg_bytes_per_step": round(pipe_alg),
                          "pipeline_achieved_GBps": round(pipe_alg * args.steps / (tot_ms * 1e-3) / 1e9, 2),
                          "pipeline_frac": round(pipe_alg * args.steps / (tot_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)},
-            "kernel_ms_per_step": {"collect": round(st.ms_collect, 2), "bwt": round(st.ms_bwt, 2), "mtf": round(st.ms_mtf, 2),
-                                   "encode": round(st.ms_encode, 2), "finish": round(st.ms_finish, 2)},
+            "kernel_ms_per_step": {k: round(v / args.steps, 2) for k, v in kms.items()},
             "sorter": {"elements_per_block_byte": round(st.sort_elems / max(1, st.n_rle), 3), "blocks": st.nblocks,
                        "periodic_blocks": st.nperiodic},
         }

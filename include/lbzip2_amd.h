@@ -99,6 +99,8 @@ int  lbzamd_compress_host(lbzamd_ctx *ctx, const uint8_t *in, size_t len,
 /* Upper bound of the stream size for len input bytes. */
 size_t lbzamd_bound(size_t len);
 int  lbzamd_get_stats(lbzamd_ctx *ctx, lbzamd_stats *st);
+/* Concurrently resident BWT workgroups (= blocks per BWT launch round). */
+uint32_t lbzamd_slots(lbzamd_ctx *ctx);
 /* The HIP stream (hipStream_t) all kernels of this context are launched on. */
 void *lbzamd_stream(lbzamd_ctx *ctx);
 

@@ -19,7 +19,7 @@ EXPORTS = [
     "lbzamd_encoder_alloc_size", "lbzamd_encoder_init", "lbzamd_collect", "lbzamd_encode",
     "lbzamd_transmit", "lbzamd_encoder_abandon",
     "lbzamd_create", "lbzamd_destroy", "lbzamd_last_error", "lbzamd_compress_device",
-    "lbzamd_compress_host", "lbzamd_bound", "lbzamd_get_stats", "lbzamd_stream",
+    "lbzamd_compress_host", "lbzamd_bound", "lbzamd_get_stats", "lbzamd_stream", "lbzamd_slots",
     "lbzamd_block_slots", "lbzamd_block_info_get", "lbzamd_read_stage", "lbzamd_run_stages",
 ]
 
@@ -91,6 +91,8 @@ class Library:
         lib.lbzamd_get_stats.restype = C.c_int
         lib.lbzamd_stream.argtypes = [vp]
         lib.lbzamd_stream.restype = vp
+        lib.lbzamd_slots.argtypes = [vp]
+        lib.lbzamd_slots.restype = C.c_uint32
         lib.lbzamd_block_slots.argtypes = [vp]
         lib.lbzamd_block_slots.restype = C.c_uint32
         lib.lbzamd_block_info_get.argtypes = [vp, C.c_uint32, C.POINTER(BlockInfo)]
@@ -189,6 +191,10 @@ class Context:
         s = Stats()
         self.L.lib.lbzamd_get_stats(self.h, C.byref(s))
         return s
+
+    @property
+    def nslots(self):
+        return self.L.lib.lbzamd_slots(self.h)
 
     @property
     def stream(self):

@@ -141,6 +141,7 @@ extern "C" size_t lbzamd_bound(size_t len)
 }
 
 extern "C" void *lbzamd_stream(lbzamd_ctx *c) { return (void *)c->stream; }
+extern "C" uint32_t lbzamd_slots(lbzamd_ctx *c) { return c ? c->nslots : 0u; }
 
 /* Enqueue stages [0, upto] for one chunk of nsl slabs already resident at d_in. */
 static int run_chunk(lbzamd_ctx *c, const u8 *d_in, size_t len, uint32_t nsl, int upto, float ms[5])

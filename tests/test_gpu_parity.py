@@ -144,6 +144,24 @@ def test_workunit_interface_threads(lib):
         assert o == L.orc_compress(d, 5)
 
 
+def test_c_host_driver(lib, tmp_path):
+    """The C program that drives the work-unit interface from pthreads the way compress.c does
+    (lbzip2_amd/host/lbzamd_compress.c), and its batch mode."""
+    import subprocess
+    exe = os.path.join(os.path.dirname(lib.path), "..", "host", "lbzamd_compress")
+    if not os.path.exists(exe):
+        pytest.skip("C driver not built")
+    data = gen("text", 3_000_000, 21) + gen("runs", 1_000_000, 22)
+    src = tmp_path / "in.bin"
+    src.write_bytes(data)
+    env = dict(os.environ, LD_LIBRARY_PATH="/opt/rocm/lib:" + os.environ.get("LD_LIBRARY_PATH", ""))
+    want, _ = cpu_reference(data, 9)
+    for extra in ([], ["-w", "6"]):
+        out = subprocess.run([exe, "-9"] + extra, stdin=open(src, "rb"), capture_output=True, env=env, timeout=300)
+        assert out.returncode == 0, out.stderr[-500:]
+        assert out.stdout == want, extra
+
+
 def test_full_size_property(lib):
     """BASELINE-sized behaviour by properties: 60 MB of text at -9 with chunked streaming
     (resident capacity smaller than the input) round-trips through an independent decoder,
