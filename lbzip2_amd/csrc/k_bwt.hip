@@ -987,11 +987,6 @@ __device__ keycfg bwt_setup(const lbz_block_meta *meta, bwt_lds *S)
   return c;
 }
 
-/* queue order: all primary blocks first (the big ones), then the spill blocks */
-__device__ __forceinline__ u32 bwt_queue_block(u32 q, u32 nslabs)
-{
-  return q < nslabs ? 2u * q : 2u * (q - nslabs) + 1u;
-}
 
 /* ---- kernel 1: partition on the key's top 24 bits: k0 <- text, k1 <- k0, k0 <- k1 ---- */
 __global__ void __launch_bounds__(LBZ_WG)
@@ -999,7 +994,7 @@ k_bwt_part(const u8 *Tbase, lbz_block_meta *meta, lbz_layout L, u32 first_q, u32
 {
   __shared__ bwt_lds S;
   const u32 tid = threadIdx.x;
-  const u32 blk = bwt_queue_block(first_q + blockIdx.x, nslabs);
+  const u32 blk = lbz_queue_block(first_q + blockIdx.x, nslabs);
   const u32 n = meta[blk].n;
   if (n <= BATCH_CAP) return;                 /* small blocks are sorted whole by k_bwt_batch */
   const bwt_slot s = slot_carve(ws + (u64)blockIdx.x * slot_bytes, L.cap_a);
@@ -1026,7 +1021,7 @@ k_bwt_batch(const u8 *Tbase, u8 *Bbase, lbz_block_meta *meta, lbz_layout L, u32 
 {
   __shared__ bwt_lds S;
   const u32 tid = threadIdx.x;
-  const u32 blk = bwt_queue_block(first_q + blockIdx.x, nslabs);
+  const u32 blk = lbz_queue_block(first_q + blockIdx.x, nslabs);
   lbz_block_meta *M = &meta[blk];
   const u32 n = M->n;
   if (n == 0u) return;
@@ -1083,7 +1078,7 @@ k_bwt_fix(const u8 *Tbase, u8 *Bbase, lbz_block_meta *meta, lbz_layout L, u32 fi
           u8 *ws, u64 slot_bytes)
 {
   __shared__ bwt_lds S;
-  const u32 blk = bwt_queue_block(first_q + blockIdx.x, nslabs);
+  const u32 blk = lbz_queue_block(first_q + blockIdx.x, nslabs);
   lbz_block_meta *M = &meta[blk];
   const u32 n = M->n;
   if (n < 2u || M->periodic != 2u) return;

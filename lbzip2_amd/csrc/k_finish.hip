@@ -54,9 +54,9 @@ k_offsets(const lbz_block_meta *meta, u32 nblk, u32 bs100k, u32 first, u32 last,
 /* one workgroup per block: byte copy into the (arbitrarily aligned) stream position */
 __global__ void __launch_bounds__(LBZ_WG)
 k_gather(const u8 *Obase, const lbz_block_meta *meta, lbz_layout L, const u64 *offs,
-         const lbz_stream_state *st, u8 *out)
+         const lbz_stream_state *st, u8 *out, u32 nslabs)
 {
-  const u32 blk = blockIdx.x;
+  const u32 blk = lbz_queue_block(blockIdx.x, nslabs);
   const lbz_block_meta *m = &meta[blk];
   if (m->n == 0u || st->err) return;
   const u8 *src = Obase + lbz_out_off(L, blk);

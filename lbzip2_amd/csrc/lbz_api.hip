@@ -178,10 +178,10 @@ static int run_chunk(lbzamd_ctx *c, const u8 *d_in, size_t len, uint32_t nsl, in
   c->nbev_used = nbev;
   HIPCHK(hipEventRecord(c->ev[2], s));
   if (upto >= 2)
-    hipLaunchKernelGGL(k_mtf, dim3(nblk), dim3(LBZ_WG), 0, s, (const u8 *)c->B, c->R, c->V, c->freq, c->meta, c->L);
+    hipLaunchKernelGGL(k_mtf, dim3(nblk), dim3(LBZ_WG), 0, s, (const u8 *)c->B, c->R, c->V, c->freq, c->meta, c->L, nsl);
   HIPCHK(hipEventRecord(c->ev[3], s));
   if (upto >= 3)
-    hipLaunchKernelGGL(k_encode, dim3(nblk), dim3(LBZ_WG), 0, s, (const u16 *)c->V, (const u32 *)c->freq, c->O, c->meta, c->L);
+    hipLaunchKernelGGL(k_encode, dim3(nblk), dim3(LBZ_WG), 0, s, (const u16 *)c->V, (const u32 *)c->freq, c->O, c->meta, c->L, nsl);
   HIPCHK(hipEventRecord(c->ev[4], s));
   HIPCHK(hipGetLastError());
   (void)ms;
@@ -236,7 +236,7 @@ extern "C" int lbzamd_compress_device(lbzamd_ctx *c, const void *d_in_v, size_t 
     if (nsl)
       hipLaunchKernelGGL(k_gather, dim3((u32)(2u * nsl)), dim3(LBZ_WG), 0, s, (const u8 *)c->O,
                          (const lbz_block_meta *)c->meta, c->L, (const u64 *)c->offs,
-                         (const lbz_stream_state *)c->st, d_out);
+                         (const lbz_stream_state *)c->st, d_out, (u32)nsl);
     HIPCHK(hipEventRecord(c->ev[5], s));
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(s));
@@ -438,8 +438,8 @@ extern "C" size_t lbzamd_encode(encoder_state *e, uint32_t *crc)
   hipLaunchKernelGGL(k_bwt_part, dim3(1), dim3(LBZ_BWT_WG), 0, s, (const u8 *)c->T, c->meta, c->L, 0u, 1u, c->ws, (u64)c->slot_bytes);
   hipLaunchKernelGGL(k_bwt_batch, dim3(1), dim3(LBZ_BWT_WG), 0, s, (const u8 *)c->T, c->B, c->meta, c->L, 0u, 1u, c->ws, (u64)c->slot_bytes);
   hipLaunchKernelGGL(k_bwt_fix, dim3(1), dim3(LBZ_BWT_WG), 0, s, (const u8 *)c->T, c->B, c->meta, c->L, 0u, 1u, c->ws, (u64)c->slot_bytes);
-  hipLaunchKernelGGL(k_mtf, dim3(1), dim3(LBZ_WG), 0, s, (const u8 *)c->B, c->R, c->V, c->freq, c->meta, c->L);
-  hipLaunchKernelGGL(k_encode, dim3(1), dim3(LBZ_WG), 0, s, (const u16 *)c->V, (const u32 *)c->freq, c->O, c->meta, c->L);
+  hipLaunchKernelGGL(k_mtf, dim3(1), dim3(LBZ_WG), 0, s, (const u8 *)c->B, c->R, c->V, c->freq, c->meta, c->L, 1u);
+  hipLaunchKernelGGL(k_encode, dim3(1), dim3(LBZ_WG), 0, s, (const u16 *)c->V, (const u32 *)c->freq, c->O, c->meta, c->L, 1u);
   if (hipStreamSynchronize(s) != hipSuccess || hipGetLastError() != hipSuccess) { g_err = "kernel failure"; die("encode"); }
   lbzamd_block_info bi;
   if (lbzamd_block_info_get(c, 0, &bi) || bi.err) { g_err = "device pipeline error"; die("encode"); }

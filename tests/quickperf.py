@@ -32,4 +32,5 @@ for kind in ("text", "rand"):
             cnt += 1
         print("   mean ms/blk: batchkernel=%.2f runs1=%.2f | partition=%.2f load=%.2f ldssort=%.2f refine=%.2f emit=%.2f chunksort=%.2f (rounds=%d)"
               % tuple([t / cnt / 1e5 for t in tk[:8]] + [bi.rounds]), flush=True)
+        print("   mtf ms/blk: lastocc=%.2f ranks=%.2f zrle=%.2f" % (tk[5]/cnt/1e5, tk[6]/cnt/1e5, tk[7]/cnt/1e5), flush=True)
         ctx.close()
