@@ -19,7 +19,7 @@
  *   batches   consecutive whole 24-bit groups of <= 4096 rows are pulled into LDS; rows are
  *             ranked inside their group by counting smaller keys (groups are short), and every
  *             run of equal 64-bit keys is refined IN LDS by fetching the rotation's next S
- *             symbols from the text and ranking inside the run, up to 4 times.  A finished
+ *             symbols from the text and ranking inside the run, up to 12 times.  A finished
  *             batch writes 1 B (BWT byte) + 4 B (row) per rotation.
  *   oversized a 24-bit group larger than a batch is sorted on its remaining 40 key bits by the
  *             HBM radix sorter and then cut into batches at key boundaries.
@@ -54,7 +54,7 @@
 #define COUNT_GROUP 48u                 /* chunks of groups this short are ordered by counting */
 #define WAVE_GROUP 1024u                /* batches holding a longer group are sorted by the whole workgroup */
 #define MAX_SYMS 32u                    /* symbols per key, capped (halo of the text tile) */
-#define REFINE_ROUNDS 4u
+#define REFINE_ROUNDS 12u                /* in-LDS refinements of a batch before rows are left to the doubling */
 #define TIE_FLAG 0x80000000u
 static_assert(BATCH_CAP == LBZ_WG * 4u, "a batch is one 4-rows-per-thread tile");
 

@@ -58,7 +58,7 @@ __device__ __forceinline__ u32 crc_xpow(u32 nbits)     /* x^nbits mod P */
 }
 
 /* CRC (init 0xFFFFFFFF, no final inversion) of x[a..b).  All threads must call. */
-__device__ u32 wg_crc32(const u8 *x, u32 a, u32 b, collect_lds *S)
+__device__ u32 wg_crc32(const u8 *x, u32 a, u32 b, u32 xlen, collect_lds *S)
 {
   const u32 tid = threadIdx.x;
   const u32 len = b - a;
@@ -70,7 +70,29 @@ __device__ u32 wg_crc32(const u8 *x, u32 a, u32 b, collect_lds *S)
     if (v1 > padn) {
       u32 p = a + (v0 > padn ? v0 - padn : 0u);
       const u32 pe = a + (v1 - padn);
-      for (; p < pe; p++) crc = (crc << 8) ^ S->crc_tab[(crc >> 24) ^ x[p]];
+      if (((uintptr_t)x & 15u) == 0u) {
+        /* aligned 16-byte loads; bytes outside [p, pe) of the first/last vector are skipped */
+        for (u32 base = p & ~15u; base < pe; base += 16u) {
+          u32 wq[4];
+          if (base + 16u <= xlen) {
+            const uint4 v = *reinterpret_cast<const uint4 *>(x + base);
+            wq[0] = v.x; wq[1] = v.y; wq[2] = v.z; wq[3] = v.w;
+          } else {                                        /* never read past the input buffer */
+#pragma unroll
+            for (u32 k = 0; k < 4u; k++) {
+              wq[k] = 0;
+              for (u32 j = 0; j < 4u; j++) if (base + 4u * k + j < xlen) wq[k] |= (u32)x[base + 4u * k + j] << (8u * j);
+            }
+          }
+#pragma unroll
+          for (u32 i = 0; i < 16u; i++) {
+            const u32 q = base + i;
+            if (q >= p && q < pe) crc = (crc << 8) ^ S->crc_tab[(crc >> 24) ^ ((wq[i >> 2] >> (8u * (i & 3u))) & 255u)];
+          }
+        }
+      } else {
+        for (; p < pe; p++) crc = (crc << 8) ^ S->crc_tab[(crc >> 24) ^ x[p]];
+      }
     }
   }
   S->part[tid] = crc;
@@ -215,7 +237,7 @@ k_collect(const u8 *in, u64 in_len, lbz_layout L, u8 *Tbase, lbz_block_meta *met
     collect_pass(x, base, len, part ? L.cap_b : L.M, Tbase + lbz_elem_off(L, blk), &S);
     const u32 nblock = S.bc[0], stop = S.bc[1];
     __syncthreads();
-    const u32 crc = wg_crc32(x, base, stop, &S);
+    const u32 crc = wg_crc32(x, base, stop, len, &S);
     if (tid < 256) m->inuse[tid] = (u8)S.inuse[tid];
     if (tid == 0) {
       m->n = nblock; m->crc = crc; m->consumed = stop - base;

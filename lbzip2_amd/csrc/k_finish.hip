@@ -12,33 +12,62 @@
 #include "lbz_kernels.h"
 
 
-/* one workgroup; offs[b] = absolute stream offset of block b of this chunk */
+/* one workgroup; offs[b] = absolute stream offset of block b of this chunk.  Sizes are
+ * prefix-summed by the whole workgroup (tiles of LBZ_WG blocks); the CRC fold, which is order
+ * dependent (rotate, then xor), runs on one lane over values staged in LDS.               */
 __global__ void __launch_bounds__(LBZ_WG)
 k_offsets(const lbz_block_meta *meta, u32 nblk, u32 bs100k, u32 first, u32 last,
           u64 *offs, lbz_stream_state *st, u8 *out, u64 out_cap)
 {
-  if (threadIdx.x != 0) return;
-  u64 pos = st->pos;
-  u32 cc = st->crc;
+  __shared__ wg_scratch sc;
+  __shared__ u32 crcs[LBZ_WG];
+  __shared__ u32 live[LBZ_WG];
+  __shared__ u32 fold;
+  const u32 tid = threadIdx.x;
+  u64 pos = first ? 4ull : st->pos;
+  u32 nb = 0, nper = 0, err = 0;
+  u64 nrle = 0, nmtf = 0, nsort = 0;
+  if (tid == 0) fold = first ? 0u : st->crc;
+  __syncthreads();
+  for (u32 t0 = 0; t0 < nblk; t0 += LBZ_WG) {
+    const u32 b = t0 + tid;
+    u32 len = 0, on = 0;
+    if (b < nblk && meta[b].n != 0u) {
+      const lbz_block_meta *m = &meta[b];
+      on = 1; len = m->out_len;
+      crcs[tid] = m->crc;
+      if (m->err) err = m->err;
+      nb++; nrle += m->n; nmtf += m->nmtf; nsort += m->sort_elems; nper += m->periodic;
+    }
+    live[tid] = on;
+    u32 tot;
+    const u32 ex = wg_excl_add(len, &tot, &sc);
+    if (b < nblk) offs[b] = pos + ex;
+    if (tid == 0) {
+      u32 cc = fold;
+      const u32 cnt = nblk - t0 < LBZ_WG ? nblk - t0 : LBZ_WG;
+      for (u32 i = 0; i < cnt; i++) if (live[i]) cc = ((cc << 1) | (cc >> 31)) ^ ~crcs[i];
+      fold = cc;
+    }
+    pos += tot;
+    __syncthreads();
+  }
+  /* statistics: per-thread partial sums -> lane 0 */
+  const u32 tnb = wg_sum(nb, &sc), tper = wg_sum(nper, &sc), terr = wg_max(err, &sc);
+  const u32 rle_lo = wg_sum((u32)(nrle & 0xFFFFFu), &sc), rle_hi = wg_sum((u32)(nrle >> 20), &sc);
+  const u32 mtf_lo = wg_sum((u32)(nmtf & 0xFFFFFu), &sc), mtf_hi = wg_sum((u32)(nmtf >> 20), &sc);
+  const u32 srt_lo = wg_sum((u32)(nsort & 0xFFFFFu), &sc), srt_hi = wg_sum((u32)(nsort >> 20), &sc);
+  if (tid != 0) return;
   if (first) {
-    pos = 0; cc = 0;
     st->nblocks = 0; st->n_rle = 0; st->n_mtf = 0; st->sort_elems = 0; st->nperiodic = 0; st->err = 0;
     if (out_cap >= 4) { out[0] = 'B'; out[1] = 'Z'; out[2] = 'h'; out[3] = (u8)('0' + bs100k); }
-    pos = 4;
   }
-  for (u32 b = 0; b < nblk; b++) {
-    const lbz_block_meta *m = &meta[b];
-    offs[b] = pos;
-    if (m->n == 0u) continue;
-    if (m->err) st->err = m->err;
-    pos += m->out_len;
-    cc = ((cc << 1) | (cc >> 31)) ^ ~m->crc;
-    st->nblocks++;
-    st->n_rle += m->n;
-    st->n_mtf += m->nmtf;
-    st->sort_elems += m->sort_elems;
-    st->nperiodic += m->periodic;
-  }
+  st->nblocks += tnb; st->nperiodic += tper;
+  st->n_rle += ((u64)rle_hi << 20) + rle_lo;
+  st->n_mtf += ((u64)mtf_hi << 20) + mtf_lo;
+  st->sort_elems += ((u64)srt_hi << 20) + srt_lo;
+  if (terr) st->err = terr;
+  const u32 cc = fold;
   if (pos + (last ? 10u : 0u) > out_cap) { st->err = 100u; st->pos = pos; st->crc = cc; return; }
   if (last) {
     const u8 tr[6] = { 0x17, 0x72, 0x45, 0x38, 0x50, 0x90 };

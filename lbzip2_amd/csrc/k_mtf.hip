@@ -24,6 +24,7 @@
 
 #define MTF_IPT 16u
 #define MTF_TILE (LBZ_WG * MTF_IPT)
+#define MTF_CHUNK 1024u                 /* bytes of a slice staged in LDS at a time */
 
 struct mtf_lds {
   wg_scratch sc;
@@ -31,6 +32,8 @@ struct mtf_lds {
   u32 hist[LBZ_MAX_ALPHA + 2];
   u8 cmap[256];
   u32 bc[4];
+  __attribute__((aligned(16))) u8 stage_in[LBZ_NW][MTF_CHUNK];
+  __attribute__((aligned(16))) u8 stage_out[LBZ_NW][MTF_CHUNK];
 };
 
 __device__ __forceinline__ u32 zrun_digits(u32 z)          /* floor(log2(z+1)) */
@@ -41,8 +44,9 @@ __device__ __forceinline__ u32 zrun_digits(u32 z)          /* floor(log2(z+1)) *
 /* MTF ranks of one wave's slice [lo, hi).  Lane l holds the "last seen at" position of
  * symbols l, l+64, ... in NQ registers.  Per run head: two scalar lane reads (symbol, its
  * last position), NQ ballots + popcounts, one predicated update -- everything but the
- * compares stays on the scalar unit.  Loads of the next 64 positions are issued before the
- * current 64 are walked.                                                                  */
+ * compares stays on the scalar unit.  The slice is staged through LDS 1 KB at a time (one
+ * 16-byte load per lane, requested a chunk ahead; ranks leave the same way), so the serial
+ * head loop never waits on HBM.                                                           */
 template <int NQ>
 __device__ __forceinline__ void mtf_ranks(const u8 *bwt, u8 *rk, u32 lo, u32 hi, mtf_lds *S)
 {
@@ -50,47 +54,61 @@ __device__ __forceinline__ void mtf_ranks(const u8 *bwt, u8 *rk, u32 lo, u32 hi,
   int Lq[NQ];
 #pragma unroll
   for (int q = 0; q < NQ; q++) Lq[q] = S->last[w][lane + 64u * q];
+  u8 *inb = S->stage_in[w], *outb = S->stage_out[w];
+  int carry = lo > 0u ? (int)S->cmap[bwt[lo - 1u]] : -1;     /* code of the position before the strip */
 
-  u32 nb = (lo + lane < hi) ? bwt[lo + lane] : 0u;
-  u32 nbp = (lo + lane < hi && lo + lane > 0u) ? bwt[lo + lane - 1u] : 0u;
-  for (u32 b0 = lo; b0 < hi; b0 += 64u) {
-    const u32 p = b0 + lane;
-    const bool ok = p < hi;
-    const u32 byte = nb, bytep = nbp;
-    const u32 pn = p + 64u;                               /* prefetch the next group */
-    nb = (pn < hi) ? bwt[pn] : 0u;
-    nbp = (pn < hi) ? bwt[pn - 1u] : 0u;
-    const int c = ok ? (int)S->cmap[byte] : 0;
-    const int cprev = (ok && p > 0u) ? (int)S->cmap[bytep] : -1;
-    u64 heads = __ballot(ok && c != cprev);
-    u32 myrank = 0;
-    while (heads) {
-      const int l = (int)__ffsll((long long)heads) - 1;
-      heads &= heads - 1ull;
-      const int s = __builtin_amdgcn_readlane(c, l);
-      const int owner = s & 63;
-      int pv;
-      if (NQ == 1) pv = __builtin_amdgcn_readlane(Lq[0], owner);
-      else {
-        const int q = s >> 6;
-        int mine = Lq[0];
+  uint4 nxt = { 0u, 0u, 0u, 0u };
+  if (lo + 16u * lane + 16u <= hi) nxt = *reinterpret_cast<const uint4 *>(bwt + lo + 16u * lane);
+  for (u32 c0 = lo; c0 < hi; c0 += MTF_CHUNK) {
+    const u32 q0 = c0 + 16u * lane;
+    if (q0 + 16u <= hi) *reinterpret_cast<uint4 *>(inb + 16u * lane) = nxt;
+    else for (u32 i = 0; i < 16u; i++) inb[16u * lane + i] = (q0 + i < hi) ? bwt[q0 + i] : (u8)0;
+    const u32 qn = q0 + MTF_CHUNK;
+    if (qn + 16u <= hi) nxt = *reinterpret_cast<const uint4 *>(bwt + qn);
+    wave_sync();
+    const u32 left = hi - c0;
+    const u32 nstrip = left >= MTF_CHUNK ? MTF_CHUNK / 64u : (left + 63u) / 64u;
+    for (u32 t = 0; t < nstrip; t++) {
+      const u32 b0 = c0 + 64u * t, p = b0 + lane;
+      const bool ok = p < hi;
+      const int c = ok ? (int)S->cmap[inb[64u * t + lane]] : 0;
+      int cprev = __shfl_up(c, 1u);
+      if (lane == 0u) cprev = carry;
+      carry = __builtin_amdgcn_readlane(c, 63);
+      u64 heads = __ballot(ok && c != cprev);
+      u32 myrank = 0;
+      while (heads) {
+        const int l = (int)__ffsll((long long)heads) - 1;
+        heads &= heads - 1ull;
+        const int s = __builtin_amdgcn_readlane(c, l);
+        const int owner = s & 63;
+        int pv;
+        if (NQ == 1) pv = __builtin_amdgcn_readlane(Lq[0], owner);
+        else {
+          const int q = s >> 6;
+          int mine = Lq[0];
 #pragma unroll
-        for (int j = 1; j < NQ; j++) mine = (q == j) ? Lq[j] : mine;
-        pv = __builtin_amdgcn_readlane(mine, owner);
+          for (int j = 1; j < NQ; j++) mine = (q == j) ? Lq[j] : mine;
+          pv = __builtin_amdgcn_readlane(mine, owner);
+        }
+        u32 cnt = 0;
+#pragma unroll
+        for (int j = 0; j < NQ; j++) cnt += (u32)__popcll(__ballot(Lq[j] > pv));
+        if ((int)lane == l) myrank = cnt;
+        const int np = (int)b0 + l;
+        if (NQ == 1) { if ((int)lane == owner) Lq[0] = np; }
+        else {
+          const int q = s >> 6;
+#pragma unroll
+          for (int j = 0; j < NQ; j++) if ((int)lane == owner && q == j) Lq[j] = np;
+        }
       }
-      u32 cnt = 0;
-#pragma unroll
-      for (int j = 0; j < NQ; j++) cnt += (u32)__popcll(__ballot(Lq[j] > pv));
-      if ((int)lane == l) myrank = cnt;
-      const int np = (int)b0 + l;
-      if (NQ == 1) { if ((int)lane == owner) Lq[0] = np; }
-      else {
-        const int q = s >> 6;
-#pragma unroll
-        for (int j = 0; j < NQ; j++) if ((int)lane == owner && q == j) Lq[j] = np;
-      }
+      outb[64u * t + lane] = (u8)myrank;
     }
-    if (ok) rk[p] = (u8)myrank;
+    wave_sync();
+    if (q0 + 16u <= hi) *reinterpret_cast<uint4 *>(rk + q0) = *reinterpret_cast<const uint4 *>(outb + 16u * lane);
+    else for (u32 i = 0; i < 16u; i++) if (q0 + i < hi) rk[q0 + i] = outb[16u * lane + i];
+    wave_sync();
   }
 }
 

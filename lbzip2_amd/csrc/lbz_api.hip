@@ -231,7 +231,7 @@ extern "C" int lbzamd_compress_device(lbzamd_ctx *c, const void *d_in_v, size_t 
       HIPCHK(hipEventRecord(c->ev[0], s));
       for (int i = 1; i <= 4; i++) HIPCHK(hipEventRecord(c->ev[i], s));
     }
-    hipLaunchKernelGGL(k_offsets, dim3(1), dim3(64), 0, s, (const lbz_block_meta *)c->meta, (u32)(2u * nsl),
+    hipLaunchKernelGGL(k_offsets, dim3(1), dim3(LBZ_WG), 0, s, (const lbz_block_meta *)c->meta, (u32)(2u * nsl),
                        (u32)c->bs100k, (u32)first, (u32)last, c->offs, c->st, d_out, (u64)out_cap);
     if (nsl)
       hipLaunchKernelGGL(k_gather, dim3((u32)(2u * nsl)), dim3(LBZ_WG), 0, s, (const u8 *)c->O,
