@@ -51,7 +51,7 @@
 #define MSD_SHIFT (64u - MSD_BITS)
 #define PART_HALO 48u
 #define BATCH_CAP (LBZ_WG * 4u)
-#define COUNT_GROUP 48u                 /* chunks of groups this short are ordered by counting */
+#define COUNT_GROUP 128u                /* groups this short are ordered by counting */
 #define WAVE_GROUP 1024u                /* batches holding a longer group are sorted by the whole workgroup */
 #define MAX_SYMS 32u                    /* symbols per key, capped (halo of the text tile) */
 #define REFINE_ROUNDS 12u                /* in-LDS refinements of a batch before rows are left to the doubling */
@@ -77,8 +77,6 @@ struct batch_lds {                      /* one batch resident in LDS */
   u8 tied[BATCH_CAP], tiedn[BATCH_CAP];
   u32 wcnt[LBZ_NW][256];
   u32 dbase[256];
-  u32 nlong, next_long;                 /* work list of long groups of the batch */
-  u16 lgroup[BATCH_CAP / COUNT_GROUP + 4u];
 };
 struct bwt_lds {
   wg_scratch sc;
@@ -690,34 +688,154 @@ __device__ void wave_radix_range(batch_lds *B, u32 cs, u32 ce)
 
 /* Order the rows of chunk [cs, ce) (whole groups of equal top MSD_BITS, data in A) by their
  * full keys.  Rows of short groups are placed by counting the smaller keys of their group;
- * each long group is radix-sorted on its own.                                              */
+ * each long group is radix-sorted on its own.  Wave-private: no workgroup barrier.          */
 __device__ void wave_sort_chunk(batch_lds *B, u32 cs, u32 ce)
 {
   const u32 lane = lane_id();
+  /* comparison keys made unique by the row number: (key << 12) | row.  Rows of one group agree
+     in the bits that are shifted out and in the 12 bits below them, so y < x is the sign of y - x */
+  for (u32 j = cs + lane; j < ce; j += 64u) B->kB[j] = (B->kA[j] << 12) | (u64)j;
+  wave_sync();
   for (u32 j0 = cs; j0 < ce; j0 += 64u) {
     const u32 j = j0 + lane;
     if (j < ce) {
       const u32 gs = B->gh[j], ge = B->gend[gs];
-      const u64 nk = B->kA[j];
       u32 dst = j;
       if (ge - gs <= COUNT_GROUP) {
+        const u64 x = B->kB[j];
         dst = gs;
-        for (u32 q = gs; q < ge; q++) {
-          const u64 k = B->kA[q];
-          dst += (k < nk) || (k == nk && q < j);
+        u32 q = gs;
+        for (; q + 2u <= ge; q += 2u) {
+          const u64 y0 = B->kB[q], y1 = B->kB[q + 1u];
+          dst += (u32)((y0 - x) >> 63) + (u32)((y1 - x) >> 63);
         }
+        if (q < ge) dst += (u32)((B->kB[q] - x) >> 63);
       }
-      B->kB[dst] = nk;
-      B->vB[dst] = B->vA[j];
+      B->ghn[j] = (u16)dst;
     }
   }
   wave_sync();
   for (u32 j = cs + lane; j < ce; j += 64u) {
-    B->kA[j] = B->kB[j]; B->vA[j] = B->vB[j];
-    /* long groups go on the batch's work list; any wave may take them */
-    if (B->gh[j] == j && ((u32)B->gend[j] - j) > COUNT_GROUP) B->lgroup[atomicAdd(&B->nlong, 1u)] = (u16)j;
+    const u32 dst = B->ghn[j];
+    B->kB[dst] = B->kA[j];
+    B->vB[dst] = B->vA[j];
   }
   wave_sync();
+  for (u32 j = cs + lane; j < ce; j += 64u) { B->kA[j] = B->kB[j]; B->vA[j] = B->vB[j]; }
+  wave_sync();
+  for (u32 j0 = cs; j0 < ce; j0 += 64u) {               /* long groups, one after the other */
+    const u32 j = j0 + lane;
+    bool longhead = false;
+    if (j < ce && B->gh[j] == j) longhead = ((u32)B->gend[j] - j) > COUNT_GROUP;
+    u64 heads = __ballot(longhead);
+    while (heads) {
+      const u32 gs = j0 + (u32)__ffsll((long long)heads) - 1u;
+      heads &= heads - 1ull;
+      wave_radix_range(B, gs, B->gend[gs]);
+    }
+  }
+}
+
+/* Runs of equal 64-bit keys inside the sorted chunk [cs, ce): gh, gend, tied, wave-private.
+ * Returns the number of tied rows (wave-uniform).                                          */
+__device__ u32 wave_runs(batch_lds *B, u32 cs, u32 ce)
+{
+  const u32 lane = lane_id();
+  u32 carry = cs, ntied = 0;
+  for (u32 j0 = cs; j0 < ce; j0 += 64u) {
+    const u32 j = j0 + lane;
+    const bool ok = j < ce;
+    const u64 k = ok ? B->kA[j] : 0ull;
+    const bool hd = ok && (j == cs || B->kA[j - 1u] != k);
+    const bool hn = ok && (j + 1u >= ce || B->kA[j + 1u] != k);
+    u32 h = wave_incl_max(hd ? j : 0u);
+    if (h < carry) h = carry;                            /* run opened in an earlier strip */
+    if (ok) {
+      B->gh[j] = (u16)h;
+      B->tied[j] = (hd && hn) ? 0 : 1;
+      if (hn) B->gend[h] = (u16)(j + 1u);
+    }
+    ntied += (u32)__popcll(__ballot(ok && !(hd && hn)));
+    carry = (u32)__shfl((int)h, 63);
+  }
+  wave_sync();
+  return ntied;
+}
+
+/* Everything a wave does for its chunk after the groups are known: order the rows (unless they
+ * already are), refine runs of equal keys with further symbols of the text, emit.  No workgroup
+ * barrier inside: the 16 waves of a batch run their chunks independently.                   */
+__device__ void wave_finish_chunk(batch_lds *B, u32 cs, u32 ce, bool need_sort, const u8 *T, u32 n, keycfg c,
+                                  u8 *bwt, u32 *sa, u32 lo, lbz_block_meta *meta, bwt_lds *S)
+{
+  const u32 lane = lane_id();
+  u32 ntied;
+  if (need_sort) {
+    wave_sort_chunk(B, cs, ce);
+    ntied = wave_runs(B, cs, ce);
+  } else {
+    ntied = 0;
+    for (u32 j0 = cs; j0 < ce; j0 += 64u) {
+      const u32 j = j0 + lane;
+      ntied += (u32)__popcll(__ballot(j < ce && B->tied[j]));
+    }
+  }
+
+  u32 depth = c.sy;
+  for (u32 r = 0; r < REFINE_ROUNDS && ntied; r++) {
+    /* next sy symbols of every tied rotation */
+    for (u32 j = cs + lane; j < ce; j += 64u)
+      if (B->tied[j]) {
+        const u32 idx = B->vA[j] & 0x00FFFFFFu;
+        B->kB[j] = key_from_text(T, n, (idx + depth % n) % n, S->cmap, c);
+      }
+    wave_sync();
+    for (u32 j = cs + lane; j < ce; j += 64u)
+      if (B->tied[j]) {
+        const u32 gs = B->gh[j], ge = B->gend[gs];
+        const u64 nk = B->kB[j];
+        u32 less = 0, eqb = 0, eqt = 0;
+        for (u32 q = gs; q < ge; q++) {
+          const u64 k = B->kB[q];
+          less += k < nk;
+          eqt += k == nk;
+          eqb += (k == nk) && (q < j);
+        }
+        const u32 dst = gs + less + eqb;
+        B->vB[dst] = B->vA[j];
+        B->ghn[dst] = (u16)(gs + less);
+        B->tiedn[dst] = eqt > 1u ? 1 : 0;
+      }
+    wave_sync();
+    for (u32 j = cs + lane; j < ce; j += 64u)
+      if (B->tied[j]) { B->vA[j] = B->vB[j]; B->gh[j] = B->ghn[j]; B->tied[j] = (u8)(B->tiedn[j] | 2u); }
+    wave_sync();
+    ntied = 0;
+    for (u32 j0 = cs; j0 < ce; j0 += 64u) {
+      const u32 j = j0 + lane;
+      bool still = false;
+      if (j < ce && (B->tied[j] & 2u)) {                 /* was tied in this round */
+        const u32 g = B->gh[j];
+        if (j + 1u >= ce || B->gh[j + 1u] != g) B->gend[g] = (u16)(j + 1u);
+        still = B->tied[j] & 1u;
+      }
+      ntied += (u32)__popcll(__ballot(still));
+    }
+    wave_sync();
+    for (u32 j = cs + lane; j < ce; j += 64u) B->tied[j] &= 1u;
+    wave_sync();
+    depth += c.sy;
+  }
+
+  for (u32 j = cs + lane; j < ce; j += 64u) {
+    const u32 v = B->vA[j];
+    const u32 idx = v & 0x00FFFFFFu;
+    const bool flagged = B->tied[j] && B->gh[j] != j;
+    bwt[lo + j] = S->inv[v >> 24];
+    sa[lo + j] = idx | (flagged ? TIE_FLAG : 0u);
+    if (idx == 0u) meta->bwt_idx = lo + j;
+  }
+  if (ntied && lane == 0u) S->bc[8] = 1u;
 }
 
 /* Runs of rows whose keys agree after `>> sh`: fills gh (first row of the run), tied (run longer
@@ -753,58 +871,12 @@ __device__ u32 batch_runs(batch_lds *B, const u64 *kR, u32 cnt, u32 sh, u32 *max
   return ntied;
 }
 
-/* Rank every tied row inside its run by keyarr (ties keep their current order), permute the
- * values accordingly and split the runs at key changes.  Returns this thread's count of rows
- * that are still tied.                                                                     */
-__device__ u32 batch_rank_round(batch_lds *B, const u64 *keyarr, u32 *vR, u32 *vX, u32 cnt)
-{
-  const u32 j0 = threadIdx.x * SORT_IPT;
-  u32 ntied = 0;
-#pragma unroll
-  for (u32 i = 0; i < SORT_IPT; i++) {
-    const u32 j = j0 + i;
-    if (j < cnt && B->tied[j]) {
-      const u32 gs = B->gh[j], ge = B->gend[gs];
-      const u64 nk = keyarr[j];
-      u32 less = 0, eqb = 0, eqt = 0;
-#pragma unroll 4
-      for (u32 q = gs; q < ge; q++) {
-        const u64 k = keyarr[q];
-        less += k < nk;
-        eqt += k == nk;
-        eqb += (k == nk) && (q < j);
-      }
-      const u32 dst = gs + less + eqb;
-      vX[dst] = vR[j];
-      B->ghn[dst] = (u16)(gs + less);
-      B->tiedn[dst] = eqt > 1u ? 1 : 0;
-      ntied += eqt > 1u;
-    }
-  }
-  __syncthreads();
-  u32 was = 0;
-#pragma unroll
-  for (u32 i = 0; i < SORT_IPT; i++) {
-    const u32 j = j0 + i;
-    if (j < cnt && B->tied[j]) { was |= 1u << i; vR[j] = vX[j]; B->gh[j] = B->ghn[j]; B->tied[j] = B->tiedn[j]; }
-  }
-  __syncthreads();
-#pragma unroll
-  for (u32 i = 0; i < SORT_IPT; i++) {
-    const u32 j = j0 + i;
-    if ((was >> i) & 1u) {
-      const u32 g = B->gh[j];
-      if (j + 1u >= cnt || B->gh[j + 1u] != g) B->gend[g] = (u16)(j + 1u);
-    }
-  }
-  __syncthreads();
-  return ntied;
-}
-
 /* Order rows [lo, lo+cnt) completely (as far as REFINE_ROUNDS reach) and emit them.
  * presorted: rows already sorted by the full key (cut at key boundaries); otherwise they are
- * only grouped by the partition's top MSD_BITS.  preloaded: the batch already sits in (kA,vA).
- * Sets S->bc[8] if ties are left over.                                                      */
+ * only grouped by the partition's top MSD_BITS.  preloaded: the batch already sits in (kA,vA),
+ * in text order (a whole small block).  Sets S->bc[8] if ties are left over.
+ * Workgroup-wide steps: load, (rarely) a full LDS radix sort, the group scan.  Everything else
+ * happens per wave on the groups that start in the wave's 256-row window.                   */
 __device__ void batch_process(const u8 *T, u32 n, u8 *bwt, lbz_block_meta *meta, bwt_slot s,
                               bwt_lds *S, keycfg c, u32 lo, u32 cnt, bool presorted, bool preloaded)
 {
@@ -816,82 +888,36 @@ __device__ void batch_process(const u8 *T, u32 n, u8 *bwt, lbz_block_meta *meta,
     __syncthreads();
   }
   const u64 tb1 = wall_clock64();
-  u32 cur = 0, maxrun, ntied;
-  if (!presorted) {
-    if (preloaded) {                     /* a whole small block, in text order */
-      cur = lds_radix_sort(B, cnt, S);
-    } else {
-      /* groups of equal top MSD_BITS: wave w sorts the groups that start in its 256-row window */
-      ntied = batch_runs(B, B->kA, cnt, MSD_SHIFT, &maxrun, S);
-      const u64 tx1 = wall_clock64();
-      if (tid == 0) S->bc[14] += (u32)(tx1 - tb1);
-      if (maxrun > WAVE_GROUP) {
-        cur = lds_radix_sort(B, cnt, S);
-      } else {
-        const u32 w0 = wave_id() * 256u, w1 = w0 + 256u;
-        if (tid == 0) { B->nlong = 0; B->next_long = 0; }
-        __syncthreads();
-        if (w0 < cnt) {
-          const u32 cs = (B->gh[w0] == w0) ? w0 : B->gend[B->gh[w0]];
-          const u32 ce = (w1 >= cnt) ? cnt : ((B->gh[w1] == w1) ? w1 : B->gend[B->gh[w1]]);
-          if (cs < ce) wave_sort_chunk(B, cs, ce);
-        }
-        __syncthreads();
-        for (;;) {                                         /* long groups, one wave each */
-          u32 it = 0;
-          if (lane_id() == 0) it = atomicAdd(&B->next_long, 1u);
-          it = (u32)__shfl((int)it, 0);
-          if (it >= B->nlong) break;
-          const u32 gs = B->lgroup[it];
-          wave_radix_range(B, gs, B->gend[gs]);
-        }
-        __syncthreads();
-        if (tid == 0) S->bc[15] += (u32)(wall_clock64() - tx1);
-      }
+  bool need_sort = !presorted;
+  u32 maxrun;
+  if (preloaded) {
+    if (lds_radix_sort(B, cnt, S)) {
+      for (u32 i = tid; i < cnt; i += LBZ_WG) { B->kA[i] = B->kB[i]; B->vA[i] = B->vB[i]; }
+      __syncthreads();
     }
+    need_sort = false;
   }
-  ntied = batch_runs(B, cur ? B->kB : B->kA, cnt, 0u, &maxrun, S);
-  u64 *kX = cur ? B->kA : B->kB;
-  u32 *vR = cur ? B->vB : B->vA, *vX = cur ? B->vA : B->vB;
-  u32 anytied = wg_sum(ntied, &S->sc);
+  batch_runs(B, B->kA, cnt, need_sort ? MSD_SHIFT : 0u, &maxrun, S);
+  if (need_sort && maxrun > WAVE_GROUP) {
+    if (lds_radix_sort(B, cnt, S)) {
+      for (u32 i = tid; i < cnt; i += LBZ_WG) { B->kA[i] = B->kB[i]; B->vA[i] = B->vB[i]; }
+      __syncthreads();
+    }
+    need_sort = false;
+    batch_runs(B, B->kA, cnt, 0u, &maxrun, S);
+  }
   const u64 tb2 = wall_clock64();
-
-  const u32 j0 = tid * SORT_IPT;
-  u32 depth = c.sy;
-  for (u32 r = 0; r < REFINE_ROUNDS && anytied; r++) {
-    /* next sy symbols of every tied rotation */
-#pragma unroll
-    for (u32 i = 0; i < SORT_IPT; i++) {
-      const u32 j = j0 + i;
-      if (j < cnt && B->tied[j]) {
-        const u32 idx = vR[j] & 0x00FFFFFFu;
-        kX[j] = key_from_text(T, n, (idx + depth % n) % n, S->cmap, c);
-      }
-    }
-    __syncthreads();
-    ntied = batch_rank_round(B, kX, vR, vX, cnt);
-    anytied = wg_sum(ntied, &S->sc);
-    depth += c.sy;
-  }
-
-  const u64 tb3 = wall_clock64();
-#pragma unroll
-  for (u32 i = 0; i < SORT_IPT; i++) {
-    const u32 j = j0 + i;
-    if (j < cnt) {
-      const u32 v = vR[j];
-      const u32 idx = v & 0x00FFFFFFu;
-      const bool flagged = B->tied[j] && B->gh[j] != j;
-      bwt[lo + j] = S->inv[v >> 24];
-      s.sa[lo + j] = idx | (flagged ? TIE_FLAG : 0u);
-      if (idx == 0u) meta->bwt_idx = lo + j;
+  {
+    const u32 w0 = wave_id() * 256u, w1 = w0 + 256u;
+    if (w0 < cnt) {
+      const u32 cs = (B->gh[w0] == w0) ? w0 : B->gend[B->gh[w0]];
+      const u32 ce = (w1 >= cnt) ? cnt : ((B->gh[w1] == w1) ? w1 : B->gend[B->gh[w1]]);
+      if (cs < ce) wave_finish_chunk(B, cs, ce, need_sort, T, n, c, bwt, s.sa, lo, meta, S);
     }
   }
-  if (anytied && tid == 0) S->bc[8] = 1u;
   __syncthreads();
   if (tid == 0) {
-    S->bc[10] += (u32)(tb1 - tb0); S->bc[11] += (u32)(tb2 - tb1);
-    S->bc[12] += (u32)(tb3 - tb2); S->bc[13] += (u32)(wall_clock64() - tb3);
+    S->bc[10] += (u32)(tb1 - tb0); S->bc[11] += (u32)(tb2 - tb1); S->bc[12] += (u32)(wall_clock64() - tb2);
   }
 }
 
@@ -1067,8 +1093,7 @@ k_bwt_batch(const u8 *Tbase, u8 *Bbase, lbz_block_meta *meta, lbz_layout L, u32 
     M->rounds = 0;
     M->sort_elems = n;
     M->ticks[0] = (u32)(wall_clock64() - tk0);
-    for (u32 i = 0; i < 4; i++) M->ticks[3 + i] = S.bc[10 + i];   /* load, sort, refine, emit */
-    M->ticks[7] = S.bc[15]; M->ticks[1] = S.bc[14];               /* wave chunk sort; first batch_runs */
+    for (u32 i = 0; i < 3; i++) M->ticks[3 + i] = S.bc[10 + i];   /* load, group scan (+block sorts), per-wave part */
   }
 }
 

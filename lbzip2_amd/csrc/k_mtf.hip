@@ -134,7 +134,6 @@ k_mtf(const u8 *Bbase, u8 *Rbase, u16 *Vbase, u32 *freq_out, lbz_block_meta *met
     if (tid < 256u) S.cmap[tid] = (u8)ex;
   }
   const u32 eob = tot_inuse + 1u;
-  const u64 tm0 = wall_clock64();
   for (u32 i = tid; i < LBZ_NW * 256u; i += LBZ_WG) (&S.last[0][0])[i] = -1;
   for (u32 i = tid; i < LBZ_MAX_ALPHA + 2u; i += LBZ_WG) S.hist[i] = 0;
   __syncthreads();
@@ -166,14 +165,12 @@ k_mtf(const u8 *Bbase, u8 *Rbase, u16 *Vbase, u32 *freq_out, lbz_block_meta *met
   }
   __syncthreads();
 
-  const u64 tm1 = wall_clock64();
   /* ranks at run heads, wave-serial over heads; NQ = registers needed for the alphabet */
   if (tot_inuse <= 64u) mtf_ranks<1>(bwt, rk, lo, hi, &S);
   else if (tot_inuse <= 128u) mtf_ranks<2>(bwt, rk, lo, hi, &S);
   else mtf_ranks<4>(bwt, rk, lo, hi, &S);
   __syncthreads();
 
-  const u64 tm2 = wall_clock64();
   /* zero-run coding + histogram */
   u32 carry_nz = 0;        /* (position of the last non-zero rank) + 1 */
   u32 o_base = 0;
@@ -243,7 +240,6 @@ k_mtf(const u8 *Bbase, u8 *Rbase, u16 *Vbase, u32 *freq_out, lbz_block_meta *met
     for (; o < padded; o++) mtfv[o] = (u16)(eob + 1u);      /* dummy symbol, encode.c:1034-1035 */
     M->nmtf = nm;
     M->alpha = eob + 1u;
-    M->ticks[5] = (u32)(tm1 - tm0); M->ticks[6] = (u32)(tm2 - tm1); M->ticks[7] = (u32)(wall_clock64() - tm2);
   }
   __syncthreads();
   for (u32 i = tid; i < LBZ_MAX_ALPHA + 2u; i += LBZ_WG) freq_out[(size_t)blk * 260u + i] = S.hist[i];

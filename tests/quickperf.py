@@ -30,7 +30,6 @@ for kind in ("text", "rand"):
             bi = ctx.block_info(b)
             for i in range(8): tk[i] += bi.ticks[i]
             cnt += 1
-        print("   mean ms/blk: batchkernel=%.2f runs1=%.2f | partition=%.2f load=%.2f ldssort=%.2f refine=%.2f emit=%.2f chunksort=%.2f (rounds=%d)"
-              % tuple([t / cnt / 1e5 for t in tk[:8]] + [bi.rounds]), flush=True)
-        print("   mtf ms/blk: lastocc=%.2f ranks=%.2f zrle=%.2f" % (tk[5]/cnt/1e5, tk[6]/cnt/1e5, tk[7]/cnt/1e5), flush=True)
+        print("   batch kernel ms/blk: total=%.2f load=%.2f groupscan=%.2f waves=%.2f (fix rounds=%d)"
+              % (tk[0] / cnt / 1e5, tk[3] / cnt / 1e5, tk[4] / cnt / 1e5, tk[5] / cnt / 1e5, bi.rounds), flush=True)
         ctx.close()
