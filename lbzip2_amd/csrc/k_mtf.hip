@@ -76,31 +76,32 @@ __device__ __forceinline__ void mtf_ranks(const u8 *bwt, u8 *rk, u32 lo, u32 hi,
       if (lane == 0u) cprev = carry;
       carry = __builtin_amdgcn_readlane(c, 63);
       u64 heads = __ballot(ok && c != cprev);
-      u32 myrank = 0;
+      int myrank = 0;
+      const int sb0 = __builtin_amdgcn_readfirstlane((int)b0);
       while (heads) {
+        /* all scalar except the compare: symbol and its last position are lane reads, rank and
+           the new position are lane writes */
         const int l = (int)__ffsll((long long)heads) - 1;
-        heads &= heads - 1ull;
+        heads &= ~(1ull << l);
         const int s = __builtin_amdgcn_readlane(c, l);
-        const int owner = s & 63;
-        int pv;
-        if (NQ == 1) pv = __builtin_amdgcn_readlane(Lq[0], owner);
-        else {
-          const int q = s >> 6;
+        const int np = sb0 + l;
+        if (NQ == 1) {
+          const int pv = __builtin_amdgcn_readlane(Lq[0], s);
+          const int cnt = (int)__popcll(__ballot(Lq[0] > pv));
+          myrank = lane_write(myrank, cnt, l);
+          Lq[0] = lane_write(Lq[0], np, s);
+        } else {
+          const int owner = s & 63, q = s >> 6;
           int mine = Lq[0];
 #pragma unroll
           for (int j = 1; j < NQ; j++) mine = (q == j) ? Lq[j] : mine;
-          pv = __builtin_amdgcn_readlane(mine, owner);
-        }
-        u32 cnt = 0;
+          const int pv = __builtin_amdgcn_readlane(mine, owner);
+          int cnt = 0;
 #pragma unroll
-        for (int j = 0; j < NQ; j++) cnt += (u32)__popcll(__ballot(Lq[j] > pv));
-        if ((int)lane == l) myrank = cnt;
-        const int np = (int)b0 + l;
-        if (NQ == 1) { if ((int)lane == owner) Lq[0] = np; }
-        else {
-          const int q = s >> 6;
+          for (int j = 0; j < NQ; j++) cnt += (int)__popcll(__ballot(Lq[j] > pv));
+          myrank = lane_write(myrank, cnt, l);
 #pragma unroll
-          for (int j = 0; j < NQ; j++) if ((int)lane == owner && q == j) Lq[j] = np;
+          for (int j = 0; j < NQ; j++) if (q == j) Lq[j] = lane_write(Lq[j], np, owner);
         }
       }
       outb[64u * t + lane] = (u8)myrank;

@@ -11,6 +11,7 @@
 #include <hip/hip_runtime.h>
 
 #include "lbz_common.h"
+#include <lbz_asm.h>
 
 typedef unsigned long long u64;
 typedef unsigned int u32;
