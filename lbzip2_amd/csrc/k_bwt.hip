@@ -19,7 +19,7 @@
  *   batches   consecutive whole 24-bit groups of <= 4096 rows are pulled into LDS; rows are
  *             ranked inside their group by counting smaller keys (groups are short), and every
  *             run of equal 64-bit keys is refined IN LDS by fetching the rotation's next S
- *             symbols from the text and ranking inside the run, up to 12 times.  A finished
+ *             symbols from the text and re-sorting the run on them (up to 12 times while ties are few and shrinking).  A finished
  *             batch writes 1 B (BWT byte) + 4 B (row) per rotation.
  *   oversized a 24-bit group larger than a batch is sorted on its remaining 40 key bits by the
  *             HBM radix sorter and then cut into batches at key boundaries.
@@ -689,27 +689,38 @@ __device__ void wave_radix_range(batch_lds *B, u32 cs, u32 ce)
 /* Order the rows of chunk [cs, ce) (whole groups of equal top MSD_BITS, data in A) by their
  * full keys.  Rows of short groups are placed by counting the smaller keys of their group;
  * each long group is radix-sorted on its own.  Wave-private: no workgroup barrier.          */
+template <bool PREFIX_EQUAL>
 __device__ void wave_sort_chunk(batch_lds *B, u32 cs, u32 ce)
 {
   const u32 lane = lane_id();
-  /* comparison keys made unique by the row number: (key << 12) | row.  Rows of one group agree
-     in the bits that are shifted out and in the 12 bits below them, so y < x is the sign of y - x */
-  for (u32 j = cs + lane; j < ce; j += 64u) B->kB[j] = (B->kA[j] << 12) | (u64)j;
-  wave_sync();
+  if (PREFIX_EQUAL) {
+    /* comparison keys made unique by the row number: (key << 12) | row.  Rows of one group agree
+       in the bits that are shifted out and in the 12 bits below them, so y < x is the sign of y - x */
+    for (u32 j = cs + lane; j < ce; j += 64u) B->kB[j] = (B->kA[j] << 12) | (u64)j;
+    wave_sync();
+  }
   for (u32 j0 = cs; j0 < ce; j0 += 64u) {
     const u32 j = j0 + lane;
     if (j < ce) {
       const u32 gs = B->gh[j], ge = B->gend[gs];
       u32 dst = j;
-      if (ge - gs <= COUNT_GROUP) {
-        const u64 x = B->kB[j];
+      if (ge - gs <= COUNT_GROUP && ge - gs > 1u) {
         dst = gs;
-        u32 q = gs;
-        for (; q + 2u <= ge; q += 2u) {
-          const u64 y0 = B->kB[q], y1 = B->kB[q + 1u];
-          dst += (u32)((y0 - x) >> 63) + (u32)((y1 - x) >> 63);
+        if (PREFIX_EQUAL) {
+          const u64 x = B->kB[j];
+          u32 q = gs;
+          for (; q + 2u <= ge; q += 2u) {
+            const u64 y0 = B->kB[q], y1 = B->kB[q + 1u];
+            dst += (u32)((y0 - x) >> 63) + (u32)((y1 - x) >> 63);
+          }
+          if (q < ge) dst += (u32)((B->kB[q] - x) >> 63);
+        } else {
+          const u64 x = B->kA[j];
+          for (u32 q = gs; q < ge; q++) {
+            const u64 y = B->kA[q];
+            dst += (y < x) || (y == x && q < j);
+          }
         }
-        if (q < ge) dst += (u32)((B->kB[q] - x) >> 63);
       }
       B->ghn[j] = (u16)dst;
     }
@@ -737,7 +748,9 @@ __device__ void wave_sort_chunk(batch_lds *B, u32 cs, u32 ce)
 }
 
 /* Runs of equal 64-bit keys inside the sorted chunk [cs, ce): gh, gend, tied, wave-private.
- * Returns the number of tied rows (wave-uniform).                                          */
+ * WITHIN: the chunk already has runs (gh) that have just been re-sorted on new keys; new runs
+ * never cross an old run's first row.  Returns the number of tied rows (wave-uniform).      */
+template <bool WITHIN>
 __device__ u32 wave_runs(batch_lds *B, u32 cs, u32 ce)
 {
   const u32 lane = lane_id();
@@ -746,8 +759,13 @@ __device__ u32 wave_runs(batch_lds *B, u32 cs, u32 ce)
     const u32 j = j0 + lane;
     const bool ok = j < ce;
     const u64 k = ok ? B->kA[j] : 0ull;
-    const bool hd = ok && (j == cs || B->kA[j - 1u] != k);
-    const bool hn = ok && (j + 1u >= ce || B->kA[j + 1u] != k);
+    bool hd = ok && (j == cs || B->kA[j - 1u] != k);
+    bool hn = ok && (j + 1u >= ce || B->kA[j + 1u] != k);
+    if (WITHIN && ok) {
+      hd = hd || B->gh[j] == j;
+      hn = hn || (j + 1u < ce && B->gh[j + 1u] == j + 1u);
+    }
+    wave_sync();                                         /* old gh read before it is rewritten */
     u32 h = wave_incl_max(hd ? j : 0u);
     if (h < carry) h = carry;                            /* run opened in an earlier strip */
     if (ok) {
@@ -771,8 +789,8 @@ __device__ void wave_finish_chunk(batch_lds *B, u32 cs, u32 ce, bool need_sort, 
   const u32 lane = lane_id();
   u32 ntied;
   if (need_sort) {
-    wave_sort_chunk(B, cs, ce);
-    ntied = wave_runs(B, cs, ce);
+    wave_sort_chunk<true>(B, cs, ce);
+    ntied = wave_runs<false>(B, cs, ce);
   } else {
     ntied = 0;
     for (u32 j0 = cs; j0 < ce; j0 += 64u) {
@@ -781,50 +799,29 @@ __device__ void wave_finish_chunk(batch_lds *B, u32 cs, u32 ce, bool need_sort, 
     }
   }
 
+  /* Refinement pays while ties are few or shrink quickly.  A chunk with many ties that barely
+     shrink (source code, markup, logs: long exact repeats) is left to the prefix doubling, which
+     needs O(log depth) rounds instead of depth/sy.  A handful of deep ties is cheaper to chase
+     here than to pay the doubling's full rank build for.                                    */
   u32 depth = c.sy;
-  for (u32 r = 0; r < REFINE_ROUNDS && ntied; r++) {
-    /* next sy symbols of every tied rotation */
+  u32 before = ntied;
+  for (u32 r = 0; r < REFINE_ROUNDS && ntied && before; r++) {
+    /* block-wide budget of tied-row rounds: a block that has burnt n/8 of them is a repetitive
+       one that will need the doubling anyway -- stop refining its remaining chunks */
+    if ((u32)__builtin_amdgcn_readfirstlane((int)S->bc[9]) > n / 8u) break;
+    if (lane == 0u) atomicAdd(&S->bc[9], ntied);
+    /* every tied rotation trades its key for its next sy symbols; its run is re-sorted on them
+       (counting for short runs, a per-run radix sort otherwise) and split where they differ */
     for (u32 j = cs + lane; j < ce; j += 64u)
       if (B->tied[j]) {
         const u32 idx = B->vA[j] & 0x00FFFFFFu;
-        B->kB[j] = key_from_text(T, n, (idx + depth % n) % n, S->cmap, c);
+        B->kA[j] = key_from_text(T, n, (idx + depth % n) % n, S->cmap, c);
       }
     wave_sync();
-    for (u32 j = cs + lane; j < ce; j += 64u)
-      if (B->tied[j]) {
-        const u32 gs = B->gh[j], ge = B->gend[gs];
-        const u64 nk = B->kB[j];
-        u32 less = 0, eqb = 0, eqt = 0;
-        for (u32 q = gs; q < ge; q++) {
-          const u64 k = B->kB[q];
-          less += k < nk;
-          eqt += k == nk;
-          eqb += (k == nk) && (q < j);
-        }
-        const u32 dst = gs + less + eqb;
-        B->vB[dst] = B->vA[j];
-        B->ghn[dst] = (u16)(gs + less);
-        B->tiedn[dst] = eqt > 1u ? 1 : 0;
-      }
-    wave_sync();
-    for (u32 j = cs + lane; j < ce; j += 64u)
-      if (B->tied[j]) { B->vA[j] = B->vB[j]; B->gh[j] = B->ghn[j]; B->tied[j] = (u8)(B->tiedn[j] | 2u); }
-    wave_sync();
-    ntied = 0;
-    for (u32 j0 = cs; j0 < ce; j0 += 64u) {
-      const u32 j = j0 + lane;
-      bool still = false;
-      if (j < ce && (B->tied[j] & 2u)) {                 /* was tied in this round */
-        const u32 g = B->gh[j];
-        if (j + 1u >= ce || B->gh[j + 1u] != g) B->gend[g] = (u16)(j + 1u);
-        still = B->tied[j] & 1u;
-      }
-      ntied += (u32)__popcll(__ballot(still));
-    }
-    wave_sync();
-    for (u32 j = cs + lane; j < ce; j += 64u) B->tied[j] &= 1u;
-    wave_sync();
+    wave_sort_chunk<false>(B, cs, ce);
+    ntied = wave_runs<true>(B, cs, ce);
     depth += c.sy;
+    if (ntied > 256u && 4u * ntied > 3u * before) before = 0; else before = ntied;   /* many ties, barely shrinking */
   }
 
   for (u32 j = cs + lane; j < ce; j += 64u) {

@@ -38,6 +38,21 @@ def gen(kind, n, seed):
             out += bytes([b]) * 4
             prev = b
         return bytes(out[:n])
+    if kind == "lines":
+        # source-code-like: lines drawn from a small pool (long exact repeats, indentation runs)
+        pool_txt = L.gen_text(40000, seed + 1000).split(b"\n")
+        pool = [b" " * (4 * (i % 5)) + l[:20 + (i * 7) % 90] for i, l in enumerate(pool_txt) if l][:150]
+        r = L.gen_rand(4 * (n // 20 + 64), seed)
+        out = bytearray()
+        i = 0
+        while len(out) < n:
+            k = int.from_bytes(r[4 * i:4 * i + 4], "little"); i += 1
+            if k % 7 == 0 and len(out) > 4000:           # repeat a recent passage verbatim
+                start = len(out) - 1 - (k >> 8) % 3500
+                out += out[start:start + 200 + (k >> 20) % 800]
+            else:
+                out += pool[(k >> 4) % len(pool)] + b"\n"
+        return bytes(out[:n])
     raise ValueError(kind)
 
 

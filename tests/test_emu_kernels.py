@@ -40,7 +40,8 @@ def _stages(emu, data, level):
     ("banana", b"banana"), ("one", b"a"), ("two", b"ab"), ("same", b"\0" * 7),
     ("text3k", gen("text", 3000, 5)), ("rand5k", gen("rand", 5000, 6)),
     ("zeros", bytes(10000)), ("abab", b"ab" * 500), ("all256", bytes(range(256)) * 3),
-    ("text30k", gen("text", 30000, 7)),
+    ("text30k", gen("text", 30000, 7)), ("lines40k", gen("lines", 40000, 3)),
+    ("alpha100", bytes((i * 37 + (i >> 3) + (i >> 9)) % 100 for i in range(12000))),
 ])
 def test_stages_small(emu, name, data):
     _stages(emu, data, 1)

@@ -98,6 +98,16 @@ def test_ragged_sizes_vs_oracle(lib, n):
         assert lib.compress(data, lvl) == L.orc_compress(data, lvl), (kind, n)
 
 
+def test_repetitive_source_like_text(lib):
+    """Long exact repeats and indentation runs (what source code and markup look like): large
+    groups, deep ties, the prefix-doubling finish."""
+    for n, seed in ((3_000_000, 4), (900_000, 5)):
+        data = gen("lines", n, seed)
+        for lvl in (9, 1):
+            want, _ = cpu_reference(data, lvl)
+            assert lib.compress(data, lvl) == want, (n, lvl)
+
+
 def test_levels_1_to_9(lib):
     data = gen("text", 1234567, 77)
     for lvl in range(1, 10):
