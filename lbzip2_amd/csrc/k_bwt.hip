@@ -197,14 +197,15 @@ __device__ u32 wg_radix_sort(u64 *k0, u32 *v0, u64 *k1, u32 *v1, u32 m, u32 nbit
  *   head  = starts a group: FLAGS ? the value's tie flag is clear : key differs from entry k-1
  *   rank  = row of the group's first entry
  * writes sa[row] = suffix, isa[suffix] = rank, and compacts the entries that are still
- * tied into (sufx, grp, pos).  pin == nullptr means row == k.  Returns the number of
- * still-tied entries.                                                                    */
+ * tied into (sufx, grp, pos) from index out_base on.  Entry k sits in row rowbase + k.  If bwt
+ * is given, entries that are no longer tied get their BWT byte written.  Returns out_base plus
+ * the number of still-tied entries.                                                       */
 template <bool FLAGS>
-__device__ u32 wg_regroup(const u64 *key, const u32 *val, const u32 *pin, u32 m,
-                          bwt_slot s, bwt_lds *S)
+__device__ u32 wg_regroup(const u64 *key, const u32 *val, u32 rowbase, u32 out_base, u32 m,
+                          bwt_slot s, bwt_lds *S, const u8 *T, u32 n, u8 *bwt)
 {
   const u32 tid = threadIdx.x;
-  u32 carry_rank = 0, carry_cnt = 0;
+  u32 carry_rank = 0, carry_cnt = out_base;
   for (u32 t0 = 0; t0 < m; t0 += SORT_TILE) {
     const u32 k0 = t0 + tid * SORT_IPT;
     u32 vv[SORT_IPT], row[SORT_IPT];
@@ -214,7 +215,7 @@ __device__ u32 wg_regroup(const u64 *key, const u32 *val, const u32 *pin, u32 m,
       for (u32 i = 0; i < SORT_IPT; i++) {
         const u32 k = k0 + i;
         vv[i] = k < m ? val[k] : 0u;
-        row[i] = k;
+        row[i] = rowbase + k;
       }
       const u32 vnext = (k0 + SORT_IPT < m) ? val[k0 + SORT_IPT] : 0u;
 #pragma unroll
@@ -232,7 +233,7 @@ __device__ u32 wg_regroup(const u64 *key, const u32 *val, const u32 *pin, u32 m,
         const u32 k = k0 + i;
         kk[i + 1] = k < m ? key[k] : 0ull;
         vv[i] = k < m ? val[k] : 0u;
-        row[i] = k < m ? (pin ? pin[k] : k) : 0u;
+        row[i] = rowbase + k;
       }
       kk[0] = (k0 > 0 && k0 <= m) ? key[k0 - 1] : 0ull;
       kk[SORT_IPT + 1] = (k0 + SORT_IPT < m) ? key[k0 + SORT_IPT] : 0ull;
@@ -269,6 +270,8 @@ __device__ u32 wg_regroup(const u64 *key, const u32 *val, const u32 *pin, u32 m,
           s.grp[o] = rank1 - 1u;
           s.pos[o] = row[i];
           o++;
+        } else if (bwt) {
+          bwt[row[i]] = T[vv[i] ? vv[i] - 1u : n - 1u];
         }
       }
     }
@@ -279,42 +282,6 @@ __device__ u32 wg_regroup(const u64 *key, const u32 *val, const u32 *pin, u32 m,
   }
   __syncthreads();
   return carry_cnt;
-}
-
-/* ======================================================================= deep ties
- * Prefix doubling from depth h0 on a suffix array whose unresolved rows carry TIE_FLAG.   */
-__device__ void finish_by_doubling(const u8 *T, u32 n, u8 *bwt, lbz_block_meta *meta, bwt_slot s,
-                                   bwt_lds *S, u32 h0, u32 *rounds_out, u32 *work_out)
-{
-  const u32 tid = threadIdx.x;
-  u32 m = wg_regroup<true>(nullptr, s.sa, nullptr, n, s, S);
-  u32 rounds = 0, work = 0;
-  for (u32 h = h0; m > 0u && h < n; h <<= 1) {
-    /* re-key the tied rows: (group, rank of the rotation h bytes further on) */
-    for (u32 k = tid; k < m; k += LBZ_WG) {
-      const u32 sfx = s.sufx[k];
-      u32 t = sfx + h;
-      if (t >= n) t -= n;
-      s.k0[k] = ((u64)s.grp[k] << RANK_BITS) | (u64)s.isa[t];
-      s.v0[k] = sfx;
-    }
-    __syncthreads();
-    const u32 which = wg_radix_sort(s.k0, s.v0, s.k1, s.v1, m, 2u * RANK_BITS, S);
-    work += m;
-    m = wg_regroup<false>(which ? s.k1 : s.k0, which ? s.v1 : s.v0, s.pos, m, s, S);
-    rounds++;
-  }
-  for (u32 j = tid; j < n; j += LBZ_WG) {
-    const u32 sfx = s.sa[j];
-    bwt[j] = T[sfx ? sfx - 1u : n - 1u];
-  }
-  if (tid == 0) {
-    meta->bwt_idx = s.isa[0];
-    meta->periodic = m > 0u ? 1u : 0u;
-  }
-  *rounds_out = rounds;
-  *work_out = work;
-  __syncthreads();
 }
 
 /* ======================================================================= keys */
@@ -931,7 +898,8 @@ __device__ void emit_tied_rows(u8 *bwt, bwt_slot s, bwt_lds *S, u32 lo, u32 hi)
 }
 
 /* last q in (pos, e] with a key change after `>> sh` between rows q-1 and q; 0 if none */
-__device__ u32 find_cut(const u64 *keys, u32 pos, u32 e, u32 sh, bwt_lds *S)
+template <class K>
+__device__ u32 find_cut(const K *keys, u32 pos, u32 e, u32 sh, bwt_lds *S)
 {
   const u32 tid = threadIdx.x;
   u32 found = 0;
@@ -947,9 +915,10 @@ __device__ u32 find_cut(const u64 *keys, u32 pos, u32 e, u32 sh, bwt_lds *S)
 }
 
 /* first q in [from, hi) whose key differs from row pos after `>> sh`; hi if none */
-__device__ u32 find_run_end(const u64 *keys, u32 pos, u32 from, u32 hi, u32 sh, bwt_lds *S)
+template <class K>
+__device__ u32 find_run_end(const K *keys, u32 pos, u32 from, u32 hi, u32 sh, bwt_lds *S)
 {
-  const u64 k = keys[pos] >> sh;
+  const K k = keys[pos] >> sh;
   for (u32 base = from; base < hi; base += LBZ_WG) {
     const u32 q = base + threadIdx.x;
     const u32 cand = (q < hi && (keys[q] >> sh) != k) ? q : 0xFFFFFFFFu;
@@ -988,6 +957,130 @@ __device__ void big_group(const u8 *T, u32 n, u8 *bwt, lbz_block_meta *meta, bwt
     batch_process(T, n, bwt, meta, s, S, c, pos, e - pos, true, false);
     pos = e;
   }
+}
+
+/* ======================================================================= deep ties
+ * Prefix doubling on a suffix array whose unresolved rows carry TIE_FLAG.  State: isa[] (rank
+ * of every rotation = first row of its run) and the list of still-tied rows in row order
+ * (sufx, grp = rank, pos = row).  One round at depth h re-sorts every run by the rank of the
+ * rotation h symbols further on and splits it where those ranks differ.  Runs are short and
+ * many, so rounds work like k_bwt_batch: consecutive whole runs of <= BATCH_CAP rows are pulled
+ * into LDS (the rank lookups are the only random HBM reads), each wave orders the runs of its
+ * window, and rows leave the list as soon as they are unique.  A run longer than a batch goes
+ * through the HBM radix sorter.                                                            */
+__device__ u32 doubling_round(const u8 *T, u32 n, u8 *bwt, bwt_slot s, bwt_lds *S, u32 h, u32 m)
+{
+  batch_lds *B = &S->u.B;
+  const u32 tid = threadIdx.x, lane = lane_id(), w = wave_id();
+  u32 out_m = 0, k0 = 0;
+  while (k0 < m) {
+    u32 e = k0 + BATCH_CAP < m ? k0 + BATCH_CAP : m;
+    if (e < m) {
+      const u32 cut = find_cut(s.grp, k0, e, 0u, S);
+      if (!cut) {
+        /* a run of more than BATCH_CAP rows: sort it by the looked-up rank in HBM, then split */
+        const u32 end = find_run_end(s.grp, k0, e, m, 0u, S);
+        const u32 g = end - k0, rowbase = s.pos[k0];
+        __syncthreads();
+        for (u32 i = tid; i < g; i += LBZ_WG) {
+          const u32 sf = s.sufx[k0 + i];
+          u32 t = sf + h;
+          if (t >= n) t -= n;
+          s.k0[i] = (u64)s.isa[t];
+          s.v0[i] = sf;
+        }
+        __syncthreads();
+        const u32 which = wg_radix_sort(s.k0, s.v0, s.k1, s.v1, g, RANK_BITS, S);
+        out_m = wg_regroup<false>(which ? s.k1 : s.k0, which ? s.v1 : s.v0, rowbase, out_m, g, s, S, T, n, bwt);
+        k0 = end;
+        continue;
+      }
+      e = cut;
+    }
+    const u32 cnt = e - k0;
+    for (u32 i = tid; i < cnt; i += LBZ_WG) {
+      const u32 sf = s.sufx[k0 + i];
+      u32 t = sf + h;
+      if (t >= n) t -= n;
+      B->kA[i] = (u64)s.isa[t];
+      B->vA[i] = sf;
+      B->kB[i] = (u64)s.grp[k0 + i];
+    }
+    __syncthreads();
+    u32 maxrun;
+    batch_runs(B, B->kB, cnt, 0u, &maxrun, S);            /* the runs as they stand */
+    u32 cs = 0, ce = 0, mytied = 0;
+    {
+      const u32 w0 = w * 256u, w1 = w0 + 256u;
+      if (w0 < cnt) {
+        cs = (B->gh[w0] == w0) ? w0 : B->gend[B->gh[w0]];
+        ce = (w1 >= cnt) ? cnt : ((B->gh[w1] == w1) ? w1 : B->gend[B->gh[w1]]);
+      }
+      if (cs < ce) {
+        wave_sort_chunk<false>(B, cs, ce);
+        /* rows of the sorted positions (a run occupies consecutive rows), kept in kB */
+        for (u32 j = cs + lane; j < ce; j += 64u) {
+          const u32 gs = B->gh[j];
+          B->kB[j] = (u64)(s.pos[k0 + gs] + (j - gs));
+        }
+        wave_sync();
+        mytied = wave_runs<true>(B, cs, ce);
+      }
+      if (lane == 0u) S->sc.a[w] = mytied;
+    }
+    __syncthreads();
+    u32 off = out_m, total = 0;
+#pragma unroll
+    for (u32 w2 = 0; w2 < LBZ_NW; w2++) { const u32 t = S->sc.a[w2]; if (w2 < w) off += t; total += t; }
+    for (u32 j0 = cs; j0 < ce; j0 += 64u) {
+      const u32 j = j0 + lane;
+      const bool ok = j < ce;
+      const bool td = ok && B->tied[j];
+      const u64 mask = __ballot(td);
+      if (ok) {
+        const u32 row = (u32)B->kB[j], sf = B->vA[j];
+        const u32 newrank = (u32)B->kB[B->gh[j]];
+        s.sa[row] = sf;
+        s.isa[sf] = newrank;
+        if (td) {
+          const u32 o = off + (u32)__popcll(mask & lanes_below());
+          s.sufx[o] = sf; s.grp[o] = newrank; s.pos[o] = row;
+        } else {
+          bwt[row] = T[sf ? sf - 1u : n - 1u];
+        }
+      }
+      off += (u32)__popcll(mask);
+    }
+    __syncthreads();
+    out_m += total;
+    k0 = e;
+  }
+  return out_m;
+}
+
+__device__ void finish_by_doubling(const u8 *T, u32 n, u8 *bwt, lbz_block_meta *meta, bwt_slot s,
+                                   bwt_lds *S, u32 h0, u32 *rounds_out, u32 *work_out)
+{
+  const u32 tid = threadIdx.x;
+  u32 m = wg_regroup<true>(nullptr, s.sa, 0u, 0u, n, s, S, T, n, nullptr);
+  u32 rounds = 0, work = 0;
+  for (u32 h = h0; m > 0u && h < n; h <<= 1) {
+    work += m;
+    m = doubling_round(T, n, bwt, s, S, h, m);
+    rounds++;
+  }
+  /* rows that are tied for good (exactly periodic block): their bytes are all equal anyway */
+  for (u32 k = tid; k < m; k += LBZ_WG) {
+    const u32 sf = s.sufx[k];
+    bwt[s.pos[k]] = T[sf ? sf - 1u : n - 1u];
+  }
+  if (tid == 0) {
+    meta->bwt_idx = s.isa[0];
+    meta->periodic = m > 0u ? 1u : 0u;
+  }
+  *rounds_out = rounds;
+  *work_out = work;
+  __syncthreads();
 }
 
 /* dense symbol codes of the used bytes and the key geometry they allow (every kernel) */
