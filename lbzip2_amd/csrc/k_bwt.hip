@@ -1062,7 +1062,9 @@ __device__ void finish_by_doubling(const u8 *T, u32 n, u8 *bwt, lbz_block_meta *
                                    bwt_lds *S, u32 h0, u32 *rounds_out, u32 *work_out)
 {
   const u32 tid = threadIdx.x;
+  const u64 tk0 = wall_clock64();
   u32 m = wg_regroup<true>(nullptr, s.sa, 0u, 0u, n, s, S, T, n, nullptr);
+  if (tid == 0) { meta->ticks[6] = (u32)(wall_clock64() - tk0); meta->ticks[1] = m; }
   u32 rounds = 0, work = 0;
   for (u32 h = h0; m > 0u && h < n; h <<= 1) {
     work += m;
@@ -1077,6 +1079,7 @@ __device__ void finish_by_doubling(const u8 *T, u32 n, u8 *bwt, lbz_block_meta *
   if (tid == 0) {
     meta->bwt_idx = s.isa[0];
     meta->periodic = m > 0u ? 1u : 0u;
+    meta->ticks[7] = (u32)(wall_clock64() - tk0);
   }
   *rounds_out = rounds;
   *work_out = work;

@@ -17,4 +17,7 @@ with lib.context(9, 64) as ctx:
     ctx.run_stages(data, 1)
     for b in range(0, 16, 2):
         bi = ctx.block_info(b)
-        print("blk", b, "n", bi.n, "rounds", bi.rounds, "sorted rows / n = %.2f" % (bi.sort_elems / bi.n - 1.0))
+        t = list(bi.ticks)
+        print("blk", b, "n", bi.n, "rounds", bi.rounds, "tied after batch %d (%.1f%%)" % (t[1], 100.0 * t[1] / bi.n),
+              "doubling rows / n = %.2f" % (bi.sort_elems / bi.n - 1.0),
+              "ms: batch %.2f regroup %.2f fix %.2f" % (t[0] / 1e5, t[6] / 1e5, t[7] / 1e5))
