@@ -47,14 +47,26 @@
 #define SORT_IPT 4u
 #define SORT_TILE (LBZ_WG * SORT_IPT)
 #define RANK_BITS 20u                   /* n <= 900000 < 2^20 */
-#define MSD_BITS 24u                    /* 8-bit partition passes in HBM: 24 = three, 16 = two (faster only on near-uniform bytes) */
+#ifndef MSD_BITS
+#define MSD_BITS 24u                    /* 8-bit partition passes in HBM: 16 = two, 24 = three, 32 = four */
+#endif
+#define MSD_PASSES (MSD_BITS / 8u)
 #define MSD_SHIFT (64u - MSD_BITS)
 #define PART_HALO 48u
 #define BATCH_CAP (LBZ_WG * 4u)
+#ifndef COUNT_GROUP
 #define COUNT_GROUP 128u                /* groups this short are ordered by counting */
+#endif
+#ifndef CHUNK_WIN
+#define CHUNK_WIN 128u                  /* rows per window a wave claims at a time inside a batch */
+#endif
+#ifndef WAVE_GROUP
 #define WAVE_GROUP 1024u                /* batches holding a longer group are sorted by the whole workgroup */
+#endif
 #define MAX_SYMS 32u                    /* symbols per key, capped (halo of the text tile) */
+#ifndef REFINE_ROUNDS
 #define REFINE_ROUNDS 12u                /* in-LDS refinements of a batch before rows are left to the doubling */
+#endif
 #define TIE_FLAG 0x80000000u
 static_assert(BATCH_CAP == LBZ_WG * 4u, "a batch is one 4-rows-per-thread tile");
 
@@ -77,6 +89,8 @@ struct batch_lds {                      /* one batch resident in LDS */
   u8 tied[BATCH_CAP], tiedn[BATCH_CAP];
   u32 wcnt[LBZ_NW][256];
   u32 dbase[256];
+  u16 cstart[BATCH_CAP / 64u + 2u];     /* first row of the chunk that belongs to each claim window */
+  u8 corder[BATCH_CAP / 64u + 2u];      /* chunks, longest first */
 };
 struct bwt_lds {
   wg_scratch sc;
@@ -495,8 +509,9 @@ __device__ void msd_text_pass(const u8 *T, u32 n, keycfg c, u64 *kout, u32 *vout
 #pragma unroll
       for (u32 k = 0; k < SORT_IPT; k++)
         if ((okmask >> k) & 1u) {
-          atomicAdd(&P->hist[1][(u32)(key[k] >> (MSD_SHIFT + 8u)) & 255u], 1u);
-          if (MSD_BITS > 16u) atomicAdd(&P->hist[2][(u32)(key[k] >> ((MSD_SHIFT + 16u) & 63u)) & 255u], 1u);
+#pragma unroll
+          for (u32 p = 1; p < MSD_PASSES; p++)
+            atomicAdd(&P->hist[p][(u32)(key[k] >> ((MSD_SHIFT + 8u * p) & 63u)) & 255u], 1u);
         }
       radix_tile_scatter_hbm(P, key, val, okmask, MSD_SHIFT, kout, vout);
     } else {
@@ -755,6 +770,7 @@ __device__ void wave_finish_chunk(batch_lds *B, u32 cs, u32 ce, bool need_sort, 
 {
   const u32 lane = lane_id();
   u32 ntied;
+  const u64 tw0 = wall_clock64();
   if (need_sort) {
     wave_sort_chunk<true>(B, cs, ce);
     ntied = wave_runs<false>(B, cs, ce);
@@ -772,6 +788,7 @@ __device__ void wave_finish_chunk(batch_lds *B, u32 cs, u32 ce, bool need_sort, 
      here than to pay the doubling's full rank build for.                                    */
   u32 depth = c.sy;
   u32 before = ntied;
+  const u64 tw1 = wall_clock64();
   for (u32 r = 0; r < REFINE_ROUNDS && ntied && before; r++) {
     /* block-wide budget of tied-row rounds: a block that has burnt n/8 of them is a repetitive
        one that will need the doubling anyway -- stop refining its remaining chunks */
@@ -800,6 +817,13 @@ __device__ void wave_finish_chunk(batch_lds *B, u32 cs, u32 ce, bool need_sort, 
     if (idx == 0u) meta->bwt_idx = lo + j;
   }
   if (ntied && lane == 0u) S->bc[8] = 1u;
+  if (lane == 0u) {
+    const u64 tw2 = wall_clock64();
+    atomicAdd(&S->bc[13], (u32)(tw2 - tw0));
+    atomicAdd(&S->bc[14], (u32)(tw1 - tw0));
+    atomicMax(&S->bc[5], (u32)(tw1 - tw0));
+    atomicMax(&S->bc[6], (u32)(tw2 - tw0));
+  }
 }
 
 /* Runs of rows whose keys agree after `>> sh`: fills gh (first row of the run), tied (run longer
@@ -847,6 +871,7 @@ __device__ void batch_process(const u8 *T, u32 n, u8 *bwt, lbz_block_meta *meta,
   batch_lds *B = &S->u.B;
   const u32 tid = threadIdx.x;
   const u64 tb0 = wall_clock64();
+  if (tid == 0) { S->bc[7] = 0; S->bc[5] = 0; S->bc[6] = 0; }   /* window claim counter; the barriers below publish it */
   if (!preloaded) {
     for (u32 i = tid; i < cnt; i += LBZ_WG) { B->kA[i] = s.k0[lo + i]; B->vA[i] = s.v0[lo + i]; }
     __syncthreads();
@@ -871,17 +896,35 @@ __device__ void batch_process(const u8 *T, u32 n, u8 *bwt, lbz_block_meta *meta,
     batch_runs(B, B->kA, cnt, 0u, &maxrun, S);
   }
   const u64 tb2 = wall_clock64();
-  {
-    const u32 w0 = wave_id() * 256u, w1 = w0 + 256u;
-    if (w0 < cnt) {
-      const u32 cs = (B->gh[w0] == w0) ? w0 : B->gend[B->gh[w0]];
-      const u32 ce = (w1 >= cnt) ? cnt : ((B->gh[w1] == w1) ? w1 : B->gend[B->gh[w1]]);
-      if (cs < ce) wave_finish_chunk(B, cs, ce, need_sort, T, n, c, bwt, s.sa, lo, meta, S);
+  /* chunk k = the groups that start inside window k of CHUNK_WIN rows; waves claim chunks in
+     turn.  The bounds are fixed before any wave starts rewriting the run tables.            */
+  const u32 nwin = (cnt + CHUNK_WIN - 1u) / CHUNK_WIN;
+  if (tid <= nwin) {
+    const u32 w0 = tid * CHUNK_WIN;
+    B->cstart[tid] = (u16)(w0 >= cnt ? cnt : ((B->gh[w0] == w0) ? w0 : B->gend[B->gh[w0]]));
+  }
+  __syncthreads();
+  if (tid < nwin) {                            /* longest chunk first: it bounds the batch */
+    const u32 mine = (u32)B->cstart[tid + 1u] - (u32)B->cstart[tid];
+    u32 r = 0;
+    for (u32 j = 0; j < nwin; j++) {
+      const u32 o = (u32)B->cstart[j + 1u] - (u32)B->cstart[j];
+      r += (o > mine || (o == mine && j < tid)) ? 1u : 0u;
     }
+    B->corder[r] = (u8)tid;
+  }
+  __syncthreads();
+  for (;;) {
+    const u32 t = wave_claim(&S->bc[7]);
+    if (t >= nwin) break;
+    const u32 k = B->corder[t];
+    const u32 cs = B->cstart[k], ce = B->cstart[k + 1u];
+    if (cs < ce) wave_finish_chunk(B, cs, ce, need_sort, T, n, c, bwt, s.sa, lo, meta, S);
   }
   __syncthreads();
   if (tid == 0) {
     S->bc[10] += (u32)(tb1 - tb0); S->bc[11] += (u32)(tb2 - tb1); S->bc[12] += (u32)(wall_clock64() - tb2);
+    S->bc[3] += S->bc[5]; S->bc[4] += S->bc[6];          /* longest single chunk: first sort, everything */
   }
 }
 
@@ -1101,14 +1144,14 @@ __device__ keycfg bwt_setup(const lbz_block_meta *meta, bwt_lds *S)
   c.sy = 64u / c.b;
   if (c.sy > MAX_SYMS) c.sy = MAX_SYMS;
   c.pad = 64u - c.b * c.sy;
-  if (tid == 0) for (u32 i = 8; i < 16; i++) S->bc[i] = 0;
+  if (tid == 0) for (u32 i = 1; i < 16; i++) S->bc[i] = 0;
   __syncthreads();
   return c;
 }
 
 
 /* ---- kernel 1: partition on the key's top 24 bits: k0 <- text, k1 <- k0, k0 <- k1 ---- */
-__global__ void __launch_bounds__(LBZ_WG)
+__global__ void __launch_bounds__(LBZ_WG, 4)
 k_bwt_part(const u8 *Tbase, lbz_block_meta *meta, lbz_layout L, u32 first_q, u32 nslabs, u8 *ws, u64 slot_bytes)
 {
   __shared__ bwt_lds S;
@@ -1121,26 +1164,26 @@ k_bwt_part(const u8 *Tbase, lbz_block_meta *meta, lbz_layout L, u32 first_q, u32
   const u64 tk0 = wall_clock64();
   const keycfg c = bwt_setup(&meta[blk], &S);
   sort_lds *P = &S.u.X;
-  for (u32 i = tid; i < 3u * 256u; i += LBZ_WG) (&P->hist[0][0])[i] = 0;
+  for (u32 i = tid; i < MSD_PASSES * 256u; i += LBZ_WG) (&P->hist[0][0])[i] = 0;
   __syncthreads();
   msd_text_pass<false>(T, n, c, nullptr, nullptr, &S);
   load_digit_offsets(P->hist[0], P->dbase, &S);
-  if (MSD_BITS > 16u) {
-    msd_text_pass<true>(T, n, c, s.k0, s.v0, &S);
-    load_digit_offsets(P->hist[1], P->dbase, &S);
-    msd_array_pass(s.k0, s.v0, n, MSD_SHIFT + 8u, s.k1, s.v1, &S);
-    load_digit_offsets(P->hist[2], P->dbase, &S);
-    msd_array_pass(s.k1, s.v1, n, (MSD_SHIFT + 16u) & 63u, s.k0, s.v0, &S);
-  } else {
-    msd_text_pass<true>(T, n, c, s.k1, s.v1, &S);
-    load_digit_offsets(P->hist[1], P->dbase, &S);
-    msd_array_pass(s.k1, s.v1, n, MSD_SHIFT + 8u, s.k0, s.v0, &S);
+  /* least significant of the MSD digits first; buffers alternate so that the last pass lands in (k0,v0) */
+  u64 *kb[2] = { s.k0, s.k1 };
+  u32 *vb[2] = { s.v0, s.v1 };
+  u32 cur = (MSD_PASSES - 1u) & 1u;
+  msd_text_pass<true>(T, n, c, kb[cur], vb[cur], &S);
+#pragma unroll
+  for (u32 p = 1; p < MSD_PASSES; p++) {
+    load_digit_offsets(P->hist[p], P->dbase, &S);
+    msd_array_pass(kb[cur], vb[cur], n, (MSD_SHIFT + 8u * p) & 63u, kb[cur ^ 1u], vb[cur ^ 1u], &S);
+    cur ^= 1u;
   }
   if (tid == 0) meta[blk].ticks[2] = (u32)(wall_clock64() - tk0);
 }
 
 /* ---- kernel 2: LDS batches of whole groups; emits BWT bytes + rows; flags deep ties ---- */
-__global__ void __launch_bounds__(LBZ_WG)
+__global__ void __launch_bounds__(LBZ_WG, 4)
 k_bwt_batch(const u8 *Tbase, u8 *Bbase, lbz_block_meta *meta, lbz_layout L, u32 first_q, u32 nslabs,
             u8 *ws, u64 slot_bytes)
 {
@@ -1193,11 +1236,12 @@ k_bwt_batch(const u8 *Tbase, u8 *Bbase, lbz_block_meta *meta, lbz_layout L, u32 
     M->sort_elems = n;
     M->ticks[0] = (u32)(wall_clock64() - tk0);
     for (u32 i = 0; i < 3; i++) M->ticks[3 + i] = S.bc[10 + i];   /* load, group scan (+block sorts), per-wave part */
+    M->ticks[6] = S.bc[13]; M->ticks[7] = S.bc[14]; M->ticks[1] = S.bc[3]; M->ticks[2] = S.bc[4];              /* summed over waves: busy, of which first sort */
   }
 }
 
 /* ---- kernel 3: blocks with ties deeper than the LDS refinements: prefix doubling ---- */
-__global__ void __launch_bounds__(LBZ_WG)
+__global__ void __launch_bounds__(LBZ_WG, 4)
 k_bwt_fix(const u8 *Tbase, u8 *Bbase, lbz_block_meta *meta, lbz_layout L, u32 first_q, u32 nslabs,
           u8 *ws, u64 slot_bytes)
 {

@@ -12,4 +12,14 @@ __device__ __forceinline__ int lane_write(int old, int val, int lane)
   return old;
 }
 
+/* One claim per wave from an LDS ticket counter (all 64 lanes active): returns 0, 1, 2, ... in
+ * claim order, wave-uniform.  Every lane adds one -- the compiler folds that into a single
+ * ds_add_rtn of 64 by one lane -- because a claim written as `if (lane == 0) atomicAdd` inside a
+ * loop gets lane 0 peeled onto its own path and the wave never reconverges for the broadcast. */
+__device__ __forceinline__ unsigned wave_claim(unsigned *tickets)
+{
+  const unsigned r = atomicAdd(tickets, 1u);
+  return (unsigned)__builtin_amdgcn_readfirstlane((int)r) >> 6;
+}
+
 #endif

@@ -28,7 +28,9 @@
 #define LBZ_WG 1024
 #endif
 #define LBZ_NW (LBZ_WG / 64)
+#ifndef LBZ_BWT_WG
 #define LBZ_BWT_WG 1024     /* the BWT kernel's own geometry (512 = 8 waves, two workgroups per CU, measured equal) */
+#endif
 
 /* Per-block record in HBM.  Blocks are numbered 2*slab (primary) and 2*slab+1 (spill). */
 typedef struct lbz_block_meta {

@@ -3,6 +3,8 @@ import sys, time
 sys.path.insert(0, "/root/repo"); sys.path.insert(0, "/root/repo/tests")
 import torch, lbzip2_amd
 import ctypes as C
+import os
+if os.environ.get('LBZ_LIB'): lbzip2_amd.LIB_PATH = os.environ['LBZ_LIB']
 lib = lbzip2_amd.library()
 g = C.CDLL("/root/repo/lbzip2_amd/host/libgen_inputs.so")
 def pysrc(n):
@@ -26,7 +28,7 @@ for kind in (sys.argv[2].split(",") if len(sys.argv) > 2 else ("text", "rand")):
     data = gen(kind, n, 2)
     src = torch.frombuffer(data, dtype=torch.uint8).cuda()
     dst = torch.empty(lib.bound(n), dtype=torch.uint8, device="cuda")
-    for slots in (256,):
+    for slots in ([int(x) for x in os.environ.get('LBZ_SLOTS', '256').split(',')]):
         ctx = lib.context(9, slabs, slots)
         for it in range(2):
             t = time.time()
@@ -43,4 +45,7 @@ for kind in (sys.argv[2].split(",") if len(sys.argv) > 2 else ("text", "rand")):
         nfix = sum(1 for b in range(0, 2 * slabs, 2) if ctx.block_info(b).rounds > 0)
         print("   batch kernel ms/blk: total=%.2f load=%.2f groupscan=%.2f waves=%.2f | blocks needing the doubling fix: %d of %d, ratio %.3f"
               % (tk[0] / cnt / 1e5, tk[3] / cnt / 1e5, tk[4] / cnt / 1e5, tk[5] / cnt / 1e5, nfix, slabs, n / max(1, m)), flush=True)
+        print("   waves phase: busy/16 = %.2f ms (utilisation %.0f%%), first sort = %.2f ms/16"
+              % (tk[6] / cnt / 1e5 / 16, 100.0 * tk[6] / 16 / max(1, tk[5]), tk[7] / cnt / 1e5 / 16), flush=True)
+        print("   sum over batches of the longest chunk: first sort %.2f ms, sort+refine+emit %.2f ms" % (tk[1] / cnt / 1e5, tk[2] / cnt / 1e5), flush=True)
         ctx.close()
