@@ -31,6 +31,7 @@ struct mtf_lds {
   int last[LBZ_NW][256];       /* per-slice last occurrence, then slice start state */
   u32 hist[LBZ_MAX_ALPHA + 2];
   u8 cmap[256];
+  u8 slot_of[256];
   u32 bc[4];
   __attribute__((aligned(16))) u8 stage_in[LBZ_NW][MTF_CHUNK];
   __attribute__((aligned(16))) u8 stage_out[LBZ_NW][MTF_CHUNK];
@@ -79,8 +80,16 @@ __device__ __forceinline__ void mtf_ranks(const u8 *bwt, u8 *rk, u32 lo, u32 hi,
       int myrank = 0;
       const int sb0 = __builtin_amdgcn_readfirstlane((int)b0);
       while (heads) {
-        /* all scalar except the compare: symbol and its last position are lane reads, rank and
+        /* all scalar except the compares: symbol and its last position are lane reads, rank and
            the new position are lane writes */
+        if (NQ > 1) {
+          /* frequent symbols (slots are numbered by falling head count, register 0 holds the 64
+             busiest): nothing to select, one register to write -- lbz_asm.h               */
+          unsigned long long h = heads;
+          mtf_fast_heads(h, myrank, Lq, c, sb0);
+          heads = h;
+          if (!heads) break;
+        }
         const int l = (int)__ffsll((long long)heads) - 1;
         heads &= ~(1ull << l);
         const int s = __builtin_amdgcn_readlane(c, l);
@@ -92,16 +101,20 @@ __device__ __forceinline__ void mtf_ranks(const u8 *bwt, u8 *rk, u32 lo, u32 hi,
           Lq[0] = lane_write(Lq[0], np, s);
         } else {
           const int owner = s & 63, q = s >> 6;
-          int mine = Lq[0];
+          int mine = Lq[1];
 #pragma unroll
-          for (int j = 1; j < NQ; j++) mine = (q == j) ? Lq[j] : mine;
+          for (int j = 2; j < NQ; j++) mine = (q == j) ? Lq[j] : mine;
           const int pv = __builtin_amdgcn_readlane(mine, owner);
           int cnt = 0;
 #pragma unroll
           for (int j = 0; j < NQ; j++) cnt += (int)__popcll(__ballot(Lq[j] > pv));
           myrank = lane_write(myrank, cnt, l);
+          if (NQ == 2) {
+            Lq[1] = lane_write(Lq[1], np, owner);
+          } else {
 #pragma unroll
-          for (int j = 0; j < NQ; j++) if (q == j) Lq[j] = lane_write(Lq[j], np, owner);
+            for (int j = 1; j < NQ; j++) if (q == j) Lq[j] = lane_write(Lq[j], np, owner);
+          }
         }
       }
       outb[64u * t + lane] = (u8)myrank;
@@ -127,6 +140,9 @@ k_mtf(const u8 *Bbase, u8 *Rbase, u16 *Vbase, u32 *freq_out, lbz_block_meta *met
   u8 *rk = Rbase + off;
   u16 *mtfv = Vbase + off;               /* room for n + 1 + 50 symbols (cap >= M + 64) */
 
+#ifdef MTF_TICKS
+  const u64 tk0 = wall_clock64();
+#endif
   /* dense symbol numbering of the used bytes (encode.c:340-355) */
   u32 tot_inuse;
   {
@@ -151,27 +167,58 @@ k_mtf(const u8 *Bbase, u8 *Rbase, u16 *Vbase, u32 *freq_out, lbz_block_meta *met
 #pragma unroll
     for (u32 k = 0; k < 4u; k++) {
       const u32 p = b0 + 64u * k + lane;
-      if (p < hi) atomicMax(&S.last[w][S.cmap[by[k]]], (int)p);
+      const u32 before = (u32)__shfl_up((int)by[k], 1u);
+      if (p < hi) {
+        const u32 code = S.cmap[by[k]];
+        atomicMax(&S.last[w][code], (int)p);
+        if (lane == 0u || before != by[k]) atomicAdd(&S.hist[code], 1u);    /* run heads (about) */
+      }
     }
   }
   __syncthreads();
+  /* Slots: the symbols numbered by falling head count, so that register 0 of mtf_ranks holds
+     the 64 busiest.  Ranks do not depend on the numbering; the initial order does (never-seen
+     symbols rank by code, virtual positions -1-code).                                       */
+  u32 slot = tid;
+  int st[LBZ_NW];
   if (tid < 256u) {
+    if (tid < tot_inuse) {
+      const u32 mine = S.hist[tid];
+      u32 r = 0;
+      for (u32 j = 0; j < tot_inuse; j++) { const u32 o = S.hist[j]; r += (o > mine || (o == mine && j < tid)) ? 1u : 0u; }
+      slot = r;
+    }
     int run = -1 - (int)tid;
 #pragma unroll
     for (u32 w2 = 0; w2 < LBZ_NW; w2++) {
       const int t = S.last[w2][tid];
-      S.last[w2][tid] = run;
+      st[w2] = run;
       if (t >= 0) run = t;
     }
   }
   __syncthreads();
+  if (tid < 256u) {
+#pragma unroll
+    for (u32 w2 = 0; w2 < LBZ_NW; w2++) S.last[w2][slot] = st[w2];
+    S.slot_of[tid] = (u8)slot;
+  }
+  for (u32 i = tid; i < LBZ_MAX_ALPHA + 2u; i += LBZ_WG) S.hist[i] = 0;
+  __syncthreads();
+  if (tid < 256u) S.cmap[tid] = S.slot_of[S.cmap[tid]];       /* byte -> slot */
+  __syncthreads();
 
+#ifdef MTF_TICKS
+  const u64 tk1 = wall_clock64();
+#endif
   /* ranks at run heads, wave-serial over heads; NQ = registers needed for the alphabet */
   if (tot_inuse <= 64u) mtf_ranks<1>(bwt, rk, lo, hi, &S);
   else if (tot_inuse <= 128u) mtf_ranks<2>(bwt, rk, lo, hi, &S);
   else mtf_ranks<4>(bwt, rk, lo, hi, &S);
   __syncthreads();
 
+#ifdef MTF_TICKS
+  const u64 tk2 = wall_clock64();
+#endif
   /* zero-run coding + histogram */
   u32 carry_nz = 0;        /* (position of the last non-zero rank) + 1 */
   u32 o_base = 0;
@@ -244,4 +291,7 @@ k_mtf(const u8 *Bbase, u8 *Rbase, u16 *Vbase, u32 *freq_out, lbz_block_meta *met
   }
   __syncthreads();
   for (u32 i = tid; i < LBZ_MAX_ALPHA + 2u; i += LBZ_WG) freq_out[(size_t)blk * 260u + i] = S.hist[i];
+#ifdef MTF_TICKS
+  if (tid == 0) { M->ticks[3] = (u32)(tk1 - tk0); M->ticks[4] = (u32)(tk2 - tk1); M->ticks[5] = (u32)(wall_clock64() - tk2); }
+#endif
 }

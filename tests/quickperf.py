@@ -48,4 +48,6 @@ for kind in (sys.argv[2].split(",") if len(sys.argv) > 2 else ("text", "rand")):
         print("   waves phase: busy/16 = %.2f ms (utilisation %.0f%%), first sort = %.2f ms/16"
               % (tk[6] / cnt / 1e5 / 16, 100.0 * tk[6] / 16 / max(1, tk[5]), tk[7] / cnt / 1e5 / 16), flush=True)
         print("   sum over batches of the longest chunk: first sort %.2f ms, sort+refine+emit %.2f ms" % (tk[1] / cnt / 1e5, tk[2] / cnt / 1e5), flush=True)
+        if os.environ.get("MTF_TICKS"):
+            print("   mtf kernel ms/blk: prelude %.2f ranks %.2f zrle %.2f" % (tk[3] / cnt / 1e5, tk[4] / cnt / 1e5, tk[5] / cnt / 1e5), flush=True)
         ctx.close()
