@@ -126,7 +126,8 @@ __device__ __forceinline__ void mtf_ranks(const u8 *bwt, u8 *rk, u32 lo, u32 hi,
   }
 }
 
-__global__ void __launch_bounds__(LBZ_WG)
+/* two workgroups per CU: the SGPR file admits 8 waves per SIMD only at <= 80 SGPRs per wave */
+__global__ void __launch_bounds__(LBZ_WG) __attribute__((amdgpu_num_sgpr(80)))
 k_mtf(const u8 *Bbase, u8 *Rbase, u16 *Vbase, u32 *freq_out, lbz_block_meta *meta, lbz_layout L, u32 nslabs)
 {
   __shared__ mtf_lds S;
