@@ -14,7 +14,11 @@ concatenated streams are a valid .bz2 file) -> weak scaling; value = all ranks' 
 over the max-over-ranks time.
 
 Prints ONE JSON line on rank 0.  Extra objects:
-  roofline      the kernel with the largest share of device time.  SURVEY 8(d) prices the path at
+  roofline      the kernel with the largest share of device time, timed live in the timed region
+                (HIP events on the stream each launch goes to; rounds of blocks run on two streams
+                and their launches overlap, so per-launch time includes sharing the device).
+                roofline.isolated repeats the per-kernel table from one extra untimed pass on a
+                single stream (nothing overlaps).  SURVEY 8(d) prices the path at
                 N_in + 13 N_rle + 20 N_mtf + N_out algorithmic bytes; per kernel that is
                 collect N_in+N_rle | bwt_part 5 N_rle | bwt_batch 6 N_rle | mtf N_rle+2 N_mtf |
                 encode 18 N_mtf+N_out.  achieved = bytes per launch / mean launch time from HIP
@@ -161,17 +165,37 @@ def main():
         import bz2
         assert bz2.decompress(bytes(dst[:out_len].cpu().numpy())) == bytes(data)
 
+    iso = None
+    if rank == 0:
+        # the same per-kernel figures with nothing overlapped: one untimed pass, one stream
+        os.environ["LBZAMD_STREAMS"] = "1"
+        try:
+            with lib.context(args.level, slabs, 0, local) as c1:
+                c1.compress_device(src.data_ptr(), n, dst.data_ptr(), dst.numel())
+                c1.compress_device(src.data_ptr(), n, dst.data_ptr(), dst.numel())
+                s1 = c1.stats()
+                iso = {"slots": c1.nslots, "ms": {"k_collect": s1.ms_collect, "k_bwt_part": s1.ms_bwt_part, "k_bwt_batch": s1.ms_bwt_batch,
+                                                  "k_mtf": s1.ms_mtf, "k_encode": s1.ms_encode}, "ms_total": s1.ms_total}
+        finally:
+            del os.environ["LBZAMD_STREAMS"]
     if rank == 0:
         nchunks = (nslabs + slabs - 1) // slabs
         nslots = ctx.nslots
         rounds = sum(-(-2 * min(slabs, nslabs - i * slabs) // nslots) for i in range(nchunks))   # BWT launches per step
         alg = {"k_collect": st.n_in + st.n_rle, "k_bwt_part": 5.0 * st.n_rle, "k_bwt_batch": 6.0 * st.n_rle,
                "k_mtf": st.n_rle + 2.0 * st.n_mtf, "k_encode": 18.0 * st.n_mtf + st.n_out}     # bytes per step
-        nlaunch = {"k_collect": nchunks, "k_bwt_part": rounds, "k_bwt_batch": rounds, "k_mtf": nchunks, "k_encode": nchunks}
+        nlaunch = {"k_collect": nchunks, "k_bwt_part": rounds, "k_bwt_batch": rounds, "k_mtf": rounds, "k_encode": rounds}
         per_kernel = {k: {"ms_per_step": round(kms[k] / args.steps, 3), "launches_per_step": nlaunch[k],
                           "alg_GB_per_step": round(alg[k] / 1e9, 3),
                           "achieved_GBps": round(alg[k] * args.steps / (kms[k] * 1e-3) / 1e9, 2) if kms[k] > 0 else 0.0}
                       for k in alg}
+        if iso:
+            iso_rounds = sum(-(-2 * min(slabs, nslabs - i * slabs) // iso["slots"]) for i in range(nchunks))
+            iso_nl = {"k_collect": nchunks, "k_bwt_part": iso_rounds, "k_bwt_batch": iso_rounds, "k_mtf": iso_rounds, "k_encode": iso_rounds}
+            iso_tab = {k: {"ms_per_step": round(iso["ms"][k], 3), "launches_per_step": iso_nl[k],
+                           "achieved_GBps": round(alg[k] / (iso["ms"][k] * 1e-3) / 1e9, 2) if iso["ms"][k] > 0 else 0.0,
+                           "frac": round(alg[k] / (iso["ms"][k] * 1e-3) / 1e9 / HBM_PEAK_GBS, 5) if iso["ms"][k] > 0 else 0.0}
+                       for k in alg}
         dom = max(alg, key=lambda k: kms[k])
         launches = nlaunch[dom] * args.steps
         achieved = per_kernel[dom]["achieved_GBps"]
@@ -182,7 +206,7 @@ def main():
             "ms_per_step": round(elapsed / args.steps * 1e3, 2), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic" if "synthetic" in source else "enwik9",
             "config": {"workload": f"{source}, level -{args.level}, {nslabs} slabs of {M} B per GPU, "
-                                   f"{slabs} resident per chunk, one bzip2 block per workgroup",
+                                   f"{slabs} resident per chunk, one bzip2 block per workgroup, rounds of {nslots} blocks on two streams",
                        "bytes_per_gpu": n, "level": args.level, "parallelism": f"{world} independent shard(s)"},
             "ratio": round(total_in / total_out, 4), "out_bytes": total_out,
             "bit_exact": "vs reference lbzip2 (tests/test_gpu_parity.py); periodic blocks: origin pointer only",
@@ -192,7 +216,9 @@ def main():
                          "avg_launch_ms": round(kms[dom] / launches, 3), "per_kernel": per_kernel,
                          "pipeline_alg_bytes_per_step": round(pipe_alg),
                          "pipeline_achieved_GBps": round(pipe_alg * args.steps / (tot_ms * 1e-3) / 1e9, 2),
-                         "pipeline_frac": round(pipe_alg * args.steps / (tot_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)},
+                         "pipeline_frac": round(pipe_alg * args.steps / (tot_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
+                         "isolated": ({"note": "one untimed single-stream pass, no overlap", "slots": iso["slots"],
+                                       "ms_total": round(iso["ms_total"], 2), "per_kernel": iso_tab} if iso else None)},
             "kernel_ms_per_step": {k: round(v / args.steps, 2) for k, v in kms.items()},
             "sorter": {"elements_per_block_byte": round(st.sort_elems / max(1, st.n_rle), 3), "blocks": st.nblocks,
                        "periodic_blocks": st.nperiodic},

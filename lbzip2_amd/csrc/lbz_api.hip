@@ -42,10 +42,14 @@ struct lbzamd_ctx {
   lbz_layout L{};
   uint32_t max_slabs = 0, nslots = 0;
   uint64_t slot_bytes = 0;
-  hipStream_t stream = nullptr;
+  hipStream_t stream = nullptr;               /* everything a caller can observe happens in order on this one */
+  hipStream_t side[7] = {};                   /* rounds of a chunk go round-robin over stream + side[0 .. nstreams-2] */
+  unsigned nstreams = 2;
   hipEvent_t ev[8] = {};
-  std::vector<hipEvent_t> bev;                /* events around the BWT launches of a chunk */
-  float bwt_ms[3] = { 0, 0, 0 };             /* partition, batch, fix: accumulated per call */
+  std::vector<hipEvent_t> bev;                /* a start/end pair around every per-round launch of a chunk */
+  std::vector<hipEvent_t> jev;                /* side streams -> caller's stream joins */
+  std::vector<int> bkind;                     /* which kernel each pair times (index into kms) */
+  float kms[5] = { 0, 0, 0, 0, 0 };          /* partition, batch, fix, mtf, encode: accumulated per call */
   /* device */
   u8 *T = nullptr, *B = nullptr, *R = nullptr, *O = nullptr, *ws = nullptr;
   u16 *V = nullptr;
@@ -70,7 +74,9 @@ static int ctx_free(lbzamd_ctx *c)
   (void)hipFree(c->d_in); (void)hipFree(c->d_out);
   for (auto &e : c->ev) if (e) (void)hipEventDestroy(e);
   for (auto &e : c->bev) if (e) (void)hipEventDestroy(e);
+  for (auto &e : c->jev) if (e) (void)hipEventDestroy(e);
   if (c->stream) (void)hipStreamDestroy(c->stream);
+  for (auto &q : c->side) if (q) (void)hipStreamDestroy(q);
   delete c;
   return 0;
 }
@@ -98,14 +104,35 @@ extern "C" int lbzamd_create(lbzamd_ctx **out, int device, unsigned bs100k, unsi
   c->L.cap_b = round_up(M / 4u + 128u, 256u);
   c->L.out_a = round_up(M + M / 8u + 4096u, 256u);
   c->L.out_b = round_up(c->L.cap_b + c->L.cap_b / 8u + 4096u, 256u);
+  c->slot_bytes = (LBZ_BWT_SLOT_BYTES(c->L.cap_a) + 255u) & ~(uint64_t)255u;
+  {
+    const char *env = getenv("LBZAMD_STREAMS");
+    c->nstreams = env ? (unsigned)atoi(env) : 2u;
+    if (c->nstreams < 1u) c->nstreams = 1u;
+    if (c->nstreams > 8u) c->nstreams = 8u;
+  }
   if (nslots == 0) {
+    /* Slots per round.  At least one workgroup per CU; with several streams the full-size blocks
+       of a chunk are dealt evenly over them (rounds of equal size overlap best), as far as half
+       of the free device memory allows (a slot is 44 B per block byte).                     */
     const char *env = getenv("LBZAMD_SLOTS");
-    nslots = env ? (unsigned)atoi(env) : (unsigned)prop.multiProcessorCount * (1024u / LBZ_BWT_WG);
+    const unsigned cus = (unsigned)prop.multiProcessorCount * (1024u / LBZ_BWT_WG);
+    if (env) {
+      nslots = (unsigned)atoi(env);
+    } else {
+      nslots = (max_slabs + c->nstreams - 1u) / c->nstreams;
+      if (nslots < cus) nslots = cus;
+      size_t free_b = 0, total_b = 0;
+      if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
+        const size_t fit = free_b / 2u / ((size_t)c->nstreams * c->slot_bytes);
+        if (nslots > fit) nslots = fit > cus ? (unsigned)fit : cus;
+      }
+    }
     if (nslots == 0) nslots = 1;
   }
   if (nslots > 2u * max_slabs) nslots = 2u * max_slabs;
   c->nslots = nslots;
-  c->slot_bytes = (LBZ_BWT_SLOT_BYTES(c->L.cap_a) + 255u) & ~(uint64_t)255u;
+  if (2u * max_slabs <= nslots) c->nstreams = 1u;            /* a single round: nothing to overlap */
 
   const size_t elems = (size_t)max_slabs * ((size_t)c->L.cap_a + c->L.cap_b);
   const size_t outb = (size_t)max_slabs * ((size_t)c->L.out_a + c->L.out_b);
@@ -117,7 +144,7 @@ extern "C" int lbzamd_create(lbzamd_ctx **out, int device, unsigned bs100k, unsi
   ALLOC(c->R, elems);
   ALLOC(c->V, elems * 2u);
   ALLOC(c->O, outb);
-  ALLOC(c->ws, (size_t)nslots * c->slot_bytes);
+  ALLOC(c->ws, (size_t)c->nstreams * nslots * c->slot_bytes);   /* one set of slots per stream */
   ALLOC(c->freq, nblk * 260u * sizeof(u32));
   ALLOC(c->queue, 256);
   ALLOC(c->offs, nblk * sizeof(u64));
@@ -126,6 +153,10 @@ extern "C" int lbzamd_create(lbzamd_ctx **out, int device, unsigned bs100k, unsi
 #undef ALLOC
   hipError_t e = hipStreamCreate(&c->stream);
   if (e != hipSuccess) { ctx_free(c); return fail_msg("hipStreamCreate", e); }
+  for (unsigned i = 0; i + 1 < c->nstreams; i++) {
+    e = hipStreamCreate(&c->side[i]);
+    if (e != hipSuccess) { ctx_free(c); return fail_msg("hipStreamCreate", e); }
+  }
   for (auto &ev : c->ev) {
     e = hipEventCreate(&ev);
     if (e != hipSuccess) { ctx_free(c); return fail_msg("hipEventCreate", e); }
@@ -143,7 +174,36 @@ extern "C" size_t lbzamd_bound(size_t len)
 extern "C" void *lbzamd_stream(lbzamd_ctx *c) { return (void *)c->stream; }
 extern "C" uint32_t lbzamd_slots(lbzamd_ctx *c) { return c ? c->nslots : 0u; }
 
-/* Enqueue stages [0, upto] for one chunk of nsl slabs already resident at d_in. */
+/* Enqueue stages [0, upto] for one chunk of nsl slabs already resident at d_in.
+ *
+ * After k_collect the chunk's queue (primaries first, then the small spill blocks) is cut into
+ * rounds of nslots entries.  A round is a chain of five launches -- partition, batches, deep
+ * ties, MTF, prefix codes + packing -- in which every workgroup owns one block (and, through
+ * the three BWT kernels, one workspace slot).  With two streams, rounds alternate between them,
+ * each stream with its own set of slots: a round's launches stay ordered, but workgroups of the
+ * other stream's round fill the CUs that a kernel boundary, or a round with fewer blocks than
+ * CUs, would leave idle.  The round that holds the end of the primaries (fewer full-size blocks
+ * than slots) is issued first so that the chunk does not END on a half-empty device.
+ * The caller's stream joins the side stream before anything else is enqueued on it.          */
+static int timed_begin(lbzamd_ctx *c, size_t *nbev, int kind, hipStream_t s)
+{
+  while (c->bev.size() < *nbev + 2) {
+    hipEvent_t e;
+    HIPCHK(hipEventCreate(&e));
+    c->bev.push_back(e);
+  }
+  if (c->bkind.size() < c->bev.size() / 2) c->bkind.resize(c->bev.size() / 2);
+  c->bkind[*nbev / 2] = kind;
+  HIPCHK(hipEventRecord(c->bev[*nbev], s));
+  return 0;
+}
+static int timed_end(lbzamd_ctx *c, size_t *nbev, hipStream_t s)
+{
+  HIPCHK(hipEventRecord(c->bev[*nbev + 1], s));
+  *nbev += 2;
+  return 0;
+}
+
 static int run_chunk(lbzamd_ctx *c, const u8 *d_in, size_t len, uint32_t nsl, int upto, float ms[5])
 {
   const uint32_t nblk = 2u * nsl;
@@ -153,55 +213,70 @@ static int run_chunk(lbzamd_ctx *c, const u8 *d_in, size_t len, uint32_t nsl, in
   HIPCHK(hipEventRecord(c->ev[1], s));
   size_t nbev = 0;
   if (upto >= 1) {
-    /* rounds of nslots queue entries (primaries first, then the small spill blocks); within a
-       round every workgroup owns one workspace slot through the three kernels */
-    for (uint32_t first = 0; first < nblk; first += c->nslots) {
+    const uint32_t nrounds = (nblk + c->nslots - 1u) / c->nslots;
+    const bool two = c->nstreams > 1 && nrounds > 1;
+    if (two) for (unsigned k = 0; k + 1 < c->nstreams; k++) HIPCHK(hipStreamWaitEvent(c->side[k], c->ev[1], 0));
+    const uint32_t odd = (nsl % c->nslots) ? nsl / c->nslots : nrounds;     /* round with the last primaries */
+    for (uint32_t i = 0; i < nrounds; i++) {
+      const uint32_t r = (odd < nrounds) ? (i == 0 ? odd : (i <= odd ? i - 1u : i)) : i;
+      const uint32_t first = r * c->nslots;
       const uint32_t grid = nblk - first < c->nslots ? nblk - first : c->nslots;
-      while (c->bev.size() < nbev + 4) {
-        hipEvent_t e;
-        HIPCHK(hipEventCreate(&e));
-        c->bev.push_back(e);
+      const unsigned lane = two ? i % c->nstreams : 0u;
+      hipStream_t q = lane ? c->side[lane - 1u] : s;
+      u8 *ws = c->ws + (size_t)lane * c->nslots * c->slot_bytes;
+      if (timed_begin(c, &nbev, 0, q)) return -1;
+      hipLaunchKernelGGL(k_bwt_part, dim3(grid), dim3(LBZ_BWT_WG), 0, q, (const u8 *)c->T, c->meta, c->L,
+                         first, nsl, ws, (u64)c->slot_bytes);
+      if (timed_end(c, &nbev, q) || timed_begin(c, &nbev, 1, q)) return -1;
+      hipLaunchKernelGGL(k_bwt_batch, dim3(grid), dim3(LBZ_BWT_WG), 0, q, (const u8 *)c->T, c->B, c->meta, c->L,
+                         first, nsl, ws, (u64)c->slot_bytes);
+      if (timed_end(c, &nbev, q) || timed_begin(c, &nbev, 2, q)) return -1;
+      hipLaunchKernelGGL(k_bwt_fix, dim3(grid), dim3(LBZ_BWT_WG), 0, q, (const u8 *)c->T, c->B, c->meta, c->L,
+                         first, nsl, ws, (u64)c->slot_bytes);
+      if (timed_end(c, &nbev, q)) return -1;
+      if (upto >= 2) {
+        if (timed_begin(c, &nbev, 3, q)) return -1;
+        hipLaunchKernelGGL(k_mtf, dim3(grid), dim3(LBZ_WG), 0, q, (const u8 *)c->B, c->R, c->V, c->freq, c->meta, c->L, first, nsl);
+        if (timed_end(c, &nbev, q)) return -1;
       }
-      HIPCHK(hipEventRecord(c->bev[nbev + 0], s));
-      hipLaunchKernelGGL(k_bwt_part, dim3(grid), dim3(LBZ_BWT_WG), 0, s, (const u8 *)c->T, c->meta, c->L,
-                         first, nsl, c->ws, (u64)c->slot_bytes);
-      HIPCHK(hipEventRecord(c->bev[nbev + 1], s));
-      hipLaunchKernelGGL(k_bwt_batch, dim3(grid), dim3(LBZ_BWT_WG), 0, s, (const u8 *)c->T, c->B, c->meta, c->L,
-                         first, nsl, c->ws, (u64)c->slot_bytes);
-      HIPCHK(hipEventRecord(c->bev[nbev + 2], s));
-      hipLaunchKernelGGL(k_bwt_fix, dim3(grid), dim3(LBZ_BWT_WG), 0, s, (const u8 *)c->T, c->B, c->meta, c->L,
-                         first, nsl, c->ws, (u64)c->slot_bytes);
-      HIPCHK(hipEventRecord(c->bev[nbev + 3], s));
-      nbev += 4;
+      if (upto >= 3) {
+        if (timed_begin(c, &nbev, 4, q)) return -1;
+        hipLaunchKernelGGL(k_encode, dim3(grid), dim3(LBZ_WG), 0, q, (const u16 *)c->V, (const u32 *)c->freq, c->O, c->meta, c->L, first, nsl);
+        if (timed_end(c, &nbev, q)) return -1;
+      }
     }
+    if (two)
+      for (unsigned k = 0; k + 1 < c->nstreams; k++) {
+        while (c->jev.size() <= k) {
+          hipEvent_t e;
+          HIPCHK(hipEventCreate(&e));
+          c->jev.push_back(e);
+        }
+        HIPCHK(hipEventRecord(c->jev[k], c->side[k]));
+        HIPCHK(hipStreamWaitEvent(s, c->jev[k], 0));
+      }
   }
   c->nbev_used = nbev;
   HIPCHK(hipEventRecord(c->ev[2], s));
-  if (upto >= 2)
-    hipLaunchKernelGGL(k_mtf, dim3(nblk), dim3(LBZ_WG), 0, s, (const u8 *)c->B, c->R, c->V, c->freq, c->meta, c->L, nsl);
-  HIPCHK(hipEventRecord(c->ev[3], s));
-  if (upto >= 3)
-    hipLaunchKernelGGL(k_encode, dim3(nblk), dim3(LBZ_WG), 0, s, (const u16 *)c->V, (const u32 *)c->freq, c->O, c->meta, c->L, nsl);
-  HIPCHK(hipEventRecord(c->ev[4], s));
   HIPCHK(hipGetLastError());
   (void)ms;
   c->last_nslabs = nsl;
   return 0;
 }
 
-static int add_times(lbzamd_ctx *c, int nev, float *acc)
+/* collect (ev0..ev1), rounds (ev1..ev2, wall), finish (ev2..ev3); per-kernel sums from the pairs */
+static int add_times(lbzamd_ctx *c, float *acc)
 {
-  for (int i = 0; i + 1 < nev; i++) {
+  for (int i = 0; i < 3; i++) {
     float t = 0;
     HIPCHK(hipEventElapsedTime(&t, c->ev[i], c->ev[i + 1]));
     acc[i] += t;
   }
-  for (size_t r = 0; r + 3 < c->nbev_used + 0 && r < c->nbev_used; r += 4)
-    for (int k = 0; k < 3; k++) {
-      float t = 0;
-      HIPCHK(hipEventElapsedTime(&t, c->bev[r + k], c->bev[r + k + 1]));
-      c->bwt_ms[k] += t;
-    }
+  for (size_t r = 0; r + 1 < c->nbev_used; r += 2) {
+    float t = 0;
+    HIPCHK(hipEventElapsedTime(&t, c->bev[r], c->bev[r + 1]));
+    c->kms[c->bkind[r / 2]] += t;
+  }
   return 0;
 }
 
@@ -216,7 +291,7 @@ extern "C" int lbzamd_compress_device(lbzamd_ctx *c, const void *d_in_v, size_t 
   const size_t nslabs = (len + M - 1u) / M;
   float acc[6] = { 0, 0, 0, 0, 0, 0 };
   hipStream_t s = c->stream;
-  c->bwt_ms[0] = c->bwt_ms[1] = c->bwt_ms[2] = 0;
+  for (float &k : c->kms) k = 0;
 
   size_t done = 0;
   bool first = true;
@@ -228,8 +303,8 @@ extern "C" int lbzamd_compress_device(lbzamd_ctx *c, const void *d_in_v, size_t 
     if (nsl) {
       if (run_chunk(c, d_in + off, clen, (uint32_t)nsl, 3, acc)) return -1;
     } else {
-      HIPCHK(hipEventRecord(c->ev[0], s));
-      for (int i = 1; i <= 4; i++) HIPCHK(hipEventRecord(c->ev[i], s));
+      c->nbev_used = 0;
+      for (int i = 0; i <= 2; i++) HIPCHK(hipEventRecord(c->ev[i], s));
     }
     hipLaunchKernelGGL(k_offsets, dim3(1), dim3(LBZ_WG), 0, s, (const lbz_block_meta *)c->meta, (u32)(2u * nsl),
                        (u32)c->bs100k, (u32)first, (u32)last, c->offs, c->st, d_out, (u64)out_cap);
@@ -237,10 +312,10 @@ extern "C" int lbzamd_compress_device(lbzamd_ctx *c, const void *d_in_v, size_t 
       hipLaunchKernelGGL(k_gather, dim3((u32)(2u * nsl)), dim3(LBZ_WG), 0, s, (const u8 *)c->O,
                          (const lbz_block_meta *)c->meta, c->L, (const u64 *)c->offs,
                          (const lbz_stream_state *)c->st, d_out, (u32)nsl);
-    HIPCHK(hipEventRecord(c->ev[5], s));
+    HIPCHK(hipEventRecord(c->ev[3], s));
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(s));
-    if (add_times(c, 6, acc)) return -1;
+    if (add_times(c, acc)) return -1;
     done += nsl;
     first = false;
   } while (done < nslabs);
@@ -249,10 +324,13 @@ extern "C" int lbzamd_compress_device(lbzamd_ctx *c, const void *d_in_v, size_t 
   HIPCHK(hipMemcpy(&st, c->st, sizeof st, hipMemcpyDeviceToHost));
   c->stats.n_in = len; c->stats.n_rle = st.n_rle; c->stats.n_mtf = st.n_mtf; c->stats.n_out = st.pos;
   c->stats.sort_elems = st.sort_elems; c->stats.nblocks = st.nblocks; c->stats.nperiodic = st.nperiodic;
-  c->stats.ms_collect = acc[0]; c->stats.ms_bwt = acc[1]; c->stats.ms_mtf = acc[2];
-  c->stats.ms_bwt_part = c->bwt_ms[0]; c->stats.ms_bwt_batch = c->bwt_ms[1]; c->stats.ms_bwt_fix = c->bwt_ms[2];
-  c->stats.ms_encode = acc[3]; c->stats.ms_finish = acc[4];
-  c->stats.ms_total = acc[0] + acc[1] + acc[2] + acc[3] + acc[4];
+  /* per-kernel figures are sums over launches (launches of the two streams overlap, so they add
+     up to more than the wall time); ms_total is wall time on the caller's stream */
+  c->stats.ms_collect = acc[0];
+  c->stats.ms_bwt_part = c->kms[0]; c->stats.ms_bwt_batch = c->kms[1]; c->stats.ms_bwt_fix = c->kms[2];
+  c->stats.ms_bwt = c->kms[0] + c->kms[1] + c->kms[2];
+  c->stats.ms_mtf = c->kms[3]; c->stats.ms_encode = c->kms[4]; c->stats.ms_finish = acc[2];
+  c->stats.ms_total = acc[0] + acc[1] + acc[2];
   if (st.err) {
     char buf[96];
     snprintf(buf, sizeof buf, "device pipeline error code %u%s", st.err, st.err == 100u ? " (output buffer too small)" : "");
@@ -438,8 +516,8 @@ extern "C" size_t lbzamd_encode(encoder_state *e, uint32_t *crc)
   hipLaunchKernelGGL(k_bwt_part, dim3(1), dim3(LBZ_BWT_WG), 0, s, (const u8 *)c->T, c->meta, c->L, 0u, 1u, c->ws, (u64)c->slot_bytes);
   hipLaunchKernelGGL(k_bwt_batch, dim3(1), dim3(LBZ_BWT_WG), 0, s, (const u8 *)c->T, c->B, c->meta, c->L, 0u, 1u, c->ws, (u64)c->slot_bytes);
   hipLaunchKernelGGL(k_bwt_fix, dim3(1), dim3(LBZ_BWT_WG), 0, s, (const u8 *)c->T, c->B, c->meta, c->L, 0u, 1u, c->ws, (u64)c->slot_bytes);
-  hipLaunchKernelGGL(k_mtf, dim3(1), dim3(LBZ_WG), 0, s, (const u8 *)c->B, c->R, c->V, c->freq, c->meta, c->L, 1u);
-  hipLaunchKernelGGL(k_encode, dim3(1), dim3(LBZ_WG), 0, s, (const u16 *)c->V, (const u32 *)c->freq, c->O, c->meta, c->L, 1u);
+  hipLaunchKernelGGL(k_mtf, dim3(1), dim3(LBZ_WG), 0, s, (const u8 *)c->B, c->R, c->V, c->freq, c->meta, c->L, 0u, 1u);
+  hipLaunchKernelGGL(k_encode, dim3(1), dim3(LBZ_WG), 0, s, (const u16 *)c->V, (const u32 *)c->freq, c->O, c->meta, c->L, 0u, 1u);
   if (hipStreamSynchronize(s) != hipSuccess || hipGetLastError() != hipSuccess) { g_err = "kernel failure"; die("encode"); }
   lbzamd_block_info bi;
   if (lbzamd_block_info_get(c, 0, &bi) || bi.err) { g_err = "device pipeline error"; die("encode"); }
