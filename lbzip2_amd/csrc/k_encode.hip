@@ -294,8 +294,15 @@ k_encode(const u16 *Vbase, const u32 *freq_in, u8 *Obase, lbz_block_meta *meta, 
   if (tid == 0) seed_tables(&S, as, nm, nt);
   __syncthreads();
 
+#ifdef ENC_TICKS
+  const u64 tk0 = wall_clock64();
+  u64 tke = 0, tkm = 0;
+#endif
   /* ---- EM (encode.c:1043-1084) ---- */
   for (u32 it = 0; it < LBZ_CLUSTER; it++) {
+#ifdef ENC_TICKS
+    const u64 ta = wall_clock64();
+#endif
     if (tid <= as) {
       u64 x = 0;
       if (tid < as)
@@ -328,6 +335,10 @@ k_encode(const u16 *Vbase, const u32 *freq_in, u8 *Obase, lbz_block_meta *meta, 
     }
     __syncthreads();
 
+#ifdef ENC_TICKS
+    const u64 tb = wall_clock64();
+    tke += tb - ta;
+#endif
     /* M-step: sort each table's weights (all threads), then one lane per table merges */
     for (u32 e = tid; e < nt * as; e += LBZ_WG) {
       const u32 t = e / as, i = e - t * as;
@@ -352,7 +363,13 @@ k_encode(const u16 *Vbase, const u32 *freq_in, u8 *Obase, lbz_block_meta *meta, 
     __syncthreads();
     if ((tid & 63u) == 0u && (tid >> 6) < nt) huffman_lengths_lane(&S, tid >> 6, as);
     __syncthreads();
+#ifdef ENC_TICKS
+    tkm += wall_clock64() - tb;
+#endif
   }
+#ifdef ENC_TICKS
+  const u64 tk1 = wall_clock64();
+#endif
 
   /* ---- renumber tables by first use (encode.c:1088-1111) ---- */
   if (tid < LBZ_MAX_TREES) S.firstpos[tid] = 0xFFFFFFFFu;
@@ -391,20 +408,62 @@ k_encode(const u16 *Vbase, const u32 *freq_in, u8 *Obase, lbz_block_meta *meta, 
     __syncthreads();
   }
 
+#ifdef ENC_TICKS
+  const u64 tk2 = wall_clock64();
+#endif
   /* ---- selector MTF, exact size, padding (encode.c:473-545) ---- */
   u8 *selmtf = reinterpret_cast<u8 *>(&S.items[0][0]);
-  if (tid == 0) {
-    u32 bits = 48u + 32u + 1u + 24u + 3u + 15u + cost;
-    u32 list = 0x543210u;                                /* six 4-bit entries, front = low nibble */
-    for (u32 g = 0; g < ns; g++) {
-      const u32 c = S.old2new[S.sel[g]];
-      u32 j = 0;
-      while (((list >> (4u * j)) & 15u) != c) j++;
-      const u32 lowmask = (1u << (4u * j)) - 1u;
-      list = (list & ~((lowmask << 4) | 15u)) | ((list & lowmask) << 4) | c;
-      selmtf[g] = (u8)j;
-      bits += j + 1u;
+  /* Selector MTF (encode.c:473-492).  As in k_mtf: the rank of a group's table is the number of
+     tables used more recently, so all that is serial is "where was table t last used before
+     group g" -- one exclusive max-scan per table.  Positions are kept as g + 7; a table not used
+     yet sits at 6 - t, i.e. in the initial order 0,1,..,5.                                   */
+  u32 selbits;
+  {
+    constexpr u32 SEL_IPT = 8u;
+    u32 carry[LBZ_MAX_TREES], mybits = 0;
+#pragma unroll
+    for (u32 t = 0; t < LBZ_MAX_TREES; t++) carry[t] = 6u - t;
+    for (u32 t0 = 0; t0 < ns; t0 += LBZ_WG * SEL_IPT) {
+      const u32 g0 = t0 + tid * SEL_IPT;
+      u32 cc[SEL_IPT], mylast[LBZ_MAX_TREES];
+#pragma unroll
+      for (u32 t = 0; t < LBZ_MAX_TREES; t++) mylast[t] = 0;
+#pragma unroll
+      for (u32 k = 0; k < SEL_IPT; k++) {
+        const u32 g = g0 + k;
+        cc[k] = g < ns ? S.old2new[S.sel[g]] : 0xFFu;
+#pragma unroll
+        for (u32 t = 0; t < LBZ_MAX_TREES; t++) if (cc[k] == t) mylast[t] = g + 7u;
+      }
+      u32 last[LBZ_MAX_TREES];
+#pragma unroll
+      for (u32 t = 0; t < LBZ_MAX_TREES; t++) {
+        u32 e, d0, tm, d1;
+        wg_excl_max_add(mylast[t], 0u, &e, &d0, &tm, &d1, &S.sc);
+        last[t] = e > carry[t] ? e : carry[t];
+        carry[t] = tm > carry[t] ? tm : carry[t];
+      }
+#pragma unroll
+      for (u32 k = 0; k < SEL_IPT; k++) {
+        const u32 g = g0 + k;
+        if (g < ns) {
+          u32 lc = 0;
+#pragma unroll
+          for (u32 t = 0; t < LBZ_MAX_TREES; t++) lc = (cc[k] == t) ? last[t] : lc;
+          u32 j = 0;
+#pragma unroll
+          for (u32 t = 0; t < LBZ_MAX_TREES; t++) j += last[t] > lc ? 1u : 0u;
+          selmtf[g] = (u8)j;
+          mybits += j + 1u;
+#pragma unroll
+          for (u32 t = 0; t < LBZ_MAX_TREES; t++) if (cc[k] == t) last[t] = g + 7u;
+        }
+      }
     }
+    selbits = wg_sum(mybits, &S.sc);
+  }
+  if (tid == 0) {
+    u32 bits = 48u + 32u + 1u + 24u + 3u + 15u + cost + selbits;
     const u32 padbits = (8u - (bits & 7u)) & 7u;
     bits += padbits;
     u32 nstx = ns;
@@ -428,6 +487,9 @@ k_encode(const u16 *Vbase, const u32 *freq_in, u8 *Obase, lbz_block_meta *meta, 
     return;
   }
 
+#ifdef ENC_TICKS
+  const u64 tk3 = wall_clock64();
+#endif
   /* ---- packing (encode.c:1185-1278) ---- */
   u32 wbase = 0;
   u64 bitpos = 0;
@@ -553,5 +615,9 @@ k_encode(const u16 *Vbase, const u32 *freq_in, u8 *Obase, lbz_block_meta *meta, 
     M->num_trees = used;
     M->num_sel = nstx;
     if ((u32)(bitpos >> 3) != out_len || (bitpos & 7ull)) M->err = 3u;   /* cf. encode.c:1275-1277 */
+#ifdef ENC_TICKS
+    M->ticks[1] = (u32)tke; M->ticks[2] = (u32)tkm; M->ticks[3] = (u32)(tk2 - tk1); M->ticks[4] = (u32)(tk3 - tk2);
+    M->ticks[5] = (u32)(wall_clock64() - tk3); M->ticks[6] = (u32)(tk0 & 0xffffffffu);
+#endif
   }
 }
