@@ -89,6 +89,7 @@ def main():
     ap.add_argument("--slabs", type=int, default=0, help="resident slabs per chunk (0 = all)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--verify", action="store_true", help="decode the stream with Python's bz2 (untimed)")
+    ap.add_argument("--no-isolated", action="store_true", help="skip the extra single-stream pass (profiling runs)")
     args = ap.parse_args()
 
     import torch
@@ -166,7 +167,7 @@ def main():
         assert bz2.decompress(bytes(dst[:out_len].cpu().numpy())) == bytes(data)
 
     iso = None
-    if rank == 0:
+    if rank == 0 and not args.no_isolated:
         # the same per-kernel figures with nothing overlapped: one untimed pass, one stream
         os.environ["LBZAMD_STREAMS"] = "1"
         try:
@@ -181,7 +182,7 @@ def main():
     if rank == 0:
         nchunks = (nslabs + slabs - 1) // slabs
         nslots = ctx.nslots
-        rounds = sum(-(-2 * min(slabs, nslabs - i * slabs) // nslots) for i in range(nchunks))   # BWT launches per step
+        rounds = sum(-(-min(slabs, nslabs - i * slabs) // nslots) for i in range(nchunks))   # rounds (launches of every per-round kernel) per step
         alg = {"k_collect": st.n_in + st.n_rle, "k_bwt_part": 5.0 * st.n_rle, "k_bwt_batch": 6.0 * st.n_rle,
                "k_mtf": st.n_rle + 2.0 * st.n_mtf, "k_encode": 18.0 * st.n_mtf + st.n_out}     # bytes per step
         nlaunch = {"k_collect": nchunks, "k_bwt_part": rounds, "k_bwt_batch": rounds, "k_mtf": rounds, "k_encode": rounds}
@@ -190,7 +191,7 @@ def main():
                           "achieved_GBps": round(alg[k] * args.steps / (kms[k] * 1e-3) / 1e9, 2) if kms[k] > 0 else 0.0}
                       for k in alg}
         if iso:
-            iso_rounds = sum(-(-2 * min(slabs, nslabs - i * slabs) // iso["slots"]) for i in range(nchunks))
+            iso_rounds = sum(-(-min(slabs, nslabs - i * slabs) // iso["slots"]) for i in range(nchunks))
             iso_nl = {"k_collect": nchunks, "k_bwt_part": iso_rounds, "k_bwt_batch": iso_rounds, "k_mtf": iso_rounds, "k_encode": iso_rounds}
             iso_tab = {k: {"ms_per_step": round(iso["ms"][k], 3), "launches_per_step": iso_nl[k],
                            "achieved_GBps": round(alg[k] / (iso["ms"][k] * 1e-3) / 1e9, 2) if iso["ms"][k] > 0 else 0.0,
@@ -198,6 +199,18 @@ def main():
                        for k in alg}
         dom = max(alg, key=lambda k: kms[k])
         launches = nlaunch[dom] * args.steps
+        # HBM traffic of the dominant kernel from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE /
+        # WRITE_SIZE, separate runs; profiles/pmc_traffic.json holds KB per block of the same workload).
+        # FETCH_SIZE is doubled (gfx950 tallies wide reads at half, MI355X_MICROARCH.md, HBM).
+        traffic = None
+        try:
+            pt = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+            if pt.get("workload") == f"{args.kind} -{args.level}" and dom in pt["kernels"]:
+                e = pt["kernels"][dom]
+                blocks_per_launch = st.nblocks * args.steps / launches
+                traffic = round((2.0 * e["fetch_kb_per_block"] + e["write_kb_per_block"]) * 1024.0 * blocks_per_launch)
+        except (OSError, ValueError, KeyError):
+            traffic = None
         achieved = per_kernel[dom]["achieved_GBps"]
         pipe_alg = st.n_in + 13.0 * st.n_rle + 20.0 * st.n_mtf + st.n_out  # SURVEY 8(d), per step
         res = {
@@ -206,12 +219,12 @@ def main():
             "ms_per_step": round(elapsed / args.steps * 1e3, 2), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic" if "synthetic" in source else "enwik9",
             "config": {"workload": f"{source}, level -{args.level}, {nslabs} slabs of {M} B per GPU, "
-                                   f"{slabs} resident per chunk, one bzip2 block per workgroup, rounds of {nslots} blocks on two streams",
+                                   f"{slabs} resident per chunk, one bzip2 block per workgroup, rounds of {nslots} slabs on two streams",
                        "bytes_per_gpu": n, "level": args.level, "parallelism": f"{world} independent shard(s)"},
             "ratio": round(total_in / total_out, 4), "out_bytes": total_out,
             "bit_exact": "vs reference lbzip2 (tests/test_gpu_parity.py); periodic blocks: origin pointer only",
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
                          "alg_bytes_per_launch": round(alg[dom] * args.steps / launches), "launches": launches,
                          "avg_launch_ms": round(kms[dom] / launches, 3), "per_kernel": per_kernel,
                          "pipeline_alg_bytes_per_step": round(pipe_alg),

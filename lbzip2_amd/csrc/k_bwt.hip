@@ -131,6 +131,14 @@ __device__ __forceinline__ bwt_slot slot_carve(u8 *ws, u32 cap)
   return s;
 }
 
+/* workspace of this workgroup in a round of `count` slabs (lbz_kernels.h) */
+__device__ __forceinline__ bwt_slot round_slot(u8 *ws, u64 slot_bytes, u8 *ws_spill, u64 spill_bytes, u32 count, lbz_layout L)
+{
+  const u32 i = blockIdx.x;
+  return i < count ? slot_carve(ws + (u64)i * slot_bytes, L.cap_a)
+                   : slot_carve(ws_spill + (u64)(i - count) * spill_bytes, L.cap_b);
+}
+
 /* Lanes of the wave holding the same 8-bit digit ("match any"): 8 ballots; each ballot is
  * folded in with an xnor against the lane's own sign-extended bit.                        */
 __device__ __forceinline__ u64 match_digit(u32 d, bool ok)
@@ -1152,14 +1160,15 @@ __device__ keycfg bwt_setup(const lbz_block_meta *meta, bwt_lds *S)
 
 /* ---- kernel 1: partition on the key's top 24 bits: k0 <- text, k1 <- k0, k0 <- k1 ---- */
 __global__ void __launch_bounds__(LBZ_WG, 4)
-k_bwt_part(const u8 *Tbase, lbz_block_meta *meta, lbz_layout L, u32 first_q, u32 nslabs, u8 *ws, u64 slot_bytes)
+k_bwt_part(const u8 *Tbase, lbz_block_meta *meta, lbz_layout L, u32 first, u32 count,
+           u8 *ws, u64 slot_bytes, u8 *ws_spill, u64 spill_bytes)
 {
   __shared__ bwt_lds S;
   const u32 tid = threadIdx.x;
-  const u32 blk = lbz_queue_block(first_q + blockIdx.x, nslabs);
+  const u32 blk = lbz_round_block(first, count, blockIdx.x);
   const u32 n = meta[blk].n;
   if (n <= BATCH_CAP) return;                 /* small blocks are sorted whole by k_bwt_batch */
-  const bwt_slot s = slot_carve(ws + (u64)blockIdx.x * slot_bytes, L.cap_a);
+  const bwt_slot s = round_slot(ws, slot_bytes, ws_spill, spill_bytes, count, L);
   const u8 *T = Tbase + lbz_elem_off(L, blk);
   const u64 tk0 = wall_clock64();
   const keycfg c = bwt_setup(&meta[blk], &S);
@@ -1184,16 +1193,16 @@ k_bwt_part(const u8 *Tbase, lbz_block_meta *meta, lbz_layout L, u32 first_q, u32
 
 /* ---- kernel 2: LDS batches of whole groups; emits BWT bytes + rows; flags deep ties ---- */
 __global__ void __launch_bounds__(LBZ_WG, 4)
-k_bwt_batch(const u8 *Tbase, u8 *Bbase, lbz_block_meta *meta, lbz_layout L, u32 first_q, u32 nslabs,
-            u8 *ws, u64 slot_bytes)
+k_bwt_batch(const u8 *Tbase, u8 *Bbase, lbz_block_meta *meta, lbz_layout L, u32 first, u32 count,
+            u8 *ws, u64 slot_bytes, u8 *ws_spill, u64 spill_bytes)
 {
   __shared__ bwt_lds S;
   const u32 tid = threadIdx.x;
-  const u32 blk = lbz_queue_block(first_q + blockIdx.x, nslabs);
+  const u32 blk = lbz_round_block(first, count, blockIdx.x);
   lbz_block_meta *M = &meta[blk];
   const u32 n = M->n;
   if (n == 0u) return;
-  const bwt_slot s = slot_carve(ws + (u64)blockIdx.x * slot_bytes, L.cap_a);
+  const bwt_slot s = round_slot(ws, slot_bytes, ws_spill, spill_bytes, count, L);
   const size_t off = lbz_elem_off(L, blk);
   const u8 *T = Tbase + off;
   u8 *bwt = Bbase + off;
@@ -1242,15 +1251,15 @@ k_bwt_batch(const u8 *Tbase, u8 *Bbase, lbz_block_meta *meta, lbz_layout L, u32 
 
 /* ---- kernel 3: blocks with ties deeper than the LDS refinements: prefix doubling ---- */
 __global__ void __launch_bounds__(LBZ_WG, 4)
-k_bwt_fix(const u8 *Tbase, u8 *Bbase, lbz_block_meta *meta, lbz_layout L, u32 first_q, u32 nslabs,
-          u8 *ws, u64 slot_bytes)
+k_bwt_fix(const u8 *Tbase, u8 *Bbase, lbz_block_meta *meta, lbz_layout L, u32 first, u32 count,
+          u8 *ws, u64 slot_bytes, u8 *ws_spill, u64 spill_bytes)
 {
   __shared__ bwt_lds S;
-  const u32 blk = lbz_queue_block(first_q + blockIdx.x, nslabs);
+  const u32 blk = lbz_round_block(first, count, blockIdx.x);
   lbz_block_meta *M = &meta[blk];
   const u32 n = M->n;
   if (n < 2u || M->periodic != 2u) return;
-  const bwt_slot s = slot_carve(ws + (u64)blockIdx.x * slot_bytes, L.cap_a);
+  const bwt_slot s = round_slot(ws, slot_bytes, ws_spill, spill_bytes, count, L);
   const size_t off = lbz_elem_off(L, blk);
   const keycfg c = bwt_setup(M, &S);
   u32 rounds = 0, work = 0;

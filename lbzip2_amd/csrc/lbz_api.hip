@@ -41,7 +41,7 @@ struct lbzamd_ctx {
   unsigned bs100k = 9;
   lbz_layout L{};
   uint32_t max_slabs = 0, nslots = 0;
-  uint64_t slot_bytes = 0;
+  uint64_t slot_bytes = 0, spill_bytes = 0;      /* BWT workspace of a full-size / a spill block */
   hipStream_t stream = nullptr;               /* everything a caller can observe happens in order on this one */
   hipStream_t side[7] = {};                   /* rounds of a chunk go round-robin over stream + side[0 .. nstreams-2] */
   unsigned nstreams = 2;
@@ -105,6 +105,7 @@ extern "C" int lbzamd_create(lbzamd_ctx **out, int device, unsigned bs100k, unsi
   c->L.out_a = round_up(M + M / 8u + 4096u, 256u);
   c->L.out_b = round_up(c->L.cap_b + c->L.cap_b / 8u + 4096u, 256u);
   c->slot_bytes = (LBZ_BWT_SLOT_BYTES(c->L.cap_a) + 255u) & ~(uint64_t)255u;
+  c->spill_bytes = (LBZ_BWT_SLOT_BYTES(c->L.cap_b) + 255u) & ~(uint64_t)255u;
   {
     const char *env = getenv("LBZAMD_STREAMS");
     c->nstreams = env ? (unsigned)atoi(env) : 2u;
@@ -112,9 +113,9 @@ extern "C" int lbzamd_create(lbzamd_ctx **out, int device, unsigned bs100k, unsi
     if (c->nstreams > 8u) c->nstreams = 8u;
   }
   if (nslots == 0) {
-    /* Slots per round.  At least one workgroup per CU; with several streams the full-size blocks
-       of a chunk are dealt evenly over them (rounds of equal size overlap best), as far as half
-       of the free device memory allows (a slot is 44 B per block byte).                     */
+    /* Slabs per round.  At least one full-size block per CU; with several streams the slabs of a
+       chunk are dealt evenly over them (rounds of equal size overlap best), as far as half of
+       the free device memory allows (a slot is 44 B per block byte, + 1/4 for the spill).   */
     const char *env = getenv("LBZAMD_SLOTS");
     const unsigned cus = (unsigned)prop.multiProcessorCount * (1024u / LBZ_BWT_WG);
     if (env) {
@@ -124,15 +125,15 @@ extern "C" int lbzamd_create(lbzamd_ctx **out, int device, unsigned bs100k, unsi
       if (nslots < cus) nslots = cus;
       size_t free_b = 0, total_b = 0;
       if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
-        const size_t fit = free_b / 2u / ((size_t)c->nstreams * c->slot_bytes);
+        const size_t fit = free_b / 2u / ((size_t)c->nstreams * (c->slot_bytes + c->spill_bytes));
         if (nslots > fit) nslots = fit > cus ? (unsigned)fit : cus;
       }
     }
     if (nslots == 0) nslots = 1;
   }
-  if (nslots > 2u * max_slabs) nslots = 2u * max_slabs;
+  if (nslots > max_slabs) nslots = max_slabs;
   c->nslots = nslots;
-  if (2u * max_slabs <= nslots) c->nstreams = 1u;            /* a single round: nothing to overlap */
+  if (max_slabs <= nslots) c->nstreams = 1u;                 /* a single round: nothing to overlap */
 
   const size_t elems = (size_t)max_slabs * ((size_t)c->L.cap_a + c->L.cap_b);
   const size_t outb = (size_t)max_slabs * ((size_t)c->L.out_a + c->L.out_b);
@@ -144,7 +145,7 @@ extern "C" int lbzamd_create(lbzamd_ctx **out, int device, unsigned bs100k, unsi
   ALLOC(c->R, elems);
   ALLOC(c->V, elems * 2u);
   ALLOC(c->O, outb);
-  ALLOC(c->ws, (size_t)c->nstreams * nslots * c->slot_bytes);   /* one set of slots per stream */
+  ALLOC(c->ws, (size_t)c->nstreams * nslots * (c->slot_bytes + c->spill_bytes));   /* one set of slots per stream */
   ALLOC(c->freq, nblk * 260u * sizeof(u32));
   ALLOC(c->queue, 256);
   ALLOC(c->offs, nblk * sizeof(u64));
@@ -176,14 +177,14 @@ extern "C" uint32_t lbzamd_slots(lbzamd_ctx *c) { return c ? c->nslots : 0u; }
 
 /* Enqueue stages [0, upto] for one chunk of nsl slabs already resident at d_in.
  *
- * After k_collect the chunk's queue (primaries first, then the small spill blocks) is cut into
- * rounds of nslots entries.  A round is a chain of five launches -- partition, batches, deep
- * ties, MTF, prefix codes + packing -- in which every workgroup owns one block (and, through
- * the three BWT kernels, one workspace slot).  With two streams, rounds alternate between them,
- * each stream with its own set of slots: a round's launches stay ordered, but workgroups of the
- * other stream's round fill the CUs that a kernel boundary, or a round with fewer blocks than
- * CUs, would leave idle.  The round that holds the end of the primaries (fewer full-size blocks
- * than slots) is issued first so that the chunk does not END on a half-empty device.
+ * After k_collect the chunk's slabs are cut into rounds of nslots.  A round is a chain of five
+ * launches -- partition, batches, deep ties, MTF, prefix codes + packing -- with one workgroup
+ * per block: the primary blocks of the round's slabs first, then their (usually empty) spill
+ * blocks; through the three BWT kernels a workgroup owns one workspace slot.  With two streams,
+ * rounds alternate between them, each stream with its own set of slots: a round's launches stay
+ * ordered, but workgroups of the other stream's round fill the CUs that a kernel boundary, or
+ * a round with fewer blocks than CUs, would leave idle.  A last round shorter than the others
+ * is issued first so that the chunk does not END on a half-empty device.
  * The caller's stream joins the side stream before anything else is enqueued on it.          */
 static int timed_begin(lbzamd_ctx *c, size_t *nbev, int kind, hipStream_t s)
 {
@@ -206,42 +207,43 @@ static int timed_end(lbzamd_ctx *c, size_t *nbev, hipStream_t s)
 
 static int run_chunk(lbzamd_ctx *c, const u8 *d_in, size_t len, uint32_t nsl, int upto, float ms[5])
 {
-  const uint32_t nblk = 2u * nsl;
   hipStream_t s = c->stream;
   HIPCHK(hipEventRecord(c->ev[0], s));
   hipLaunchKernelGGL(k_collect, dim3(nsl), dim3(LBZ_WG), 0, s, d_in, (u64)len, c->L, c->T, c->meta);
   HIPCHK(hipEventRecord(c->ev[1], s));
   size_t nbev = 0;
   if (upto >= 1) {
-    const uint32_t nrounds = (nblk + c->nslots - 1u) / c->nslots;
+    const uint32_t nrounds = (nsl + c->nslots - 1u) / c->nslots;
     const bool two = c->nstreams > 1 && nrounds > 1;
     if (two) for (unsigned k = 0; k + 1 < c->nstreams; k++) HIPCHK(hipStreamWaitEvent(c->side[k], c->ev[1], 0));
-    const uint32_t odd = (nsl % c->nslots) ? nsl / c->nslots : nrounds;     /* round with the last primaries */
+    const bool short_last = (nsl % c->nslots) != 0u;                         /* issue the short round first */
     for (uint32_t i = 0; i < nrounds; i++) {
-      const uint32_t r = (odd < nrounds) ? (i == 0 ? odd : (i <= odd ? i - 1u : i)) : i;
+      const uint32_t r = short_last ? (i == 0 ? nrounds - 1u : i - 1u) : i;
       const uint32_t first = r * c->nslots;
-      const uint32_t grid = nblk - first < c->nslots ? nblk - first : c->nslots;
+      const uint32_t count = nsl - first < c->nslots ? nsl - first : c->nslots;
+      const uint32_t grid = 2u * count;
       const unsigned lane = two ? i % c->nstreams : 0u;
       hipStream_t q = lane ? c->side[lane - 1u] : s;
-      u8 *ws = c->ws + (size_t)lane * c->nslots * c->slot_bytes;
+      u8 *ws = c->ws + (size_t)lane * c->nslots * (c->slot_bytes + c->spill_bytes);
+      u8 *wsp = ws + (size_t)c->nslots * c->slot_bytes;
       if (timed_begin(c, &nbev, 0, q)) return -1;
       hipLaunchKernelGGL(k_bwt_part, dim3(grid), dim3(LBZ_BWT_WG), 0, q, (const u8 *)c->T, c->meta, c->L,
-                         first, nsl, ws, (u64)c->slot_bytes);
+                         first, count, ws, (u64)c->slot_bytes, wsp, (u64)c->spill_bytes);
       if (timed_end(c, &nbev, q) || timed_begin(c, &nbev, 1, q)) return -1;
       hipLaunchKernelGGL(k_bwt_batch, dim3(grid), dim3(LBZ_BWT_WG), 0, q, (const u8 *)c->T, c->B, c->meta, c->L,
-                         first, nsl, ws, (u64)c->slot_bytes);
+                         first, count, ws, (u64)c->slot_bytes, wsp, (u64)c->spill_bytes);
       if (timed_end(c, &nbev, q) || timed_begin(c, &nbev, 2, q)) return -1;
       hipLaunchKernelGGL(k_bwt_fix, dim3(grid), dim3(LBZ_BWT_WG), 0, q, (const u8 *)c->T, c->B, c->meta, c->L,
-                         first, nsl, ws, (u64)c->slot_bytes);
+                         first, count, ws, (u64)c->slot_bytes, wsp, (u64)c->spill_bytes);
       if (timed_end(c, &nbev, q)) return -1;
       if (upto >= 2) {
         if (timed_begin(c, &nbev, 3, q)) return -1;
-        hipLaunchKernelGGL(k_mtf, dim3(grid), dim3(LBZ_WG), 0, q, (const u8 *)c->B, c->R, c->V, c->freq, c->meta, c->L, first, nsl);
+        hipLaunchKernelGGL(k_mtf, dim3(grid), dim3(LBZ_WG), 0, q, (const u8 *)c->B, c->R, c->V, c->freq, c->meta, c->L, first, count);
         if (timed_end(c, &nbev, q)) return -1;
       }
       if (upto >= 3) {
         if (timed_begin(c, &nbev, 4, q)) return -1;
-        hipLaunchKernelGGL(k_encode, dim3(grid), dim3(LBZ_WG), 0, q, (const u16 *)c->V, (const u32 *)c->freq, c->O, c->meta, c->L, first, nsl);
+        hipLaunchKernelGGL(k_encode, dim3(grid), dim3(LBZ_WG), 0, q, (const u16 *)c->V, (const u32 *)c->freq, c->O, c->meta, c->L, first, count);
         if (timed_end(c, &nbev, q)) return -1;
       }
     }
@@ -513,9 +515,12 @@ extern "C" size_t lbzamd_encode(encoder_state *e, uint32_t *crc)
   hipStream_t s = c->stream;
   /* the slab is resident and collected; run the remaining stages on its primary block only */
   if (hipSetDevice(c->device) != hipSuccess) die("encode");
-  hipLaunchKernelGGL(k_bwt_part, dim3(1), dim3(LBZ_BWT_WG), 0, s, (const u8 *)c->T, c->meta, c->L, 0u, 1u, c->ws, (u64)c->slot_bytes);
-  hipLaunchKernelGGL(k_bwt_batch, dim3(1), dim3(LBZ_BWT_WG), 0, s, (const u8 *)c->T, c->B, c->meta, c->L, 0u, 1u, c->ws, (u64)c->slot_bytes);
-  hipLaunchKernelGGL(k_bwt_fix, dim3(1), dim3(LBZ_BWT_WG), 0, s, (const u8 *)c->T, c->B, c->meta, c->L, 0u, 1u, c->ws, (u64)c->slot_bytes);
+  hipLaunchKernelGGL(k_bwt_part, dim3(1), dim3(LBZ_BWT_WG), 0, s, (const u8 *)c->T, c->meta, c->L, 0u, 1u, c->ws, (u64)c->slot_bytes,
+                     c->ws + c->slot_bytes, (u64)c->spill_bytes);
+  hipLaunchKernelGGL(k_bwt_batch, dim3(1), dim3(LBZ_BWT_WG), 0, s, (const u8 *)c->T, c->B, c->meta, c->L, 0u, 1u, c->ws, (u64)c->slot_bytes,
+                     c->ws + c->slot_bytes, (u64)c->spill_bytes);
+  hipLaunchKernelGGL(k_bwt_fix, dim3(1), dim3(LBZ_BWT_WG), 0, s, (const u8 *)c->T, c->B, c->meta, c->L, 0u, 1u, c->ws, (u64)c->slot_bytes,
+                     c->ws + c->slot_bytes, (u64)c->spill_bytes);
   hipLaunchKernelGGL(k_mtf, dim3(1), dim3(LBZ_WG), 0, s, (const u8 *)c->B, c->R, c->V, c->freq, c->meta, c->L, 0u, 1u);
   hipLaunchKernelGGL(k_encode, dim3(1), dim3(LBZ_WG), 0, s, (const u16 *)c->V, (const u32 *)c->freq, c->O, c->meta, c->L, 0u, 1u);
   if (hipStreamSynchronize(s) != hipSuccess || hipGetLastError() != hipSuccess) { g_err = "kernel failure"; die("encode"); }

@@ -16,25 +16,31 @@ struct lbz_stream_state {
 };
 
 __global__ void k_collect(const u8 *in, u64 in_len, lbz_layout L, u8 *Tbase, lbz_block_meta *meta);
-/* the BWT stage: queue entries [first_q, first_q + gridDim.x) -> workspace slot blockIdx.x */
-__global__ void k_bwt_part(const u8 *Tbase, lbz_block_meta *meta, lbz_layout L, u32 first_q, u32 nslabs,
-                           u8 *ws, u64 slot_bytes);
-__global__ void k_bwt_batch(const u8 *Tbase, u8 *Bbase, lbz_block_meta *meta, lbz_layout L, u32 first_q,
-                            u32 nslabs, u8 *ws, u64 slot_bytes);
-__global__ void k_bwt_fix(const u8 *Tbase, u8 *Bbase, lbz_block_meta *meta, lbz_layout L, u32 first_q,
-                          u32 nslabs, u8 *ws, u64 slot_bytes);
-/* grid = 2*nslabs: workgroup g owns block lbz_queue_block(g, nslabs): primaries first, so the
- * heavy blocks are spread over all XCDs (block ids of primaries are all even) */
-__global__ void k_mtf(const u8 *Bbase, u8 *Rbase, u16 *Vbase, u32 *freq_out, lbz_block_meta *meta, lbz_layout L, u32 first_q, u32 nslabs);
-__global__ void k_encode(const u16 *Vbase, const u32 *freq_in, u8 *Obase, lbz_block_meta *meta, lbz_layout L, u32 first_q, u32 nslabs);
+/* Per-round kernels.  A round = slabs [first, first + count), grid = 2 * count: workgroup
+ * i < count owns the primary block of slab first + i, workgroup count + i its (usually empty)
+ * spill block -- lbz_round_block().  Primaries come first so that the heavy blocks spread over
+ * all XCDs (their block ids are all even).  The BWT kernels give workgroup i the workspace slot
+ * i of `ws` (count full-size slots, then count spill-size slots at ws_spill).               */
+__global__ void k_bwt_part(const u8 *Tbase, lbz_block_meta *meta, lbz_layout L, u32 first, u32 count,
+                           u8 *ws, u64 slot_bytes, u8 *ws_spill, u64 spill_bytes);
+__global__ void k_bwt_batch(const u8 *Tbase, u8 *Bbase, lbz_block_meta *meta, lbz_layout L, u32 first,
+                            u32 count, u8 *ws, u64 slot_bytes, u8 *ws_spill, u64 spill_bytes);
+__global__ void k_bwt_fix(const u8 *Tbase, u8 *Bbase, lbz_block_meta *meta, lbz_layout L, u32 first,
+                          u32 count, u8 *ws, u64 slot_bytes, u8 *ws_spill, u64 spill_bytes);
+__global__ void k_mtf(const u8 *Bbase, u8 *Rbase, u16 *Vbase, u32 *freq_out, lbz_block_meta *meta, lbz_layout L, u32 first, u32 count);
+__global__ void k_encode(const u16 *Vbase, const u32 *freq_in, u8 *Obase, lbz_block_meta *meta, lbz_layout L, u32 first, u32 count);
 __global__ void k_offsets(const lbz_block_meta *meta, u32 nblk, u32 bs100k, u32 first, u32 last,
                           u64 *offs, lbz_stream_state *st, u8 *out, u64 out_cap);
 __global__ void k_gather(const u8 *Obase, const lbz_block_meta *meta, lbz_layout L, const u64 *offs,
                          const lbz_stream_state *st, u8 *out, u32 nslabs);
 
-__device__ __forceinline__ u32 lbz_queue_block(u32 q, u32 nslabs)
+__device__ __forceinline__ u32 lbz_queue_block(u32 q, u32 nslabs)      /* whole chunk: k_gather */
 {
   return q < nslabs ? 2u * q : 2u * (q - nslabs) + 1u;
+}
+__device__ __forceinline__ u32 lbz_round_block(u32 first, u32 count, u32 i)
+{
+  return i < count ? 2u * (first + i) : 2u * (first + i - count) + 1u;
 }
 
 #endif
