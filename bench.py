@@ -200,15 +200,15 @@ def main():
         dom = max(alg, key=lambda k: kms[k])
         launches = nlaunch[dom] * args.steps
         # HBM traffic of the dominant kernel from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE /
-        # WRITE_SIZE, separate runs; profiles/pmc_traffic.json holds KB per block of the same workload).
+        # WRITE_SIZE, separate runs; profiles/pmc_traffic.json holds KB per slab of the same workload).
         # FETCH_SIZE is doubled (gfx950 tallies wide reads at half, MI355X_MICROARCH.md, HBM).
         traffic = None
         try:
             pt = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
             if pt.get("workload") == f"{args.kind} -{args.level}" and dom in pt["kernels"]:
                 e = pt["kernels"][dom]
-                blocks_per_launch = st.nblocks * args.steps / launches
-                traffic = round((2.0 * e["fetch_kb_per_block"] + e["write_kb_per_block"]) * 1024.0 * blocks_per_launch)
+                slabs_per_launch = nslabs * args.steps / launches
+                traffic = round((2.0 * e["fetch_kb_per_slab"] + e["write_kb_per_slab"]) * 1024.0 * slabs_per_launch)
         except (OSError, ValueError, KeyError):
             traffic = None
         achieved = per_kernel[dom]["achieved_GBps"]
