@@ -209,11 +209,11 @@ __device__ void collect_pass(const u8 *x, u32 base, u32 end, u32 cap, u8 *out, c
 }
 
 __global__ void __launch_bounds__(LBZ_WG)
-k_collect(const u8 *in, u64 in_len, lbz_layout L, u8 *Tbase, lbz_block_meta *meta)
+k_collect(const u8 *in, u64 in_len, lbz_layout L, u8 *Tbase, lbz_block_meta *meta, u32 first)
 {
   __shared__ collect_lds S;
   const u32 tid = threadIdx.x;
-  const u32 slab = blockIdx.x;
+  const u32 slab = first + blockIdx.x;
   const u8 *x = in + (u64)slab * L.M;
   const u64 left = in_len - (u64)slab * L.M;
   const u32 len = left < L.M ? (u32)left : L.M;

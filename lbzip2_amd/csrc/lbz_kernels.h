@@ -15,7 +15,8 @@ struct lbz_stream_state {
   u32 err;
 };
 
-__global__ void k_collect(const u8 *in, u64 in_len, lbz_layout L, u8 *Tbase, lbz_block_meta *meta);
+/* slabs [first, first + gridDim.x) of the chunk that starts at `in` */
+__global__ void k_collect(const u8 *in, u64 in_len, lbz_layout L, u8 *Tbase, lbz_block_meta *meta, u32 first);
 /* Per-round kernels.  A round = slabs [first, first + count), grid = 2 * count: workgroup
  * i < count owns the primary block of slab first + i, workgroup count + i its (usually empty)
  * spill block -- lbz_round_block().  Primaries come first so that the heavy blocks spread over
