@@ -1245,7 +1245,10 @@ k_bwt_batch(const u8 *Tbase, u8 *Bbase, lbz_block_meta *meta, lbz_layout L, u32 
     M->sort_elems = n;
     M->ticks[0] = (u32)(wall_clock64() - tk0);
     for (u32 i = 0; i < 3; i++) M->ticks[3 + i] = S.bc[10 + i];   /* load, group scan (+block sorts), per-wave part */
-    M->ticks[6] = S.bc[13]; M->ticks[7] = S.bc[14]; M->ticks[1] = S.bc[3]; M->ticks[2] = S.bc[4];              /* summed over waves: busy, of which first sort */
+#ifndef COL_TICKS
+    M->ticks[6] = S.bc[13]; M->ticks[7] = S.bc[14];
+#endif
+    M->ticks[1] = S.bc[3]; M->ticks[2] = S.bc[4];              /* summed over waves: busy, of which first sort */
   }
 }
 

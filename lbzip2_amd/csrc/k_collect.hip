@@ -34,6 +34,8 @@ struct collect_lds {
   u32 part[LBZ_WG];
   u32 inuse[256];
   u32 bc[4];
+  /* one tile's output, laid out like the 16-byte vectors of the block array it goes to */
+  __attribute__((aligned(16))) u8 stage[COL_TILE + COL_TILE / 4u + 64u];
 };
 
 __device__ __forceinline__ u32 crc_mulmod(u32 a, u32 b)
@@ -119,19 +121,25 @@ __device__ void collect_pass(const u8 *x, u32 base, u32 end, u32 cap, u8 *out, c
   u32 o_base = 0;
   u32 cut = end;
 
-  for (u32 t0 = base & ~(COL_TILE - 1u); t0 < end; t0 += COL_TILE) {
+  const u32 tfirst = base & ~(COL_TILE - 1u);
+  uint4 nxt = { 0u, 0u, 0u, 0u };
+  if (vec_ok && tfirst + tid * COL_IPT + COL_IPT <= end) nxt = *reinterpret_cast<const uint4 *>(x + tfirst + tid * COL_IPT);
+  for (u32 t0 = tfirst; t0 < end; t0 += COL_TILE) {
     const u32 p0 = t0 + tid * COL_IPT;
     u8 b[COL_IPT];
     if (vec_ok && p0 + COL_IPT <= end) {
-      const uint4 q = *reinterpret_cast<const uint4 *>(x + p0);
-      const u32 wq[4] = { q.x, q.y, q.z, q.w };
+      const u32 wq[4] = { nxt.x, nxt.y, nxt.z, nxt.w };
 #pragma unroll
       for (u32 i = 0; i < COL_IPT; i++) b[i] = (u8)(wq[i >> 2] >> (8u * (i & 3u)));
     } else {
 #pragma unroll
       for (u32 i = 0; i < COL_IPT; i++) b[i] = (p0 + i < end) ? x[p0 + i] : (u8)0;
     }
-    const u8 prevb = (p0 > base && p0 <= end) ? x[p0 - 1] : (u8)0;
+    if (vec_ok && p0 + COL_TILE + COL_IPT <= end)        /* the next tile's bytes, requested a tile ahead */
+      nxt = *reinterpret_cast<const uint4 *>(x + p0 + COL_TILE);
+    /* the byte before this thread's first: the neighbour lane's last, or one load per wave */
+    u8 prevb = (u8)__shfl_up((int)b[COL_IPT - 1u], 1u);
+    if (lane_id() == 0u) prevb = (p0 > base && p0 <= end) ? x[p0 - 1] : (u8)0;
 
     /* run heads and the start of the run each position belongs to */
     u32 headmask = 0, lh = 0;
@@ -185,17 +193,32 @@ __device__ void collect_pass(const u8 *x, u32 base, u32 end, u32 cap, u8 *out, c
       cut = limit;
     }
 
+    /* the tile's bytes go to LDS first and leave as whole 16-byte vectors of the block array */
+    const u32 gbase = o_base & ~15u;
     u32 oo = o;
 #pragma unroll
     for (u32 i = 0; i < COL_IPT; i++) {
       const u32 e = (emit2 >> (2u * i)) & 3u;
       if (e && p0 + i < limit) {
-        out[oo] = b[i];
+        S->stage[oo - gbase] = b[i];
         S->inuse[b[i]] = 1u;
-        if (e == 2u) { out[oo + 1u] = cnt[i]; S->inuse[cnt[i]] = 1u; }
+        if (e == 2u) { S->stage[oo + 1u - gbase] = cnt[i]; S->inuse[cnt[i]] = 1u; }
       }
       oo += e;
     }
+    __syncthreads();
+    {
+      const u32 o_end = (cut != end) ? S->bc[0] : o_base + ttot;        /* bytes of this block so far */
+      const bool out_ok = ((uintptr_t)out & 15u) == 0u;
+      for (u32 v = gbase + 16u * tid; v < o_end; v += 16u * LBZ_WG) {
+        if (out_ok && v >= o_base && v + 16u <= o_end) {
+          *reinterpret_cast<uint4 *>(out + v) = *reinterpret_cast<const uint4 *>(S->stage + (v - gbase));
+        } else {
+          for (u32 k = 0; k < 16u; k++) if (v + k >= o_base && v + k < o_end) out[v + k] = S->stage[v + k - gbase];
+        }
+      }
+    }
+    __syncthreads();
     if (cut != end) break;
     o_base += ttot;
     carry_rs = tmax > carry_rs ? tmax : carry_rs;
@@ -234,10 +257,19 @@ k_collect(const u8 *in, u64 in_len, lbz_layout L, u8 *Tbase, lbz_block_meta *met
     }
     if (tid < 256) S.inuse[tid] = 0;
     __syncthreads();
+#ifdef COL_TICKS
+    const u64 tk0 = wall_clock64();
+#endif
     collect_pass(x, base, len, part ? L.cap_b : L.M, Tbase + lbz_elem_off(L, blk), &S);
     const u32 nblock = S.bc[0], stop = S.bc[1];
     __syncthreads();
+#ifdef COL_TICKS
+    const u64 tk1 = wall_clock64();
+#endif
     const u32 crc = wg_crc32(x, base, stop, len, &S);
+#ifdef COL_TICKS
+    if (tid == 0) { m->ticks[6] = (u32)(tk1 - tk0); m->ticks[7] = (u32)(wall_clock64() - tk1); }
+#endif
     if (tid < 256) m->inuse[tid] = (u8)S.inuse[tid];
     if (tid == 0) {
       m->n = nblock; m->crc = crc; m->consumed = stop - base;

@@ -169,9 +169,11 @@ k_mtf(const u8 *Bbase, u8 *Rbase, u16 *Vbase, u32 *freq_out, lbz_block_meta *met
     for (u32 k = 0; k < 4u; k++) {
       const u32 p = b0 + 64u * k + lane;
       const u32 before = (u32)__shfl_up((int)by[k], 1u);
+      const u32 after = (u32)__shfl_down((int)by[k], 1u);
       if (p < hi) {
+        /* only the ends of runs touch LDS: far fewer atomics, and fewer of them on one address */
         const u32 code = S.cmap[by[k]];
-        atomicMax(&S.last[w][code], (int)p);
+        if (lane == 63u || p + 1u == hi || after != by[k]) atomicMax(&S.last[w][code], (int)p);
         if (lane == 0u || before != by[k]) atomicAdd(&S.hist[code], 1u);    /* run heads (about) */
       }
     }
@@ -221,6 +223,7 @@ k_mtf(const u8 *Bbase, u8 *Rbase, u16 *Vbase, u32 *freq_out, lbz_block_meta *met
   const u64 tk2 = wall_clock64();
 #endif
   /* zero-run coding + histogram */
+  u32 hot0 = 0, hot1 = 0, hot2 = 0;   /* RUNA, RUNB and rank 1 are counted in registers: half of all symbols */
   u32 carry_nz = 0;        /* (position of the last non-zero rank) + 1 */
   u32 o_base = 0;
   for (u32 t0 = 0; t0 < n; t0 += MTF_TILE) {
@@ -261,17 +264,19 @@ k_mtf(const u8 *Bbase, u8 *Rbase, u16 *Vbase, u32 *freq_out, lbz_block_meta *met
         while (z) {
           const u32 d = (z - 1u) & 1u;
           mtfv[o++] = (u16)d;
-          atomicAdd(&S.hist[d], 1u);
+          if (d) hot1++; else hot0++;
           z = (z - 1u) >> 1;
         }
         mtfv[o++] = (u16)(r[i] + 1u);
-        atomicAdd(&S.hist[r[i] + 1u], 1u);
+        if (r[i] == 1u) hot2++; else atomicAdd(&S.hist[r[i] + 1u], 1u);
         prev1 = p0 + i + 1u;
       }
     }
     o_base += ttot;
     carry_nz = tnz > carry_nz ? tnz : carry_nz;
   }
+  hot0 = wave_sum(hot0); hot1 = wave_sum(hot1); hot2 = wave_sum(hot2);
+  if (lane == 0u) { atomicAdd(&S.hist[0], hot0); atomicAdd(&S.hist[1], hot1); atomicAdd(&S.hist[2], hot2); }
   __syncthreads();
   if (tid == 0) {
     u32 o = o_base;
