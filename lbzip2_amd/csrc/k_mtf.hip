@@ -77,6 +77,7 @@ __device__ __forceinline__ void mtf_ranks(const u8 *bwt, u8 *rk, u32 lo, u32 hi,
       if (lane == 0u) cprev = carry;
       carry = __builtin_amdgcn_readlane(c, 63);
       u64 heads = __ballot(ok && c != cprev);
+      const u64 rare = NQ > 1 ? __ballot(c > 63) : 0ull;
       int myrank = 0;
       const int sb0 = __builtin_amdgcn_readfirstlane((int)b0);
       while (heads) {
@@ -84,10 +85,12 @@ __device__ __forceinline__ void mtf_ranks(const u8 *bwt, u8 *rk, u32 lo, u32 hi,
            the new position are lane writes */
         if (NQ > 1) {
           /* frequent symbols (slots are numbered by falling head count, register 0 holds the 64
-             busiest): nothing to select, one register to write -- lbz_asm.h               */
-          unsigned long long h = heads;
-          mtf_fast_heads(h, myrank, Lq, c, sb0);
-          heads = h;
+             busiest): nothing to select, one register to write.  All heads below the first
+             rare one go through the hand-scheduled loop of lbz_asm.h in one call.           */
+          const u64 low = rare & heads;
+          const u64 fast = low ? heads & ((low & (0ull - low)) - 1ull) : heads;
+          mtf_fast_heads(fast, myrank, Lq, c, sb0);
+          heads &= ~fast;
           if (!heads) break;
         }
         const int l = (int)__ffsll((long long)heads) - 1;
