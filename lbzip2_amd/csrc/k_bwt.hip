@@ -64,6 +64,9 @@
 #define WAVE_GROUP 1024u                /* batches holding a longer group are sorted by the whole workgroup */
 #endif
 #define MAX_SYMS 32u                    /* symbols per key, capped (halo of the text tile) */
+#ifndef REFINE_BUDGET_DIV
+#define REFINE_BUDGET_DIV 8u             /* a block stops refining after re-sorting n / this many tied rows */
+#endif
 #ifndef REFINE_ROUNDS
 #define REFINE_ROUNDS 12u                /* in-LDS refinements of a batch before rows are left to the doubling */
 #endif
@@ -91,6 +94,7 @@ struct batch_lds {                      /* one batch resident in LDS */
   u32 dbase[256];
   u16 cstart[BATCH_CAP / 64u + 2u];     /* first row of the chunk that belongs to each claim window */
   u8 corder[BATCH_CAP / 64u + 2u];      /* chunks, longest first */
+  u16 ctied[BATCH_CAP / 64u + 2u];      /* doubling: rows of each chunk that stay tied */
 };
 struct bwt_lds {
   wg_scratch sc;
@@ -800,7 +804,7 @@ __device__ void wave_finish_chunk(batch_lds *B, u32 cs, u32 ce, bool need_sort, 
   for (u32 r = 0; r < REFINE_ROUNDS && ntied && before; r++) {
     /* block-wide budget of tied-row rounds: a block that has burnt n/8 of them is a repetitive
        one that will need the doubling anyway -- stop refining its remaining chunks */
-    if ((u32)__builtin_amdgcn_readfirstlane((int)S->bc[9]) > n / 8u) break;
+    if ((u32)__builtin_amdgcn_readfirstlane((int)S->bc[9]) > n / REFINE_BUDGET_DIV) break;
     if (lane == 0u) atomicAdd(&S->bc[9], ntied);
     /* every tied rotation trades its key for its next sy symbols; its run is re-sorted on them
        (counting for short runs, a per-run radix sort otherwise) and split where they differ */
@@ -867,6 +871,32 @@ __device__ u32 batch_runs(batch_lds *B, const u64 *kR, u32 cnt, u32 sh, u32 *max
   return ntied;
 }
 
+/* Chunks of a batch whose runs (gh, gend) are known: chunk k = the groups that start inside
+ * window k of CHUNK_WIN rows, [cstart[k], cstart[k+1]).  The bounds are fixed here, before any
+ * wave starts rewriting the run tables; corder lists the chunks longest first (the longest
+ * bounds the batch).  Waves then claim chunks with wave_claim().  Returns the number of windows. */
+__device__ u32 chunk_plan(batch_lds *B, u32 cnt)
+{
+  const u32 tid = threadIdx.x;
+  const u32 nwin = (cnt + CHUNK_WIN - 1u) / CHUNK_WIN;
+  if (tid <= nwin) {
+    const u32 w0 = tid * CHUNK_WIN;
+    B->cstart[tid] = (u16)(w0 >= cnt ? cnt : ((B->gh[w0] == w0) ? w0 : B->gend[B->gh[w0]]));
+  }
+  __syncthreads();
+  if (tid < nwin) {
+    const u32 mine = (u32)B->cstart[tid + 1u] - (u32)B->cstart[tid];
+    u32 r = 0;
+    for (u32 j = 0; j < nwin; j++) {
+      const u32 o = (u32)B->cstart[j + 1u] - (u32)B->cstart[j];
+      r += (o > mine || (o == mine && j < tid)) ? 1u : 0u;
+    }
+    B->corder[r] = (u8)tid;
+  }
+  __syncthreads();
+  return nwin;
+}
+
 /* Order rows [lo, lo+cnt) completely (as far as REFINE_ROUNDS reach) and emit them.
  * presorted: rows already sorted by the full key (cut at key boundaries); otherwise they are
  * only grouped by the partition's top MSD_BITS.  preloaded: the batch already sits in (kA,vA),
@@ -904,24 +934,7 @@ __device__ void batch_process(const u8 *T, u32 n, u8 *bwt, lbz_block_meta *meta,
     batch_runs(B, B->kA, cnt, 0u, &maxrun, S);
   }
   const u64 tb2 = wall_clock64();
-  /* chunk k = the groups that start inside window k of CHUNK_WIN rows; waves claim chunks in
-     turn.  The bounds are fixed before any wave starts rewriting the run tables.            */
-  const u32 nwin = (cnt + CHUNK_WIN - 1u) / CHUNK_WIN;
-  if (tid <= nwin) {
-    const u32 w0 = tid * CHUNK_WIN;
-    B->cstart[tid] = (u16)(w0 >= cnt ? cnt : ((B->gh[w0] == w0) ? w0 : B->gend[B->gh[w0]]));
-  }
-  __syncthreads();
-  if (tid < nwin) {                            /* longest chunk first: it bounds the batch */
-    const u32 mine = (u32)B->cstart[tid + 1u] - (u32)B->cstart[tid];
-    u32 r = 0;
-    for (u32 j = 0; j < nwin; j++) {
-      const u32 o = (u32)B->cstart[j + 1u] - (u32)B->cstart[j];
-      r += (o > mine || (o == mine && j < tid)) ? 1u : 0u;
-    }
-    B->corder[r] = (u8)tid;
-  }
-  __syncthreads();
+  const u32 nwin = chunk_plan(B, cnt);
   for (;;) {
     const u32 t = wave_claim(&S->bc[7]);
     if (t >= nwin) break;
@@ -1022,7 +1035,7 @@ __device__ void big_group(const u8 *T, u32 n, u8 *bwt, lbz_block_meta *meta, bwt
 __device__ u32 doubling_round(const u8 *T, u32 n, u8 *bwt, bwt_slot s, bwt_lds *S, u32 h, u32 m)
 {
   batch_lds *B = &S->u.B;
-  const u32 tid = threadIdx.x, lane = lane_id(), w = wave_id();
+  const u32 tid = threadIdx.x, lane = lane_id();
   u32 out_m = 0, k0 = 0;
   while (k0 < m) {
     u32 e = k0 + BATCH_CAP < m ? k0 + BATCH_CAP : m;
@@ -1049,6 +1062,8 @@ __device__ u32 doubling_round(const u8 *T, u32 n, u8 *bwt, bwt_slot s, bwt_lds *
       e = cut;
     }
     const u32 cnt = e - k0;
+    const u64 td0 = wall_clock64();
+    if (tid == 0) { S->bc[7] = 0; S->bc[6] = 0; }        /* chunk tickets of the two phases */
     for (u32 i = tid; i < cnt; i += LBZ_WG) {
       const u32 sf = s.sufx[k0 + i];
       u32 t = sf + h;
@@ -1058,17 +1073,20 @@ __device__ u32 doubling_round(const u8 *T, u32 n, u8 *bwt, bwt_slot s, bwt_lds *
       B->kB[i] = (u64)s.grp[k0 + i];
     }
     __syncthreads();
+    const u64 td1 = wall_clock64();
     u32 maxrun;
     batch_runs(B, B->kB, cnt, 0u, &maxrun, S);            /* the runs as they stand */
-    u32 cs = 0, ce = 0, mytied = 0;
-    {
-      const u32 w0 = w * 256u, w1 = w0 + 256u;
-      if (w0 < cnt) {
-        cs = (B->gh[w0] == w0) ? w0 : B->gend[B->gh[w0]];
-        ce = (w1 >= cnt) ? cnt : ((B->gh[w1] == w1) ? w1 : B->gend[B->gh[w1]]);
-      }
+    const u64 td2 = wall_clock64();
+    /* sort phase: waves claim chunks, longest first (as in batch_process) */
+    const u32 nwin = chunk_plan(B, cnt);
+    for (;;) {
+      const u32 t = wave_claim(&S->bc[7]);
+      if (t >= nwin) break;
+      const u32 k = B->corder[t];
+      const u32 cs = B->cstart[k], ce = B->cstart[k + 1u];
+      u32 mytied = 0;
       if (cs < ce) {
-        wave_sort_chunk<false>(B, cs, ce);
+        wave_sort_chunk<true>(B, cs, ce);       /* ranks are 20-bit keys: (key << 12 | row) loses nothing */
         /* rows of the sorted positions (a run occupies consecutive rows), kept in kB */
         for (u32 j = cs + lane; j < ce; j += 64u) {
           const u32 gs = B->gh[j];
@@ -1077,32 +1095,43 @@ __device__ u32 doubling_round(const u8 *T, u32 n, u8 *bwt, bwt_slot s, bwt_lds *
         wave_sync();
         mytied = wave_runs<true>(B, cs, ce);
       }
-      if (lane == 0u) S->sc.a[w] = mytied;
+      if (lane == 0u) B->ctied[k] = (u16)mytied;
     }
     __syncthreads();
-    u32 off = out_m, total = 0;
-#pragma unroll
-    for (u32 w2 = 0; w2 < LBZ_NW; w2++) { const u32 t = S->sc.a[w2]; if (w2 < w) off += t; total += t; }
-    for (u32 j0 = cs; j0 < ce; j0 += 64u) {
-      const u32 j = j0 + lane;
-      const bool ok = j < ce;
-      const bool td = ok && B->tied[j];
-      const u64 mask = __ballot(td);
-      if (ok) {
-        const u32 row = (u32)B->kB[j], sf = B->vA[j];
-        const u32 newrank = (u32)B->kB[B->gh[j]];
-        s.sa[row] = sf;
-        s.isa[sf] = newrank;
-        if (td) {
-          const u32 o = off + (u32)__popcll(mask & lanes_below());
-          s.sufx[o] = sf; s.grp[o] = newrank; s.pos[o] = row;
-        } else {
-          bwt[row] = T[sf ? sf - 1u : n - 1u];
+    const u64 td3 = wall_clock64();
+    /* write phase: a chunk's still-tied rows go behind those of the chunks before it */
+    const u32 myct = lane < nwin ? (u32)B->ctied[lane] : 0u;         /* nwin <= 64: one lane per chunk */
+    const u32 total = wave_sum(myct);
+    for (;;) {
+      const u32 k = wave_claim(&S->bc[6]);
+      if (k >= nwin) break;
+      const u32 cs = B->cstart[k], ce = B->cstart[k + 1u];
+      u32 off = out_m + wave_sum(lane < k ? myct : 0u);
+      for (u32 j0 = cs; j0 < ce; j0 += 64u) {
+        const u32 j = j0 + lane;
+        const bool ok = j < ce;
+        const bool td = ok && B->tied[j];
+        const u64 mask = __ballot(td);
+        if (ok) {
+          const u32 row = (u32)B->kB[j], sf = B->vA[j];
+          const u32 newrank = (u32)B->kB[B->gh[j]];
+          s.sa[row] = sf;
+          s.isa[sf] = newrank;
+          if (td) {
+            const u32 o = off + (u32)__popcll(mask & lanes_below());
+            s.sufx[o] = sf; s.grp[o] = newrank; s.pos[o] = row;
+          } else {
+            bwt[row] = T[sf ? sf - 1u : n - 1u];
+          }
         }
+        off += (u32)__popcll(mask);
       }
-      off += (u32)__popcll(mask);
     }
     __syncthreads();
+    if (tid == 0) {
+      S->bc[10] += (u32)(td1 - td0); S->bc[11] += (u32)(td2 - td1); S->bc[12] += (u32)(td3 - td2);
+      S->bc[13] += (u32)(wall_clock64() - td3); S->bc[14] += 1u;
+    }
     out_m += total;
     k0 = e;
   }
@@ -1267,5 +1296,9 @@ k_bwt_fix(const u8 *Tbase, u8 *Bbase, lbz_block_meta *meta, lbz_layout L, u32 fi
   const keycfg c = bwt_setup(M, &S);
   u32 rounds = 0, work = 0;
   finish_by_doubling(Tbase + off, n, Bbase + off, M, s, &S, c.sy, &rounds, &work);
-  if (threadIdx.x == 0) { M->rounds = rounds; M->sort_elems = n + work; }
+  if (threadIdx.x == 0) {
+    M->rounds = rounds; M->sort_elems = n + work;
+    M->ticks[0] = S.bc[14];                                   /* LDS batches of the doubling rounds */
+    for (u32 i = 0; i < 4; i++) M->ticks[2 + i] = S.bc[10 + i];  /* load, run scan, per-wave sort, write-back */
+  }
 }

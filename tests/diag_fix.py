@@ -20,4 +20,4 @@ with lib.context(9, 64) as ctx:
         t = list(bi.ticks)
         print("blk", b, "n", bi.n, "rounds", bi.rounds, "tied after batch %d (%.1f%%)" % (t[1], 100.0 * t[1] / bi.n),
               "doubling rows / n = %.2f" % (bi.sort_elems / bi.n - 1.0),
-              "ms: batch %.2f regroup %.2f fix %.2f" % (t[0] / 1e5, t[6] / 1e5, t[7] / 1e5))
+              "| fix ms: regroup %.2f total %.2f | %d batches: load %.2f runs %.2f sort %.2f write %.2f" % (t[6] / 1e5, t[7] / 1e5, t[0], t[2] / 1e5, t[3] / 1e5, t[4] / 1e5, t[5] / 1e5))
