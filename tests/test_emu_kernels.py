@@ -57,6 +57,17 @@ def test_streams_multi_slab_spill_chunked(emu):
     assert emu.compress(b"", 9) == L.orc_compress(b"", 9)
 
 
+def test_round_schedule(emu, monkeypatch):
+    """Rounds of nslots slabs (short last round issued first, slot sets per stream, spill blocks
+    riding with their primaries): the stream must not depend on the schedule."""
+    data = gen("text", 110000, 11) + gen("runs", 90000, 5) + gen("rand", 70000, 6)   # 3 slabs at -1, one with a big spill
+    want = L.orc_compress(data, 1)
+    for streams, nslots, max_slabs in (("2", 2, 3), ("3", 1, 3), ("2", 1, 2)):           # the last one: two chunks
+        monkeypatch.setenv("LBZAMD_STREAMS", streams)
+        with emu.context(1, max_slabs, nslots) as ctx:
+            assert ctx.compress(data) == want, (streams, nslots, max_slabs)
+
+
 def test_workunit_interface(emu):
     data = gen("runs", 110000, 2) + gen("text", 20000, 9)
     assert emu.compress_workunits(data, 1) == L.orc_compress(data, 1)

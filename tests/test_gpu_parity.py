@@ -193,6 +193,20 @@ def test_full_size_property(lib):
     assert out[:4] == b"BZh9" and out[-10:-4] == bytes([0x17, 0x72, 0x45, 0x38, 0x50, 0x90])
 
 
+@pytest.mark.parametrize("streams,nslots,max_slabs", [("1", 3, 14), ("2", 3, 14), ("2", 4, 14), ("3", 2, 14), ("2", 5, 9)])
+def test_round_schedule(lib, monkeypatch, streams, nslots, max_slabs):
+    """Multi-round, multi-stream scheduling (what the 1 GB benchmark runs with 2 x 556 slots) at a
+    size the CPU reference checks in a second: rounds of nslots slabs on `streams` streams, short
+    last round first, spill blocks (large ones: the `runs` part expands under RLE1) riding with
+    their primaries, and a second chunk when max_slabs < 14."""
+    data = gen("text", 6_000_000, 21) + gen("runs", 3_000_000, 22) + gen("rand", 2_000_000, 23) + gen("lines", 1_500_000, 24)
+    want = cpu_reference(data, 9)[0]
+    monkeypatch.setenv("LBZAMD_STREAMS", streams)
+    with lib.context(9, max_slabs, nslots) as ctx:
+        for _ in range(2):                                    # the second call reuses slots and events
+            assert ctx.compress(data) == want
+
+
 def test_device_resident_api(lib):
     import torch
     data = gen("text", 3_000_000, 8)
