@@ -693,41 +693,64 @@ __device__ void wave_sort_chunk(batch_lds *B, u32 cs, u32 ce)
     for (u32 j = cs + lane; j < ce; j += 64u) B->kB[j] = (B->kA[j] << 12) | (u64)j;
     wave_sync();
   }
-  for (u32 j0 = cs; j0 < ce; j0 += 64u) {
-    const u32 j = j0 + lane;
-    if (j < ce) {
-      const u32 gs = B->gh[j], ge = B->gend[gs];
-      u32 dst = j;
-      if (ge - gs <= COUNT_GROUP && ge - gs > 1u) {
-        dst = gs;
-        if (PREFIX_EQUAL) {
+  if (PREFIX_EQUAL) {
+    /* Counted rows go straight to their place: the value into vB, the key back into kA -- rebuilt
+       from the unique key (its low 52 bits) and the 12 bits every row of the group shares, so it
+       does not matter that kA is being overwritten while other rows are still counting.      */
+    for (u32 j0 = cs; j0 < ce; j0 += 64u) {
+      const u32 j = j0 + lane;
+      if (j < ce) {
+        const u32 gs = B->gh[j], ge = B->gend[gs];
+        const u32 v = B->vA[j];
+        u32 dst = j;
+        if (ge - gs <= COUNT_GROUP && ge - gs > 1u) {
           const u64 x = B->kB[j];
+          const u64 top = B->kA[gs] & 0xFFF0000000000000ull;
+          dst = gs;
           u32 q = gs;
           for (; q + 2u <= ge; q += 2u) {
             const u64 y0 = B->kB[q], y1 = B->kB[q + 1u];
             dst += (u32)((y0 - x) >> 63) + (u32)((y1 - x) >> 63);
           }
           if (q < ge) dst += (u32)((B->kB[q] - x) >> 63);
-        } else {
+          B->kA[dst] = top | (x >> 12);
+        }
+        B->vB[dst] = v;
+      }
+    }
+    wave_sync();
+    for (u32 j = cs + lane; j < ce; j += 64u) B->vA[j] = B->vB[j];
+    wave_sync();
+  } else {
+    for (u32 j0 = cs; j0 < ce; j0 += 64u) {
+      const u32 j = j0 + lane;
+      if (j < ce) {
+        const u32 gs = B->gh[j], ge = B->gend[gs];
+        u32 dst = j;
+        if (ge - gs <= COUNT_GROUP && ge - gs > 1u) {
+          dst = gs;
           const u64 x = B->kA[j];
           for (u32 q = gs; q < ge; q++) {
             const u64 y = B->kA[q];
             dst += (y < x) || (y == x && q < j);
           }
         }
+        B->ghn[j] = (u16)dst;
       }
-      B->ghn[j] = (u16)dst;
     }
+    wave_sync();
+    for (u32 j = cs + lane; j < ce; j += 64u) {
+      const u32 dst = B->ghn[j];
+      B->kB[dst] = B->kA[j];
+      B->vB[dst] = B->vA[j];
+    }
+    wave_sync();
+    for (u32 j = cs + lane; j < ce; j += 64u) { B->kA[j] = B->kB[j]; B->vA[j] = B->vB[j]; }
+    wave_sync();
   }
-  wave_sync();
-  for (u32 j = cs + lane; j < ce; j += 64u) {
-    const u32 dst = B->ghn[j];
-    B->kB[dst] = B->kA[j];
-    B->vB[dst] = B->vA[j];
-  }
-  wave_sync();
-  for (u32 j = cs + lane; j < ce; j += 64u) { B->kA[j] = B->kB[j]; B->vA[j] = B->vB[j]; }
-  wave_sync();
+#ifdef SORT_TICKS
+  const u64 tl0 = wall_clock64();
+#endif
   for (u32 j0 = cs; j0 < ce; j0 += 64u) {               /* long groups, one after the other */
     const u32 j = j0 + lane;
     bool longhead = false;
@@ -739,6 +762,9 @@ __device__ void wave_sort_chunk(batch_lds *B, u32 cs, u32 ce)
       wave_radix_range(B, gs, B->gend[gs]);
     }
   }
+#ifdef SORT_TICKS
+  if (PREFIX_EQUAL && lane == 0u) atomicAdd(&reinterpret_cast<bwt_lds *>(reinterpret_cast<char *>(B) - offsetof(bwt_lds, u))->bc[15], (u32)(wall_clock64() - tl0));
+#endif
 }
 
 /* Runs of equal 64-bit keys inside the sorted chunk [cs, ce): gh, gend, tied, wave-private.
@@ -785,7 +811,13 @@ __device__ void wave_finish_chunk(batch_lds *B, u32 cs, u32 ce, bool need_sort, 
   const u64 tw0 = wall_clock64();
   if (need_sort) {
     wave_sort_chunk<true>(B, cs, ce);
+#ifdef SORT_TICKS
+    const u64 tr0 = wall_clock64();
+#endif
     ntied = wave_runs<false>(B, cs, ce);
+#ifdef SORT_TICKS
+    if (lane == 0u) atomicAdd(&S->bc[2], (u32)(wall_clock64() - tr0));
+#endif
   } else {
     ntied = 0;
     for (u32 j0 = cs; j0 < ce; j0 += 64u) {
@@ -1277,7 +1309,13 @@ k_bwt_batch(const u8 *Tbase, u8 *Bbase, lbz_block_meta *meta, lbz_layout L, u32 
 #ifndef COL_TICKS
     M->ticks[6] = S.bc[13]; M->ticks[7] = S.bc[14];
 #endif
-    M->ticks[1] = S.bc[3]; M->ticks[2] = S.bc[4];              /* summed over waves: busy, of which first sort */
+#ifdef SORT_TICKS
+    M->ticks[0] = S.bc[15]; M->ticks[2] = S.bc[2];      /* summed over waves: radix sorts of long groups in the first sort */
+#endif
+#ifndef SORT_TICKS
+    M->ticks[2] = S.bc[4];
+#endif
+    M->ticks[1] = S.bc[3];              /* summed over waves: busy, of which first sort */
   }
 }
 

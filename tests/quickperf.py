@@ -50,6 +50,8 @@ for kind in (sys.argv[2].split(",") if len(sys.argv) > 2 else ("text", "rand")):
         print("   sum over batches of the longest chunk: first sort %.2f ms, sort+refine+emit %.2f ms" % (tk[1] / cnt / 1e5, tk[2] / cnt / 1e5), flush=True)
         if os.environ.get("MTF_TICKS"):
             print("   mtf kernel ms/blk: prelude %.2f ranks %.2f zrle %.2f" % (tk[3] / cnt / 1e5, tk[4] / cnt / 1e5, tk[5] / cnt / 1e5), flush=True)
+        if os.environ.get("SORT_TICKS"):
+            print("   first sort: long-group radix %.2f ms/16, run detection %.2f ms/16 of %.2f" % (tk[0] / cnt / 1e5 / 16, tk[2] / cnt / 1e5 / 16, tk[7] / cnt / 1e5 / 16), flush=True)
         if os.environ.get("COL_TICKS"):
             print("   collect kernel ms/blk (primary block): rle pass %.3f crc %.3f" % (tk[6] / cnt / 1e5, tk[7] / cnt / 1e5), flush=True)
         if os.environ.get("ENC_TICKS"):
