@@ -51,8 +51,9 @@ def gen_input(kind, n, seed):
     return buf
 
 
-def cpu_baseline(data, level, seconds_budget=20.0):
-    """Time the CPU codec on the host cores over a bounded sample of the same workload."""
+def cpu_baseline(data, level, seconds_budget=1.0):
+    """Time the CPU codec on all host cores over a bounded sample of the same workload
+    (at most seconds_budget seconds of wall time at the single-thread rate, i.e. ~cores x that of CPU work)."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_lib as L   # test infrastructure: only used here as the timed CPU baseline
     kind = "reference" if L.have_ref() else "port"
@@ -64,9 +65,10 @@ def cpu_baseline(data, level, seconds_budget=20.0):
     fn(bytes(data[:3 * M]), level)
     t1 = time.perf_counter() - t0
     rate1 = 3 * M / t1
-    # all cores: slabs_per_thread sized for the budget
-    per_thread = max(1, min(16, int(seconds_budget * rate1 / M)))
-    nthreads = min(cores, max(1, len(data) // (per_thread * M)))
+    # every host core gets the same number of whole slabs; the sample is bounded by the budget of CPU seconds
+    nslabs = max(1, len(data) // M)
+    nthreads = min(cores, nslabs)
+    per_thread = max(1, min(nslabs // nthreads, int(seconds_budget * cores * rate1 / M / nthreads)))
     pieces = [bytes(data[i * per_thread * M:(i + 1) * per_thread * M]) for i in range(nthreads)]
     with ThreadPoolExecutor(nthreads) as ex:
         t0 = time.perf_counter()
