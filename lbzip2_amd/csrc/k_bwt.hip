@@ -1,6 +1,6 @@
 /*
  * k_bwt.hip -- stage 2: Burrows-Wheeler transform of the CYCLIC rotations of one block,
- * one block per workgroup, persistent workgroups pulling blocks from a queue.
+ * one block per workgroup, three kernels per round of blocks (lbz_kernels.h).
  *
  * Replaces divbwt() (reference src/divbwt.c:1706-1726; its sort_typeBstar/sssort/trsort/
  * construct_BWT machinery, divbwt.c:1488-1699, is a serial induced-sorting design with no
@@ -10,33 +10,34 @@
  *
  *   keys      every rotation i gets a 64-bit key: the dense codes (b = ceil(log2 #used bytes)
  *             bits each) of its first S = 64/b symbols, plus a 32-bit value
- *             (preceding byte << 24 | i) -- the BWT output byte rides along with the index.
- *   partition three stable 8-bit radix passes in HBM on the key's top 24 bits.  Keys are built
- *             on the fly from the block text streamed through an LDS tile (the first pass
- *             never reads a key array); per-wave digit counters live in LDS, ranks inside a
- *             wave come from 8 ballots per row, tiles are scattered in order so every write
- *             is a run of equal-digit rows.
- *   batches   consecutive whole 24-bit groups of <= 4096 rows are pulled into LDS; rows are
- *             ranked inside their group by counting smaller keys (groups are short), and every
- *             run of equal 64-bit keys is refined IN LDS by fetching the rotation's next S
- *             symbols from the text and re-sorting the run on them (up to 12 times while ties are few and shrinking).  A finished
- *             batch writes 1 B (BWT byte) + 4 B (row) per rotation.
- *   oversized a 24-bit group larger than a batch is sorted on its remaining 40 key bits by the
- *             HBM radix sorter and then cut into batches at key boundaries.
- *   deep ties rows still tied after the LDS refinements (long repeats, periodic blocks) are
- *             finished by prefix doubling on ranks: (group << 20 | rank of the rotation h
- *             further on) keys, HBM radix sort, regroup by max/add scans; it ends when every
- *             row is unique or h >= n.  In the latter case the block is exactly periodic
- *             (T = u^k), equal rows stay tied and the origin pointer is the smallest equal row
- *             (the reference's choice among the k equal rows is an artefact of its unstable
- *             quicksort, SURVEY.md 8a-4 -- documented divergence, identical BWT bytes).
+ *             (code of the preceding byte << 24 | i) -- the BWT output byte rides along.
+ *   k_bwt_part   three stable 8-bit radix passes in HBM on the key's top 24 bits.  Keys are
+ *             built on the fly from the block text streamed through an LDS tile (the first
+ *             pass never reads a key array); per-wave digit counters live in LDS, ranks inside
+ *             a wave come from 8 ballots per row, a tile is regrouped by digit in LDS so that
+ *             every write is a run of equal-digit rows.
+ *   k_bwt_batch  consecutive whole 24-bit groups of <= 4096 rows are pulled into LDS.  Waves
+ *             claim chunks of groups (longest first) from a ticket counter; rows of a short
+ *             group are placed by counting smaller keys, long groups are radix-sorted by their
+ *             wave; every run of equal 64-bit keys is refined IN LDS by fetching the rotations'
+ *             next S symbols from the text and re-sorting the run (bounded: REFINE_ROUNDS, a
+ *             no-progress rule and a block-wide budget).  A finished batch writes 1 B (BWT
+ *             byte) + 4 B (row) per rotation.  A 24-bit group larger than a batch is sorted on
+ *             its remaining 40 key bits by the HBM radix sorter and cut at key boundaries.
+ *   k_bwt_fix    rows still tied (long repeats, periodic blocks) are finished by prefix
+ *             doubling on ranks, in LDS batches of whole runs (doubling_round); it ends when
+ *             every row is unique or h >= n.  In the latter case the block is exactly
+ *             periodic (T = u^k), equal rows stay tied and the origin pointer is the smallest
+ *             equal row (the reference's choice among the k equal rows is an artefact of its
+ *             unstable quicksort, SURVEY.md 8a-4 -- documented divergence, identical BWT bytes).
  *
  * Algorithmic traffic of the stage as priced in SURVEY.md 8(d): read T (1) + write SA (4) +
- * read SA (4) + gather T (1) + write BWT (1) = 11 B per block byte.
+ * read SA (4) + gather T (1) + write BWT (1) = 11 B per block byte; measured HBM traffic is in
+ * profiles/README.md.  ticks[] in the block record are diagnostics (tests/quickperf.py).
  */
-/* The kernel's geometry is its own constant: with LBZ_BWT_WG = 512 (8 waves, 2048-row batches,
- * 73 KB of LDS) two blocks share a CU; measured throughput is the same as one 1024-thread
- * workgroup per CU (the stage is bound by LDS instruction throughput, not by latency).    */
+/* The kernels' geometry is their own constant.  One 1024-thread workgroup per CU (16 waves) is
+ * what the 149 KB of LDS of a batch allow; 512 threads with 2048-row batches (two workgroups per
+ * CU, the same 16 waves) measured the same.                                                */
 #include "lbz_common.h"
 #undef LBZ_WG
 #define LBZ_WG LBZ_BWT_WG
