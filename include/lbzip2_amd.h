@@ -79,12 +79,18 @@ typedef struct lbzamd_stats {
   uint64_t sort_elems;  /* elements passed through the radix sorter (all rounds) */
   uint32_t nblocks;
   uint32_t nperiodic;   /* exactly periodic blocks (origin pointer = smallest equal row) */
-  float ms_collect, ms_bwt, ms_mtf, ms_encode, ms_finish, ms_total;  /* device time, HIP events */
+  /* Device time from HIP events.  ms_total is wall time on the context's stream.  The per-kernel
+     figures are sums over launches on the stream each launch went to; rounds of blocks run on two
+     streams, so launches overlap and the sums exceed ms_total (LBZAMD_STREAMS=1: no overlap). */
+  float ms_collect, ms_bwt, ms_mtf, ms_encode, ms_finish, ms_total;
   float ms_bwt_part, ms_bwt_batch, ms_bwt_fix;   /* the BWT stage's three kernels (sum = ms_bwt) */
 } lbzamd_stats;
 
 /* device < 0: current device.  max_slabs: slabs resident at once (input beyond that is
- * streamed through in chunks).  nslots: concurrently resident BWT workgroups (0 = one per CU). */
+ * streamed through in chunks).  nslots: slabs per round (a round = one launch of every kernel,
+ * one workgroup per block; each round owns one BWT workspace slot per slab); 0 = max_slabs dealt
+ * evenly over the streams, at least one per CU, at most half of the free device memory.
+ * Environment: LBZAMD_STREAMS (1..8, default 2), LBZAMD_SLOTS (default for nslots = 0).        */
 int  lbzamd_create(lbzamd_ctx **ctx, int device, unsigned bs100k, unsigned max_slabs, unsigned nslots);
 void lbzamd_destroy(lbzamd_ctx *ctx);
 const char *lbzamd_last_error(void);
@@ -99,9 +105,10 @@ int  lbzamd_compress_host(lbzamd_ctx *ctx, const uint8_t *in, size_t len,
 /* Upper bound of the stream size for len input bytes. */
 size_t lbzamd_bound(size_t len);
 int  lbzamd_get_stats(lbzamd_ctx *ctx, lbzamd_stats *st);
-/* Concurrently resident BWT workgroups (= blocks per BWT launch round). */
+/* Slabs per round (see lbzamd_create). */
 uint32_t lbzamd_slots(lbzamd_ctx *ctx);
-/* The HIP stream (hipStream_t) all kernels of this context are launched on. */
+/* The HIP stream (hipStream_t) a caller orders against: every call starts and ends on it (rounds
+ * fan out to internal side streams and are joined before the call's last kernels).          */
 void *lbzamd_stream(lbzamd_ctx *ctx);
 
 /* ---- stage access for parity tests (valid for the last chunk of the last call) ---- */

@@ -1,9 +1,9 @@
 /*
  * lbz_api.hip -- host runtime and C ABI (include/lbzip2_amd.h) of the MI355X block
- * compressor: device buffers laid out per block (lbz_common.h), one HIP stream per
- * context, HIP events around every kernel, chunked streaming for inputs larger than the
- * resident capacity, and the drop-in encode.h work-unit functions on top of a pool of
- * one-slab contexts.
+ * compressor: device buffers laid out per block (lbz_common.h), rounds of blocks pipelined
+ * over two HIP streams per context (run_chunk), HIP events around every kernel, chunked
+ * streaming for inputs larger than the resident capacity, and the drop-in encode.h work-unit
+ * functions on top of a pool of one-slab contexts.
  *
  * Mirrors the call sequence of the reference's src/compress.c (work units :73-118,
  * transmit :210-228, reorder + CRC fold :238-250, header/trailer :291-321); nothing here
