@@ -1221,11 +1221,31 @@ __device__ keycfg bwt_setup(const lbz_block_meta *meta, bwt_lds *S)
 
 
 /* ---- kernel 1: partition on the key's top 24 bits: k0 <- text, k1 <- k0, k0 <- k1 ---- */
+/* The partition only needs the sorter's part of the LDS layout, 80 KB: with 64 VGPRs and 80 SGPRs
+ * two workgroups share a CU (twice the loads in flight; -10 % although 12 registers spill).    */
+#ifndef PART_ONE_PER_CU
+struct part_lds {
+  wg_scratch sc;
+  u32 bc[16];
+  u8 cmap[256];
+  u8 inv[256];
+  sort_lds X;
+};
+static_assert(offsetof(part_lds, X) == offsetof(bwt_lds, u), "same layout up to the union");
+static_assert(sizeof(part_lds) <= 81920, "two per CU");
+__global__ void __launch_bounds__(LBZ_WG, 8) __attribute__((amdgpu_num_sgpr(80)))
+#else
 __global__ void __launch_bounds__(LBZ_WG, 4)
+#endif
 k_bwt_part(const u8 *Tbase, lbz_block_meta *meta, lbz_layout L, u32 first, u32 count,
            u8 *ws, u64 slot_bytes, u8 *ws_spill, u64 spill_bytes)
 {
+#ifndef PART_ONE_PER_CU
+  __shared__ part_lds S_;
+  bwt_lds &S = *reinterpret_cast<bwt_lds *>(&S_);
+#else
   __shared__ bwt_lds S;
+#endif
   const u32 tid = threadIdx.x;
   const u32 blk = lbz_round_block(first, count, blockIdx.x);
   const u32 n = meta[blk].n;
