@@ -936,13 +936,20 @@ __device__ u32 chunk_plan(batch_lds *B, u32 cnt)
  * in text order (a whole small block).  Sets S->bc[8] if ties are left over.
  * Workgroup-wide steps: load, (rarely) a full LDS radix sort, the group scan.  Everything else
  * happens per wave on the groups that start in the wave's 256-row window.                   */
-__device__ void batch_process(const u8 *T, u32 n, u8 *bwt, lbz_block_meta *meta, bwt_slot s,
-                              bwt_lds *S, keycfg c, u32 lo, u32 cnt, bool presorted, bool preloaded)
+/* trim: rows [lo, lo+cnt) are as many as fit; a last group that continues beyond them is left
+ * for the next batch (the caller advances by the return value; 0 = a single group fills the whole
+ * batch).  Finding the cut on the rows already in LDS saves the separate search in HBM.      */
+__device__ u32 batch_process(const u8 *T, u32 n, u8 *bwt, lbz_block_meta *meta, bwt_slot s,
+                             bwt_lds *S, keycfg c, u32 lo, u32 cnt, bool presorted, bool preloaded,
+                             bool trim = false)
 {
   batch_lds *B = &S->u.B;
   const u32 tid = threadIdx.x;
   const u64 tb0 = wall_clock64();
-  if (tid == 0) { S->bc[7] = 0; S->bc[5] = 0; S->bc[6] = 0; }   /* window claim counter; the barriers below publish it */
+  if (tid == 0) {
+    S->bc[7] = 0; S->bc[5] = 0; S->bc[6] = 0;        /* window claim counter; the barriers below publish it */
+    if (trim) S->bc[1] = lo + cnt < n ? (u32)(s.k0[lo + cnt] >> MSD_SHIFT) : 0xFFFFFFFFu;   /* MSD_BITS <= 32 */
+  }
   if (!preloaded) {
     for (u32 i = tid; i < cnt; i += LBZ_WG) { B->kA[i] = s.k0[lo + i]; B->vA[i] = s.v0[lo + i]; }
     __syncthreads();
@@ -958,6 +965,10 @@ __device__ void batch_process(const u8 *T, u32 n, u8 *bwt, lbz_block_meta *meta,
     need_sort = false;
   }
   batch_runs(B, B->kA, cnt, need_sort ? MSD_SHIFT : 0u, &maxrun, S);
+  if (trim && lo + cnt < n && (u32)(B->kA[cnt - 1u] >> MSD_SHIFT) == S->bc[1]) {
+    cnt = B->gh[cnt - 1u];                       /* the last group goes on: it waits for the next batch */
+    if (cnt == 0u) { __syncthreads(); return 0u; }
+  }
   if (need_sort && maxrun > WAVE_GROUP) {
     if (lds_radix_sort(B, cnt, S)) {
       for (u32 i = tid; i < cnt; i += LBZ_WG) { B->kA[i] = B->kB[i]; B->vA[i] = B->vB[i]; }
@@ -980,6 +991,7 @@ __device__ void batch_process(const u8 *T, u32 n, u8 *bwt, lbz_block_meta *meta,
     S->bc[10] += (u32)(tb1 - tb0); S->bc[11] += (u32)(tb2 - tb1); S->bc[12] += (u32)(wall_clock64() - tb2);
     S->bc[3] += S->bc[5]; S->bc[4] += S->bc[6];          /* longest single chunk: first sort, everything */
   }
+  return cnt;
 }
 
 /* rows [lo,hi) share one 64-bit key: nothing an LDS batch can do for them */
@@ -1221,9 +1233,7 @@ __device__ keycfg bwt_setup(const lbz_block_meta *meta, bwt_lds *S)
 
 
 /* ---- kernel 1: partition on the key's top 24 bits: k0 <- text, k1 <- k0, k0 <- k1 ---- */
-/* The partition only needs the sorter's part of the LDS layout, 80 KB: with 64 VGPRs and 80 SGPRs
- * two workgroups share a CU (twice the loads in flight; -10 % although 12 registers spill).    */
-#ifndef PART_ONE_PER_CU
+/* the partition only needs the sorter's part of the LDS layout: 80 KB */
 struct part_lds {
   wg_scratch sc;
   u32 bc[16];
@@ -1233,19 +1243,10 @@ struct part_lds {
 };
 static_assert(offsetof(part_lds, X) == offsetof(bwt_lds, u), "same layout up to the union");
 static_assert(sizeof(part_lds) <= 81920, "two per CU");
-__global__ void __launch_bounds__(LBZ_WG, 8) __attribute__((amdgpu_num_sgpr(80)))
-#else
-__global__ void __launch_bounds__(LBZ_WG, 4)
-#endif
-k_bwt_part(const u8 *Tbase, lbz_block_meta *meta, lbz_layout L, u32 first, u32 count,
-           u8 *ws, u64 slot_bytes, u8 *ws_spill, u64 spill_bytes)
+
+__device__ __forceinline__ void part_block(bwt_lds &S, const u8 *Tbase, lbz_block_meta *meta, lbz_layout L, u32 first, u32 count,
+                                           u8 *ws, u64 slot_bytes, u8 *ws_spill, u64 spill_bytes)
 {
-#ifndef PART_ONE_PER_CU
-  __shared__ part_lds S_;
-  bwt_lds &S = *reinterpret_cast<bwt_lds *>(&S_);
-#else
-  __shared__ bwt_lds S;
-#endif
   const u32 tid = threadIdx.x;
   const u32 blk = lbz_round_block(first, count, blockIdx.x);
   const u32 n = meta[blk].n;
@@ -1271,6 +1272,25 @@ k_bwt_part(const u8 *Tbase, lbz_block_meta *meta, lbz_layout L, u32 first, u32 c
     cur ^= 1u;
   }
   if (tid == 0) meta[blk].ticks[2] = (u32)(wall_clock64() - tk0);
+}
+
+/* One body, two register budgets.  k_bwt_part: 128 VGPRs, one workgroup per CU -- for rounds of
+ * at most one full-size block per CU.  k_bwt_part2: 64 VGPRs (12 spill) and 80 SGPRs, so that
+ * two workgroups share a CU (the LDS layout is 80 KB either way): twice the loads in flight,
+ * -10 % on rounds that have the blocks for it, +12 % on those that do not.                    */
+__global__ void __launch_bounds__(LBZ_WG, 4)
+k_bwt_part(const u8 *Tbase, lbz_block_meta *meta, lbz_layout L, u32 first, u32 count,
+           u8 *ws, u64 slot_bytes, u8 *ws_spill, u64 spill_bytes)
+{
+  __shared__ part_lds S_;
+  part_block(*reinterpret_cast<bwt_lds *>(&S_), Tbase, meta, L, first, count, ws, slot_bytes, ws_spill, spill_bytes);
+}
+__global__ void __launch_bounds__(LBZ_WG, 8) __attribute__((amdgpu_num_sgpr(80)))
+k_bwt_part2(const u8 *Tbase, lbz_block_meta *meta, lbz_layout L, u32 first, u32 count,
+            u8 *ws, u64 slot_bytes, u8 *ws_spill, u64 spill_bytes)
+{
+  __shared__ part_lds S_;
+  part_block(*reinterpret_cast<bwt_lds *>(&S_), Tbase, meta, L, first, count, ws, slot_bytes, ws_spill, spill_bytes);
 }
 
 /* ---- kernel 2: LDS batches of whole groups; emits BWT bytes + rows; flags deep ties ---- */
@@ -1305,19 +1325,15 @@ k_bwt_batch(const u8 *Tbase, u8 *Bbase, lbz_block_meta *meta, lbz_layout L, u32 
   } else {
     u32 pos = 0;
     while (pos < n) {
-      u32 e = pos + BATCH_CAP < n ? pos + BATCH_CAP : n;
-      if (e < n) {
-        const u32 cut = find_cut(s.k0, pos, e, MSD_SHIFT, &S);
-        if (!cut) {
-          const u32 end = find_run_end(s.k0, pos, e, n, MSD_SHIFT, &S);
-          big_group(T, n, bwt, M, s, &S, c, pos, end);
-          pos = end;
-          continue;
-        }
-        e = cut;
+      const u32 want = n - pos < BATCH_CAP ? n - pos : BATCH_CAP;
+      const u32 used = batch_process(T, n, bwt, M, s, &S, c, pos, want, false, false, true);
+      if (used == 0u) {                          /* one group fills the batch: sort it in HBM first */
+        const u32 end = find_run_end(s.k0, pos, pos + want, n, MSD_SHIFT, &S);
+        big_group(T, n, bwt, M, s, &S, c, pos, end);
+        pos = end;
+        continue;
       }
-      batch_process(T, n, bwt, M, s, &S, c, pos, e - pos, false, false);
-      pos = e;
+      pos += used;
     }
   }
   __syncthreads();

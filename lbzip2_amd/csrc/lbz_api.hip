@@ -40,7 +40,7 @@ struct lbzamd_ctx {
   int device = 0;
   unsigned bs100k = 9;
   lbz_layout L{};
-  uint32_t max_slabs = 0, nslots = 0;
+  uint32_t max_slabs = 0, nslots = 0, ncus = 0;
   uint64_t slot_bytes = 0, spill_bytes = 0;      /* BWT workspace of a full-size / a spill block */
   hipStream_t stream = nullptr;               /* everything a caller can observe happens in order on this one */
   hipStream_t side[7] = {};                   /* rounds of a chunk go round-robin over stream + side[0 .. nstreams-2] */
@@ -98,6 +98,7 @@ extern "C" int lbzamd_create(lbzamd_ctx **out, int device, unsigned bs100k, unsi
   c->device = device;
   c->bs100k = bs100k;
   c->max_slabs = max_slabs;
+  c->ncus = (uint32_t)prop.multiProcessorCount;
   const uint32_t M = bs100k * 100000u;
   c->L.M = M;
   c->L.cap_a = round_up(M + 64u, 256u);
@@ -234,8 +235,12 @@ static int run_chunk(lbzamd_ctx *c, const u8 *d_in, size_t len, uint32_t nsl, in
       hipLaunchKernelGGL(k_collect, dim3(count), dim3(LBZ_WG), 0, q, d_in, (u64)len, c->L, c->T, c->meta, first);
       if (timed_end(c, &nbev, q)) return -1;
       if (timed_begin(c, &nbev, 0, q)) return -1;
-      hipLaunchKernelGGL(k_bwt_part, dim3(grid), dim3(LBZ_BWT_WG), 0, q, (const u8 *)c->T, c->meta, c->L,
-                         first, count, ws, (u64)c->slot_bytes, wsp, (u64)c->spill_bytes);
+      if (count > c->ncus)
+        hipLaunchKernelGGL(k_bwt_part2, dim3(grid), dim3(LBZ_BWT_WG), 0, q, (const u8 *)c->T, c->meta, c->L,
+                           first, count, ws, (u64)c->slot_bytes, wsp, (u64)c->spill_bytes);
+      else
+        hipLaunchKernelGGL(k_bwt_part, dim3(grid), dim3(LBZ_BWT_WG), 0, q, (const u8 *)c->T, c->meta, c->L,
+                           first, count, ws, (u64)c->slot_bytes, wsp, (u64)c->spill_bytes);
       if (timed_end(c, &nbev, q) || timed_begin(c, &nbev, 1, q)) return -1;
       hipLaunchKernelGGL(k_bwt_batch, dim3(grid), dim3(LBZ_BWT_WG), 0, q, (const u8 *)c->T, c->B, c->meta, c->L,
                          first, count, ws, (u64)c->slot_bytes, wsp, (u64)c->spill_bytes);

@@ -24,6 +24,8 @@ __global__ void k_collect(const u8 *in, u64 in_len, lbz_layout L, u8 *Tbase, lbz
  * i of `ws` (count full-size slots, then count spill-size slots at ws_spill).               */
 __global__ void k_bwt_part(const u8 *Tbase, lbz_block_meta *meta, lbz_layout L, u32 first, u32 count,
                            u8 *ws, u64 slot_bytes, u8 *ws_spill, u64 spill_bytes);
+__global__ void k_bwt_part2(const u8 *Tbase, lbz_block_meta *meta, lbz_layout L, u32 first, u32 count,
+                            u8 *ws, u64 slot_bytes, u8 *ws_spill, u64 spill_bytes);
 __global__ void k_bwt_batch(const u8 *Tbase, u8 *Bbase, lbz_block_meta *meta, lbz_layout L, u32 first,
                             u32 count, u8 *ws, u64 slot_bytes, u8 *ws_spill, u64 spill_bytes);
 __global__ void k_bwt_fix(const u8 *Tbase, u8 *Bbase, lbz_block_meta *meta, lbz_layout L, u32 first,
