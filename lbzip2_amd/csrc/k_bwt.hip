@@ -65,6 +65,9 @@
 #define WAVE_GROUP 1024u                /* batches holding a longer group are sorted by the whole workgroup */
 #endif
 #define MAX_SYMS 32u                    /* symbols per key, capped (halo of the text tile) */
+#ifndef SPLIT_MIN
+#define SPLIT_MIN 256u                  /* a group longer than this is first cut into sub-groups on its next key byte */
+#endif
 #ifndef REFINE_BUDGET_DIV
 #define REFINE_BUDGET_DIV 8u             /* a block stops refining after re-sorting n / this many tied rows */
 #endif
@@ -622,7 +625,8 @@ __device__ u32 lds_radix_sort(batch_lds *B, u32 cnt, bwt_lds *S)
 /* Wave-private LSD radix sort of rows [cs, ce) of the batch (data in A, result in A): strips
  * of 64 rows, the wave's own digit counters, no workgroup barrier.  Key bytes that do not
  * vary inside the range are skipped, so a group that shares its top 24 bits costs <= 5 passes. */
-__device__ void wave_radix_range(batch_lds *B, u32 cs, u32 ce)
+template <bool TOP_ONLY = false>
+__device__ u32 wave_radix_range(batch_lds *B, u32 cs, u32 ce)
 {
   const u32 lane = lane_id(), w = wave_id();
   u64 vo = 0, va = ~0ull;
@@ -630,10 +634,13 @@ __device__ void wave_radix_range(batch_lds *B, u32 cs, u32 ce)
 #pragma unroll
   for (u32 d = 32; d >= 1; d >>= 1) { vo |= __shfl_xor(vo, (int)d); va &= __shfl_xor(va, (int)d); }
   const u64 varying = vo ^ va;
+  if (TOP_ONLY && varying == 0ull) return 64u;
+  const u32 ptop = TOP_ONLY ? (63u - (u32)__clzll((long long)varying)) / 8u : 0u;   /* most significant varying byte */
   u32 cur = 0;
   for (u32 p = 0; p < 8u; p++) {
     const u32 shift = 8u * p;
     if (((varying >> shift) & 255ull) == 0ull) continue;
+    if (TOP_ONLY && p != ptop) continue;
     const u64 *kin = cur ? B->kB : B->kA;
     const u32 *vin = cur ? B->vB : B->vA;
     u64 *kout = cur ? B->kA : B->kB;
@@ -679,6 +686,7 @@ __device__ void wave_radix_range(batch_lds *B, u32 cs, u32 ce)
     for (u32 j = cs + lane; j < ce; j += 64u) { B->kA[j] = B->kB[j]; B->vA[j] = B->vB[j]; }
     wave_sync();
   }
+  return 8u * ptop;
 }
 
 /* Order the rows of chunk [cs, ce) (whole groups of equal top MSD_BITS, data in A) by their
@@ -760,7 +768,7 @@ __device__ void wave_sort_chunk(batch_lds *B, u32 cs, u32 ce)
     while (heads) {
       const u32 gs = j0 + (u32)__ffsll((long long)heads) - 1u;
       heads &= heads - 1ull;
-      wave_radix_range(B, gs, B->gend[gs]);
+      wave_radix_range<false>(B, gs, B->gend[gs]);
     }
   }
 #ifdef SORT_TICKS
@@ -772,16 +780,16 @@ __device__ void wave_sort_chunk(batch_lds *B, u32 cs, u32 ce)
  * WITHIN: the chunk already has runs (gh) that have just been re-sorted on new keys; new runs
  * never cross an old run's first row.  Returns the number of tied rows (wave-uniform).      */
 template <bool WITHIN>
-__device__ u32 wave_runs(batch_lds *B, u32 cs, u32 ce)
+__device__ u32 wave_runs(batch_lds *B, u32 cs, u32 ce, u32 sh = 0u)
 {
   const u32 lane = lane_id();
   u32 carry = cs, ntied = 0;
   for (u32 j0 = cs; j0 < ce; j0 += 64u) {
     const u32 j = j0 + lane;
     const bool ok = j < ce;
-    const u64 k = ok ? B->kA[j] : 0ull;
-    bool hd = ok && (j == cs || B->kA[j - 1u] != k);
-    bool hn = ok && (j + 1u >= ce || B->kA[j + 1u] != k);
+    const u64 k = ok ? B->kA[j] >> sh : 0ull;
+    bool hd = ok && (j == cs || (B->kA[j - 1u] >> sh) != k);
+    bool hn = ok && (j + 1u >= ce || (B->kA[j + 1u] >> sh) != k);
     if (WITHIN && ok) {
       hd = hd || B->gh[j] == j;
       hn = hn || (j + 1u < ce && B->gh[j + 1u] == j + 1u);
@@ -976,6 +984,27 @@ __device__ u32 batch_process(const u8 *T, u32 n, u8 *bwt, lbz_block_meta *meta, 
     }
     need_sort = false;
     batch_runs(B, B->kA, cnt, 0u, &maxrun, S);
+  }
+  if (need_sort && maxrun > SPLIT_MIN) {
+    /* A long group would be one wave's job from start to end and hold the whole batch up.  Cut
+       every such group into sub-groups first: one wave per group orders it on its most
+       significant varying key byte (one counting pass) and marks the runs of that byte as
+       groups, which the chunking below then deals out over several waves.               */
+    if (tid == 0) S->bc[2] = 0;
+    __syncthreads();
+#pragma unroll
+    for (u32 i = 0; i < SORT_IPT; i++) {
+      const u32 j = tid * SORT_IPT + i;
+      if (j < cnt && B->gh[j] == j && (u32)B->gend[j] - j > SPLIT_MIN) B->cstart[atomicAdd(&S->bc[2], 1u)] = (u16)j;
+    }
+    __syncthreads();
+    const u32 nlong = S->bc[2];                               /* <= BATCH_CAP / SPLIT_MIN < size of cstart */
+    for (u32 i = wave_id(); i < nlong; i += LBZ_NW) {
+      const u32 gs = B->cstart[i], ge = B->gend[gs];
+      const u32 sh = wave_radix_range<true>(B, gs, ge);
+      if (sh < 64u) wave_runs<false>(B, gs, ge, sh);
+    }
+    __syncthreads();
   }
   const u64 tb2 = wall_clock64();
   const u32 nwin = chunk_plan(B, cnt);
