@@ -22,6 +22,11 @@
  * Memory: reads the slab once (16 B per lane, coalesced), writes <= 1.25 bytes per input
  * byte; algorithmic traffic N_in + N_rle.
  */
+#include "lbz_common.h"
+#undef LBZ_WG
+#define LBZ_WG LBZ_COLLECT_WG
+#undef LBZ_NW
+#define LBZ_NW (LBZ_WG / 64)
 #include "lbz_kernels.h"
 
 #define COL_IPT 16u
@@ -231,7 +236,7 @@ __device__ void collect_pass(const u8 *x, u32 base, u32 end, u32 cap, u8 *out, c
   __syncthreads();
 }
 
-__global__ void __launch_bounds__(LBZ_WG)
+__global__ void __launch_bounds__(LBZ_WG, 4)
 k_collect(const u8 *in, u64 in_len, lbz_layout L, u8 *Tbase, lbz_block_meta *meta, u32 first)
 {
   __shared__ collect_lds S;

@@ -213,7 +213,7 @@ static int run_chunk(lbzamd_ctx *c, const u8 *d_in, size_t len, uint32_t nsl, in
   size_t nbev = 0;
   if (upto < 1) {
     if (timed_begin(c, &nbev, 5, s)) return -1;
-    hipLaunchKernelGGL(k_collect, dim3(nsl), dim3(LBZ_WG), 0, s, d_in, (u64)len, c->L, c->T, c->meta, 0u);
+    hipLaunchKernelGGL(k_collect, dim3(nsl), dim3(LBZ_COLLECT_WG), 0, s, d_in, (u64)len, c->L, c->T, c->meta, 0u);
     if (timed_end(c, &nbev, s)) return -1;
   }
   HIPCHK(hipEventRecord(c->ev[1], s));
@@ -232,7 +232,7 @@ static int run_chunk(lbzamd_ctx *c, const u8 *d_in, size_t len, uint32_t nsl, in
       u8 *ws = c->ws + (size_t)lane * c->nslots * (c->slot_bytes + c->spill_bytes);
       u8 *wsp = ws + (size_t)c->nslots * c->slot_bytes;
       if (timed_begin(c, &nbev, 5, q)) return -1;
-      hipLaunchKernelGGL(k_collect, dim3(count), dim3(LBZ_WG), 0, q, d_in, (u64)len, c->L, c->T, c->meta, first);
+      hipLaunchKernelGGL(k_collect, dim3(count), dim3(LBZ_COLLECT_WG), 0, q, d_in, (u64)len, c->L, c->T, c->meta, first);
       if (timed_end(c, &nbev, q)) return -1;
       if (timed_begin(c, &nbev, 0, q)) return -1;
       if (count > c->ncus)

@@ -28,6 +28,9 @@
 #define LBZ_WG 1024
 #endif
 #define LBZ_NW (LBZ_WG / 64)
+#ifndef LBZ_COLLECT_WG
+#define LBZ_COLLECT_WG 512  /* k_collect's own geometry: scans and barriers, two workgroups per CU wait less on each other (-13 %) */
+#endif
 #ifndef LBZ_BWT_WG
 #define LBZ_BWT_WG 1024     /* the BWT kernel's own geometry (512 = 8 waves, two workgroups per CU, measured equal) */
 #endif
