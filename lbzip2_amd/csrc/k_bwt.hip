@@ -93,7 +93,7 @@ struct batch_lds {                      /* one batch resident in LDS */
   u32 vA[BATCH_CAP], vB[BATCH_CAP];
   u16 gh[BATCH_CAP], ghn[BATCH_CAP];    /* local row of the run's first element */
   u16 gend[BATCH_CAP];                  /* indexed by a run's first row: one past its last row */
-  u8 tied[BATCH_CAP], tiedn[BATCH_CAP];
+  u8 tied[BATCH_CAP];
   u32 wcnt[LBZ_NW][256];
   u32 dbase[256];
   u16 cstart[BATCH_CAP / 64u + 2u];     /* first row of the chunk that belongs to each claim window */
@@ -113,7 +113,7 @@ struct bwt_lds {
 
 struct bwt_slot {
   u64 *k0, *k1;
-  u32 *v0, *v1, *sufx, *grp, *pos, *sa, *isa, *gb;
+  u32 *v0, *v1, *sufx, *grp, *pos, *sa, *isa;
 };
 
 struct keycfg {
@@ -134,8 +134,7 @@ __device__ __forceinline__ bwt_slot slot_carve(u8 *ws, u32 cap)
   s.grp = (u32 *)p; p += (size_t)cap * 4u;
   s.pos = (u32 *)p; p += (size_t)cap * 4u;
   s.sa = (u32 *)p; p += (size_t)cap * 4u;
-  s.isa = (u32 *)p; p += (size_t)cap * 4u;
-  s.gb = (u32 *)p;                                   /* spare */
+  s.isa = (u32 *)p;
   return s;
 }
 

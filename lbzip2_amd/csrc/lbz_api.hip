@@ -53,7 +53,7 @@ struct lbzamd_ctx {
   /* device */
   u8 *T = nullptr, *B = nullptr, *R = nullptr, *O = nullptr, *ws = nullptr;
   u16 *V = nullptr;
-  u32 *freq = nullptr, *queue = nullptr;
+  u32 *freq = nullptr;
   u64 *offs = nullptr;
   lbz_block_meta *meta = nullptr;
   lbz_stream_state *st = nullptr;
@@ -70,7 +70,7 @@ static int ctx_free(lbzamd_ctx *c)
 {
   if (!c) return 0;
   (void)hipFree(c->T); (void)hipFree(c->B); (void)hipFree(c->R); (void)hipFree(c->O); (void)hipFree(c->ws); (void)hipFree(c->V);
-  (void)hipFree(c->freq); (void)hipFree(c->queue); (void)hipFree(c->offs); (void)hipFree(c->meta); (void)hipFree(c->st);
+  (void)hipFree(c->freq); (void)hipFree(c->offs); (void)hipFree(c->meta); (void)hipFree(c->st);
   (void)hipFree(c->d_in); (void)hipFree(c->d_out);
   for (auto &e : c->ev) if (e) (void)hipEventDestroy(e);
   for (auto &e : c->bev) if (e) (void)hipEventDestroy(e);
@@ -148,7 +148,6 @@ extern "C" int lbzamd_create(lbzamd_ctx **out, int device, unsigned bs100k, unsi
   ALLOC(c->O, outb);
   ALLOC(c->ws, (size_t)c->nstreams * nslots * (c->slot_bytes + c->spill_bytes));   /* one set of slots per stream */
   ALLOC(c->freq, nblk * 260u * sizeof(u32));
-  ALLOC(c->queue, 256);
   ALLOC(c->offs, nblk * sizeof(u64));
   ALLOC(c->meta, nblk * sizeof(lbz_block_meta));
   ALLOC(c->st, sizeof(lbz_stream_state));
@@ -206,7 +205,7 @@ static int timed_end(lbzamd_ctx *c, size_t *nbev, hipStream_t s)
   return 0;
 }
 
-static int run_chunk(lbzamd_ctx *c, const u8 *d_in, size_t len, uint32_t nsl, int upto, float ms[5])
+static int run_chunk(lbzamd_ctx *c, const u8 *d_in, size_t len, uint32_t nsl, int upto)
 {
   hipStream_t s = c->stream;
   HIPCHK(hipEventRecord(c->ev[0], s));
@@ -273,7 +272,6 @@ static int run_chunk(lbzamd_ctx *c, const u8 *d_in, size_t len, uint32_t nsl, in
   c->nbev_used = nbev;
   HIPCHK(hipEventRecord(c->ev[2], s));
   HIPCHK(hipGetLastError());
-  (void)ms;
   c->last_nslabs = nsl;
   return 0;
 }
@@ -315,7 +313,7 @@ extern "C" int lbzamd_compress_device(lbzamd_ctx *c, const void *d_in_v, size_t 
     const size_t off = done * (size_t)M;
     const size_t clen = last ? len - off : nsl * (size_t)M;
     if (nsl) {
-      if (run_chunk(c, d_in + off, clen, (uint32_t)nsl, 3, acc)) return -1;
+      if (run_chunk(c, d_in + off, clen, (uint32_t)nsl, 3)) return -1;
     } else {
       c->nbev_used = 0;
       for (int i = 0; i <= 2; i++) HIPCHK(hipEventRecord(c->ev[i], s));
@@ -403,8 +401,7 @@ extern "C" int lbzamd_run_stages(lbzamd_ctx *c, const uint8_t *in, size_t len, i
   if (nsl > c->max_slabs) { g_err = "lbzamd_run_stages: input exceeds one chunk"; return -1; }
   if (ensure_staging(c, len, 0)) return -1;
   HIPCHK(hipMemcpyAsync(c->d_in, in, len, hipMemcpyHostToDevice, c->stream));
-  float acc[6] = { 0 };
-  if (run_chunk(c, c->d_in, len, (uint32_t)nsl, upto, acc)) return -1;
+  if (run_chunk(c, c->d_in, len, (uint32_t)nsl, upto)) return -1;
   HIPCHK(hipStreamSynchronize(c->stream));
   return 0;
 }
