@@ -207,6 +207,14 @@ def test_round_schedule(lib, monkeypatch, streams, nslots, max_slabs):
             assert ctx.compress(data) == want
 
 
+def test_fuzz_vs_oracle(lib):
+    """Structured random inputs (tests/fuzz_gpu.py): tiny alphabets (oversized groups, pre-split,
+    trimmed batches), runs at the RLE1 limits, near-periodic and periodic text, word soups."""
+    import fuzz_gpu
+    assert fuzz_gpu.run(lib, L.orc_compress, 11, 150) == []
+    assert fuzz_gpu.run(lib, L.orc_compress, 12, 4, big=True) == []
+
+
 def test_device_resident_api(lib):
     import torch
     data = gen("text", 3_000_000, 8)
