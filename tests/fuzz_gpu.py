@@ -4,12 +4,14 @@ test_gpu_parity.py runs a slice of it."""
 import random, sys, time
 
 BIG = False
+SMALL = False
 
 
 def make(rng):
     kind = rng.choice(["alpha", "markov", "repeat", "runs", "mix", "periodic", "words"])
     n = rng.choice([rng.randint(1, 300), rng.randint(4000, 9000), rng.randint(20000, 120000), rng.randint(150000, 400000)])
     if BIG: n = rng.randint(900000, 2200000)
+    if SMALL: n = rng.choice([rng.randint(1, 300), rng.randint(4000, 9000)])
     if kind == "alpha":
         k = rng.choice([1, 2, 3, 4, 7, 16, 60, 64, 65, 128, 129, 200, 256])
         syms = rng.sample(range(256), k)
@@ -44,10 +46,10 @@ def make(rng):
     a, b = make(rng), make(rng)
     return (a + b)[:max(1, n)]
 
-def run(lib, oracle_compress, seed, count, big=False, save=None):
+def run(lib, oracle_compress, seed, count, big=False, save=None, small=False):
     """Returns the list of (index, length, level) of mismatching cases."""
-    global BIG
-    BIG = big
+    global BIG, SMALL
+    BIG, SMALL = big, small
     rng = random.Random(seed)
     bad = []
     for i in range(count):

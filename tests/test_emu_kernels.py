@@ -68,6 +68,12 @@ def test_round_schedule(emu, monkeypatch):
             assert ctx.compress(data) == want, (streams, nslots, max_slabs)
 
 
+def test_fuzz_slice(emu):
+    """A slice of tests/fuzz_gpu.py small enough for the emulator (blocks of <= 9000 bytes)."""
+    import fuzz_gpu
+    assert fuzz_gpu.run(emu, L.orc_compress, 21, 120, small=True) == []
+
+
 def test_workunit_interface(emu):
     data = gen("runs", 110000, 2) + gen("text", 20000, 9)
     assert emu.compress_workunits(data, 1) == L.orc_compress(data, 1)
