@@ -171,13 +171,26 @@ class Context:
             pass
 
     def compress(self, data):
+        """bytes-like -> .bz2 bytes.  No copy on the way in (the C ABI reads the object's own buffer);
+        the output buffer is kept with the context and one copy of the result is returned."""
         cap = self.L.bound(len(data))
-        out = C.create_string_buffer(cap)
+        if getattr(self, "_out_cap", 0) < cap:
+            self._out = C.create_string_buffer(cap)
+            self._out_cap = cap
         n = C.c_size_t()
-        buf = (C.c_char * len(data)).from_buffer_copy(data) if len(data) else None
-        if self.L.lib.lbzamd_compress_host(self.h, buf, len(data), out, cap, C.byref(n)):
+        if not isinstance(data, bytes):
+            try:
+                keep = (C.c_char * len(data)).from_buffer(data) if len(data) else None   # writable buffers (bytearray, numpy)
+            except TypeError:
+                data = bytes(data)                                                  # read-only views: one copy
+        if isinstance(data, bytes):
+            keep = data
+            buf = C.cast(C.c_char_p(data), C.c_void_p) if data else None      # pointer into the bytes object
+        else:
+            buf = C.cast(keep, C.c_void_p) if keep is not None else None
+        if self.L.lib.lbzamd_compress_host(self.h, buf, len(data), self._out, cap, C.byref(n)):
             raise LbzError("lbzamd_compress_host: " + self.L.error())
-        return out.raw[:n.value]
+        return C.string_at(self._out, n.value)
 
     def compress_device(self, d_in, length, d_out, out_cap):
         """d_in/d_out: integer device addresses (e.g. torch tensor .data_ptr())."""
