@@ -58,6 +58,7 @@ struct lbzamd_ctx {
   lbz_block_meta *meta = nullptr;
   lbz_stream_state *st = nullptr;
   u8 *d_in = nullptr, *d_out = nullptr;      /* staging for the host-buffer path */
+  const u8 *h2d_host = nullptr;              /* host-buffer call in progress: rounds copy their own slabs in */
   size_t d_in_cap = 0, d_out_cap = 0;
   /* host */
   std::vector<lbz_block_meta> h_meta;
@@ -230,6 +231,13 @@ static int run_chunk(lbzamd_ctx *c, const u8 *d_in, size_t len, uint32_t nsl, in
       hipStream_t q = lane ? c->side[lane - 1u] : s;
       u8 *ws = c->ws + (size_t)lane * c->nslots * (c->slot_bytes + c->spill_bytes);
       u8 *wsp = ws + (size_t)c->nslots * c->slot_bytes;
+      if (c->h2d_host) {
+        /* host-buffer path: the round's slabs come in on the round's stream, so the copy of one
+           round overlaps the kernels of the other stream's round */
+        const size_t o = (size_t)first * c->L.M;
+        const size_t nb = (size_t)count * c->L.M < len - o ? (size_t)count * c->L.M : len - o;
+        HIPCHK(hipMemcpyAsync(const_cast<u8 *>(d_in) + o, c->h2d_host + (d_in - c->d_in) + o, nb, hipMemcpyHostToDevice, q));
+      }
       if (timed_begin(c, &nbev, 5, q)) return -1;
       hipLaunchKernelGGL(k_collect, dim3(count), dim3(LBZ_COLLECT_WG), 0, q, d_in, (u64)len, c->L, c->T, c->meta, first);
       if (timed_end(c, &nbev, q)) return -1;
@@ -375,9 +383,10 @@ extern "C" int lbzamd_compress_host(lbzamd_ctx *c, const uint8_t *in, size_t len
   HIPCHK(hipSetDevice(c->device));
   const size_t bound = lbzamd_bound(len);
   if (ensure_staging(c, len ? len : 1, bound)) return -1;
-  if (len) HIPCHK(hipMemcpyAsync(c->d_in, in, len, hipMemcpyHostToDevice, c->stream));
   size_t n = 0;
+  c->h2d_host = in;                           /* run_chunk copies round by round */
   const int rc = lbzamd_compress_device(c, c->d_in, len, c->d_out, bound, &n);
+  c->h2d_host = nullptr;
   if (rc) return rc;
   if (n > out_cap) { g_err = "lbzamd_compress_host: output buffer too small"; return -2; }
   HIPCHK(hipMemcpy(out, c->d_out, n, hipMemcpyDeviceToHost));
