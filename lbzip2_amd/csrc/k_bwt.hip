@@ -1273,10 +1273,10 @@ static_assert(offsetof(part_lds, X) == offsetof(bwt_lds, u), "same layout up to 
 static_assert(sizeof(part_lds) <= 81920, "two per CU");
 
 __device__ __forceinline__ void part_block(bwt_lds &S, const u8 *Tbase, lbz_block_meta *meta, lbz_layout L, u32 first, u32 count,
-                                           u8 *ws, u64 slot_bytes, u8 *ws_spill, u64 spill_bytes)
+                                           u8 *ws, u64 slot_bytes, u8 *ws_spill, u64 spill_bytes, const u32 *slabs)
 {
   const u32 tid = threadIdx.x;
-  const u32 blk = lbz_round_block(first, count, blockIdx.x);
+  const u32 blk = lbz_round_block(first, count, blockIdx.x, slabs);
   const u32 n = meta[blk].n;
   if (n <= BATCH_CAP) return;                 /* small blocks are sorted whole by k_bwt_batch */
   const bwt_slot s = round_slot(ws, slot_bytes, ws_spill, spill_bytes, count, L);
@@ -1308,27 +1308,27 @@ __device__ __forceinline__ void part_block(bwt_lds &S, const u8 *Tbase, lbz_bloc
  * -10 % on rounds that have the blocks for it, +12 % on those that do not.                    */
 __global__ void __launch_bounds__(LBZ_WG, 4)
 k_bwt_part(const u8 *Tbase, lbz_block_meta *meta, lbz_layout L, u32 first, u32 count,
-           u8 *ws, u64 slot_bytes, u8 *ws_spill, u64 spill_bytes)
+           u8 *ws, u64 slot_bytes, u8 *ws_spill, u64 spill_bytes, const u32 *slabs)
 {
   __shared__ part_lds S_;
-  part_block(*reinterpret_cast<bwt_lds *>(&S_), Tbase, meta, L, first, count, ws, slot_bytes, ws_spill, spill_bytes);
+  part_block(*reinterpret_cast<bwt_lds *>(&S_), Tbase, meta, L, first, count, ws, slot_bytes, ws_spill, spill_bytes, slabs);
 }
 __global__ void __launch_bounds__(LBZ_WG, 8) __attribute__((amdgpu_num_sgpr(80)))
 k_bwt_part2(const u8 *Tbase, lbz_block_meta *meta, lbz_layout L, u32 first, u32 count,
-            u8 *ws, u64 slot_bytes, u8 *ws_spill, u64 spill_bytes)
+            u8 *ws, u64 slot_bytes, u8 *ws_spill, u64 spill_bytes, const u32 *slabs)
 {
   __shared__ part_lds S_;
-  part_block(*reinterpret_cast<bwt_lds *>(&S_), Tbase, meta, L, first, count, ws, slot_bytes, ws_spill, spill_bytes);
+  part_block(*reinterpret_cast<bwt_lds *>(&S_), Tbase, meta, L, first, count, ws, slot_bytes, ws_spill, spill_bytes, slabs);
 }
 
 /* ---- kernel 2: LDS batches of whole groups; emits BWT bytes + rows; flags deep ties ---- */
 __global__ void __launch_bounds__(LBZ_WG, 4)
 k_bwt_batch(const u8 *Tbase, u8 *Bbase, lbz_block_meta *meta, lbz_layout L, u32 first, u32 count,
-            u8 *ws, u64 slot_bytes, u8 *ws_spill, u64 spill_bytes)
+            u8 *ws, u64 slot_bytes, u8 *ws_spill, u64 spill_bytes, const u32 *slabs)
 {
   __shared__ bwt_lds S;
   const u32 tid = threadIdx.x;
-  const u32 blk = lbz_round_block(first, count, blockIdx.x);
+  const u32 blk = lbz_round_block(first, count, blockIdx.x, slabs);
   lbz_block_meta *M = &meta[blk];
   const u32 n = M->n;
   if (n == 0u) return;
@@ -1387,10 +1387,10 @@ k_bwt_batch(const u8 *Tbase, u8 *Bbase, lbz_block_meta *meta, lbz_layout L, u32 
 /* ---- kernel 3: blocks with ties deeper than the LDS refinements: prefix doubling ---- */
 __global__ void __launch_bounds__(LBZ_WG, 4)
 k_bwt_fix(const u8 *Tbase, u8 *Bbase, lbz_block_meta *meta, lbz_layout L, u32 first, u32 count,
-          u8 *ws, u64 slot_bytes, u8 *ws_spill, u64 spill_bytes)
+          u8 *ws, u64 slot_bytes, u8 *ws_spill, u64 spill_bytes, const u32 *slabs)
 {
   __shared__ bwt_lds S;
-  const u32 blk = lbz_round_block(first, count, blockIdx.x);
+  const u32 blk = lbz_round_block(first, count, blockIdx.x, slabs);
   lbz_block_meta *M = &meta[blk];
   const u32 n = M->n;
   if (n < 2u || M->periodic != 2u) return;

@@ -237,14 +237,15 @@ __device__ void collect_pass(const u8 *x, u32 base, u32 end, u32 cap, u8 *out, c
 }
 
 __global__ void __launch_bounds__(LBZ_WG, 4)
-k_collect(const u8 *in, u64 in_len, lbz_layout L, u8 *Tbase, lbz_block_meta *meta, u32 first)
+k_collect(const u8 *in, u64 in_len, lbz_layout L, u8 *Tbase, lbz_block_meta *meta, u32 first,
+          const u32 *slabs, const u32 *slab_len)
 {
   __shared__ collect_lds S;
   const u32 tid = threadIdx.x;
-  const u32 slab = first + blockIdx.x;
+  const u32 slab = slabs ? slabs[blockIdx.x] : first + blockIdx.x;
   const u8 *x = in + (u64)slab * L.M;
   const u64 left = in_len - (u64)slab * L.M;
-  const u32 len = left < L.M ? (u32)left : L.M;
+  const u32 len = slab_len ? slab_len[blockIdx.x] : (left < L.M ? (u32)left : L.M);   /* listed slabs carry their own length */
 
   if (tid < 256) {
     u32 c = tid << 24;

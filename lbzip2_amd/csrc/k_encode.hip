@@ -270,11 +270,11 @@ __device__ u32 flush_window(u32 *win, u32 *out32, u32 wbase, u64 endbit)
 }
 
 __global__ void __launch_bounds__(LBZ_WG)
-k_encode(const u16 *Vbase, const u32 *freq_in, u8 *Obase, lbz_block_meta *meta, lbz_layout L, u32 first, u32 count)
+k_encode(const u16 *Vbase, const u32 *freq_in, u8 *Obase, lbz_block_meta *meta, lbz_layout L, u32 first, u32 count, const u32 *slabs)
 {
   __shared__ enc_lds S;
   const u32 tid = threadIdx.x;
-  const u32 blk = lbz_round_block(first, count, blockIdx.x);
+  const u32 blk = lbz_round_block(first, count, blockIdx.x, slabs);
   lbz_block_meta *M = &meta[blk];
   if (M->n == 0u) return;
   const u16 *mtfv = Vbase + lbz_elem_off(L, blk);

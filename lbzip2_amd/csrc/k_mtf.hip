@@ -131,11 +131,11 @@ __device__ __forceinline__ void mtf_ranks(const u8 *bwt, u8 *rk, u32 lo, u32 hi,
 
 /* two workgroups per CU: the SGPR file admits 8 waves per SIMD only at <= 80 SGPRs per wave */
 __global__ void __launch_bounds__(LBZ_WG) __attribute__((amdgpu_num_sgpr(80)))
-k_mtf(const u8 *Bbase, u8 *Rbase, u16 *Vbase, u32 *freq_out, lbz_block_meta *meta, lbz_layout L, u32 first, u32 count)
+k_mtf(const u8 *Bbase, u8 *Rbase, u16 *Vbase, u32 *freq_out, lbz_block_meta *meta, lbz_layout L, u32 first, u32 count, const u32 *slabs)
 {
   __shared__ mtf_lds S;
   const u32 tid = threadIdx.x, lane = lane_id(), w = wave_id();
-  const u32 blk = lbz_round_block(first, count, blockIdx.x);
+  const u32 blk = lbz_round_block(first, count, blockIdx.x, slabs);
   lbz_block_meta *M = &meta[blk];
   const u32 n = M->n;
   if (n == 0u) return;

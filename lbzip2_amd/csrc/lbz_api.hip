@@ -15,6 +15,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <condition_variable>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -213,7 +214,7 @@ static int run_chunk(lbzamd_ctx *c, const u8 *d_in, size_t len, uint32_t nsl, in
   size_t nbev = 0;
   if (upto < 1) {
     if (timed_begin(c, &nbev, 5, s)) return -1;
-    hipLaunchKernelGGL(k_collect, dim3(nsl), dim3(LBZ_COLLECT_WG), 0, s, d_in, (u64)len, c->L, c->T, c->meta, 0u);
+    hipLaunchKernelGGL(k_collect, dim3(nsl), dim3(LBZ_COLLECT_WG), 0, s, d_in, (u64)len, c->L, c->T, c->meta, 0u, nullptr, nullptr);
     if (timed_end(c, &nbev, s)) return -1;
   }
   HIPCHK(hipEventRecord(c->ev[1], s));
@@ -239,30 +240,30 @@ static int run_chunk(lbzamd_ctx *c, const u8 *d_in, size_t len, uint32_t nsl, in
         HIPCHK(hipMemcpyAsync(const_cast<u8 *>(d_in) + o, c->h2d_host + (d_in - c->d_in) + o, nb, hipMemcpyHostToDevice, q));
       }
       if (timed_begin(c, &nbev, 5, q)) return -1;
-      hipLaunchKernelGGL(k_collect, dim3(count), dim3(LBZ_COLLECT_WG), 0, q, d_in, (u64)len, c->L, c->T, c->meta, first);
+      hipLaunchKernelGGL(k_collect, dim3(count), dim3(LBZ_COLLECT_WG), 0, q, d_in, (u64)len, c->L, c->T, c->meta, first, nullptr, nullptr);
       if (timed_end(c, &nbev, q)) return -1;
       if (timed_begin(c, &nbev, 0, q)) return -1;
       if (count > c->ncus)
         hipLaunchKernelGGL(k_bwt_part2, dim3(grid), dim3(LBZ_BWT_WG), 0, q, (const u8 *)c->T, c->meta, c->L,
-                           first, count, ws, (u64)c->slot_bytes, wsp, (u64)c->spill_bytes);
+                           first, count, ws, (u64)c->slot_bytes, wsp, (u64)c->spill_bytes, nullptr);
       else
         hipLaunchKernelGGL(k_bwt_part, dim3(grid), dim3(LBZ_BWT_WG), 0, q, (const u8 *)c->T, c->meta, c->L,
-                           first, count, ws, (u64)c->slot_bytes, wsp, (u64)c->spill_bytes);
+                           first, count, ws, (u64)c->slot_bytes, wsp, (u64)c->spill_bytes, nullptr);
       if (timed_end(c, &nbev, q) || timed_begin(c, &nbev, 1, q)) return -1;
       hipLaunchKernelGGL(k_bwt_batch, dim3(grid), dim3(LBZ_BWT_WG), 0, q, (const u8 *)c->T, c->B, c->meta, c->L,
-                         first, count, ws, (u64)c->slot_bytes, wsp, (u64)c->spill_bytes);
+                         first, count, ws, (u64)c->slot_bytes, wsp, (u64)c->spill_bytes, nullptr);
       if (timed_end(c, &nbev, q) || timed_begin(c, &nbev, 2, q)) return -1;
       hipLaunchKernelGGL(k_bwt_fix, dim3(grid), dim3(LBZ_BWT_WG), 0, q, (const u8 *)c->T, c->B, c->meta, c->L,
-                         first, count, ws, (u64)c->slot_bytes, wsp, (u64)c->spill_bytes);
+                         first, count, ws, (u64)c->slot_bytes, wsp, (u64)c->spill_bytes, nullptr);
       if (timed_end(c, &nbev, q)) return -1;
       if (upto >= 2) {
         if (timed_begin(c, &nbev, 3, q)) return -1;
-        hipLaunchKernelGGL(k_mtf, dim3(grid), dim3(LBZ_WG), 0, q, (const u8 *)c->B, c->R, c->V, c->freq, c->meta, c->L, first, count);
+        hipLaunchKernelGGL(k_mtf, dim3(grid), dim3(LBZ_WG), 0, q, (const u8 *)c->B, c->R, c->V, c->freq, c->meta, c->L, first, count, nullptr);
         if (timed_end(c, &nbev, q)) return -1;
       }
       if (upto >= 3) {
         if (timed_begin(c, &nbev, 4, q)) return -1;
-        hipLaunchKernelGGL(k_encode, dim3(grid), dim3(LBZ_WG), 0, q, (const u16 *)c->V, (const u32 *)c->freq, c->O, c->meta, c->L, first, count);
+        hipLaunchKernelGGL(k_encode, dim3(grid), dim3(LBZ_WG), 0, q, (const u16 *)c->V, (const u32 *)c->freq, c->O, c->meta, c->L, first, count, nullptr);
         if (timed_end(c, &nbev, q)) return -1;
       }
     }
@@ -453,9 +454,18 @@ extern "C" long lbzamd_read_stage(lbzamd_ctx *c, uint32_t blk, int stage, void *
 }
 
 /* ===================================================================== drop-in (A) */
-/* encoder_state as seen by the caller: an opaque blob it malloc'ed.  We keep a small header
- * in it, the raw bytes collect() consumed are uploaded at once, and the compressed block is
- * staged after the header for transmit(NULL).                                             */
+/* The reference calls collect / encode / transmit once per block, from many worker threads at
+ * once (compress.c:81-115 runs them outside the scheduler lock).  One block per launch would
+ * leave the device empty -- a kernel of one workgroup, and a handful of hardware queues for any
+ * number of streams -- so the calls of all threads are COMBINED: every state leases one slab of a
+ * shared pool context; a call posts a request and the first thread to find no leader becomes the
+ * leader, takes every request posted so far (collects and encodes alike), runs them as one round
+ * of launches over the listed slabs, publishes the block records and wakes the others.  With N
+ * worker threads a round has up to N blocks, as in the batch interface.
+ *
+ * encoder_state as seen by the caller: an opaque blob it malloc'ed.  We keep a small header in
+ * it; the compressed block is staged after the header for transmit(NULL).                   */
+struct wu_pool;
 struct encoder_state {
   uint32_t magic;
   uint32_t mbs;
@@ -463,36 +473,132 @@ struct encoder_state {
   uint32_t out_len;
   uint32_t crc;
   uint32_t collected;
-  lbzamd_ctx *ctx;            /* one-slab context leased from the pool */
-  uint32_t pad_[8];
+  wu_pool *pool;              /* set while the state holds a slab */
+  uint32_t slab;
+  uint32_t pad_[7];
 };
 #define ENC_MAGIC 0x6c627a41u
-
-static std::mutex g_pool_mu;
-static std::vector<lbzamd_ctx *> g_pool[10];
 
 [[noreturn]] static void die(const char *what)
 {
   fprintf(stderr, "lbzip2_amd: fatal: %s: %s\n", what, g_err.c_str());
   abort();
 }
+#define HIPDIE(x, what) do { hipError_t e_ = (x); if (e_ != hipSuccess) { g_err = std::string(#x) + ": " + hipGetErrorString(e_); die(what); } } while (0)
 
-static lbzamd_ctx *lease(unsigned bs100k)
+struct wu_req {
+  uint32_t slab, len;
+  const uint8_t *buf;         /* collect: the caller's bytes (it is blocked until the round is done) */
+  int stage;                  /* 0 = collect, 1 = encode */
+  bool done;
+};
+
+struct wu_pool {
+  lbzamd_ctx *c = nullptr;    /* P resident slabs, staging for P slabs of input */
+  uint32_t P = 0;
+  hipStream_t q = nullptr, copyq = nullptr;   /* non-blocking: no ties to the null stream */
+  u32 *d_list[2] = { nullptr, nullptr }, *d_len = nullptr;
+  std::mutex mu;
+  std::condition_variable cv;
+  std::vector<uint32_t> free_slabs;
+  std::vector<wu_req *> pending;
+  bool leader = false;
+  std::vector<lbz_block_meta> h_meta;         /* block records as of the last round that touched them */
+};
+
+static std::mutex g_pools_mu;
+static wu_pool *g_pools[10];
+
+static wu_pool *pool_for(unsigned bs100k)
 {
-  {
-    std::lock_guard<std::mutex> lk(g_pool_mu);
-    auto &v = g_pool[bs100k];
-    if (!v.empty()) { lbzamd_ctx *c = v.back(); v.pop_back(); return c; }
-  }
-  lbzamd_ctx *c = nullptr;
-  if (lbzamd_create(&c, -1, bs100k, 1, 2)) die("cannot create a device context");
-  return c;
+  std::lock_guard<std::mutex> lk(g_pools_mu);
+  if (g_pools[bs100k]) return g_pools[bs100k];
+  wu_pool *p = new wu_pool;
+  const char *env = getenv("LBZAMD_POOL_SLABS");
+  p->P = env ? (uint32_t)atoi(env) : 512u;
+  if (p->P < 1u) p->P = 1u;
+  if (lbzamd_create(&p->c, -1, bs100k, p->P, p->P < 256u ? p->P : 256u)) die("cannot create the work-unit pool");
+  lbzamd_ctx *c = p->c;
+  if (ensure_staging(c, (size_t)p->P * c->L.M, 0)) die("work-unit pool staging");
+  HIPDIE(hipStreamCreateWithFlags(&p->q, hipStreamNonBlocking), "pool");
+  HIPDIE(hipStreamCreateWithFlags(&p->copyq, hipStreamNonBlocking), "pool");
+  for (int i = 0; i < 2; i++) HIPDIE(hipMalloc((void **)&p->d_list[i], p->P * sizeof(u32)), "pool");
+  HIPDIE(hipMalloc((void **)&p->d_len, p->P * sizeof(u32)), "pool");
+  p->h_meta.resize(2u * (size_t)p->P);
+  for (uint32_t i = p->P; i-- > 0;) p->free_slabs.push_back(i);
+  g_pools[bs100k] = p;
+  return p;
 }
 
-static void release(lbzamd_ctx *c)
+/* One round: every posted collect, then every posted encode (a state's two calls never share a
+ * round: encode() is only posted after collect() has returned).                             */
+static void pool_round(wu_pool *p, const std::vector<wu_req *> &batch)
 {
-  std::lock_guard<std::mutex> lk(g_pool_mu);
-  g_pool[c->bs100k].push_back(c);
+  lbzamd_ctx *c = p->c;
+  HIPDIE(hipSetDevice(c->device), "work-unit round");
+  std::vector<u32> la, len, lb;
+  for (wu_req *r : batch) {
+    if (r->stage == 0) {
+      la.push_back(r->slab); len.push_back(r->len);
+      HIPDIE(hipMemcpyAsync(c->d_in + (size_t)r->slab * c->L.M, r->buf, r->len, hipMemcpyHostToDevice, p->q), "collect");
+    } else {
+      lb.push_back(r->slab);
+    }
+  }
+  if (!la.empty()) {
+    HIPDIE(hipMemcpyAsync(p->d_list[0], la.data(), la.size() * sizeof(u32), hipMemcpyHostToDevice, p->q), "collect");
+    HIPDIE(hipMemcpyAsync(p->d_len, len.data(), len.size() * sizeof(u32), hipMemcpyHostToDevice, p->q), "collect");
+    hipLaunchKernelGGL(k_collect, dim3((u32)la.size()), dim3(LBZ_COLLECT_WG), 0, p->q, (const u8 *)c->d_in,
+                       (u64)p->P * c->L.M, c->L, c->T, c->meta, 0u, (const u32 *)p->d_list[0], (const u32 *)p->d_len);
+  }
+  if (!lb.empty()) {
+    HIPDIE(hipMemcpyAsync(p->d_list[1], lb.data(), lb.size() * sizeof(u32), hipMemcpyHostToDevice, p->q), "encode");
+    u8 *ws = c->ws, *wsp = c->ws + (size_t)c->nslots * c->slot_bytes;
+    for (size_t o = 0; o < lb.size(); o += c->nslots) {
+      /* primaries only (grid = count): what collect() left over went back to the caller */
+      const u32 count = (u32)(lb.size() - o < c->nslots ? lb.size() - o : c->nslots);
+      const u32 *lst = p->d_list[1] + o;
+      if (count > c->ncus)
+        hipLaunchKernelGGL(k_bwt_part2, dim3(count), dim3(LBZ_BWT_WG), 0, p->q, (const u8 *)c->T, c->meta, c->L, 0u, count,
+                           ws, (u64)c->slot_bytes, wsp, (u64)c->spill_bytes, lst);
+      else
+        hipLaunchKernelGGL(k_bwt_part, dim3(count), dim3(LBZ_BWT_WG), 0, p->q, (const u8 *)c->T, c->meta, c->L, 0u, count,
+                           ws, (u64)c->slot_bytes, wsp, (u64)c->spill_bytes, lst);
+      hipLaunchKernelGGL(k_bwt_batch, dim3(count), dim3(LBZ_BWT_WG), 0, p->q, (const u8 *)c->T, c->B, c->meta, c->L, 0u, count,
+                         ws, (u64)c->slot_bytes, wsp, (u64)c->spill_bytes, lst);
+      hipLaunchKernelGGL(k_bwt_fix, dim3(count), dim3(LBZ_BWT_WG), 0, p->q, (const u8 *)c->T, c->B, c->meta, c->L, 0u, count,
+                         ws, (u64)c->slot_bytes, wsp, (u64)c->spill_bytes, lst);
+      hipLaunchKernelGGL(k_mtf, dim3(count), dim3(LBZ_WG), 0, p->q, (const u8 *)c->B, c->R, c->V, c->freq, c->meta, c->L, 0u, count, lst);
+      hipLaunchKernelGGL(k_encode, dim3(count), dim3(LBZ_WG), 0, p->q, (const u16 *)c->V, (const u32 *)c->freq, c->O, c->meta, c->L, 0u, count, lst);
+    }
+  }
+  /* the block records of the whole pool in one copy (a few hundred KB) */
+  HIPDIE(hipMemcpyAsync(p->h_meta.data(), c->meta, p->h_meta.size() * sizeof(lbz_block_meta), hipMemcpyDeviceToHost, p->q), "round");
+  HIPDIE(hipStreamSynchronize(p->q), "round");
+  HIPDIE(hipGetLastError(), "round");
+}
+
+/* post a request and return when it is done; whoever finds no leader leads */
+static void pool_submit(wu_pool *p, wu_req *r)
+{
+  std::unique_lock<std::mutex> lk(p->mu);
+  r->done = false;
+  p->pending.push_back(r);
+  while (!r->done) {
+    if (!p->leader) {
+      p->leader = true;
+      std::vector<wu_req *> batch;
+      batch.swap(p->pending);
+      lk.unlock();
+      pool_round(p, batch);
+      lk.lock();
+      for (wu_req *b : batch) b->done = true;
+      p->leader = false;
+      p->cv.notify_all();
+    } else {
+      p->cv.wait(lk);
+    }
+  }
 }
 
 extern "C" size_t lbzamd_encoder_alloc_size(unsigned long mbs)
@@ -513,59 +619,71 @@ extern "C" void lbzamd_encoder_init(encoder_state *e, unsigned long mbs, unsigne
 extern "C" int lbzamd_collect(encoder_state *e, const uint8_t *buf, size_t *buf_sz)
 {
   if (!e || e->magic != ENC_MAGIC || !buf || !buf_sz) { g_err = "bad encoder state"; die("collect"); }
-  if (e->ctx) { g_err = "collect() called twice on one state (only the default, non -u mode is supported)"; die("collect"); }
+  if (e->pool) { g_err = "collect() called twice on one state (only the default, non -u mode is supported)"; die("collect"); }
   const size_t avail = *buf_sz < e->mbs ? *buf_sz : e->mbs;
   if (avail == 0) return 0;
-  lbzamd_ctx *c = lease(e->mbs / 100000u);
-  e->ctx = c;
-  if (lbzamd_run_stages(c, buf, avail, 0)) die("collect");
-  lbzamd_block_info bi;
-  if (lbzamd_block_info_get(c, 0, &bi)) die("collect");
-  e->collected = bi.consumed;
-  *buf_sz -= bi.consumed;
-  return bi.consumed < avail;
+  wu_pool *p = pool_for(e->mbs / 100000u);
+  {
+    std::unique_lock<std::mutex> lk(p->mu);
+    while (p->free_slabs.empty()) p->cv.wait(lk);           /* more states in flight than the pool has slabs */
+    e->slab = p->free_slabs.back();
+    p->free_slabs.pop_back();
+  }
+  e->pool = p;
+  wu_req r = { e->slab, (uint32_t)avail, buf, 0, false };
+  pool_submit(p, &r);
+  const lbz_block_meta &m = p->h_meta[2u * e->slab];
+  e->collected = m.consumed;
+  *buf_sz -= m.consumed;
+  return m.consumed < avail;
 }
 
 extern "C" size_t lbzamd_encode(encoder_state *e, uint32_t *crc)
 {
-  if (!e || e->magic != ENC_MAGIC || !e->ctx || !crc) { g_err = "encode() before collect()"; die("encode"); }
-  lbzamd_ctx *c = e->ctx;
-  hipStream_t s = c->stream;
-  /* the slab is resident and collected; run the remaining stages on its primary block only */
-  if (hipSetDevice(c->device) != hipSuccess) die("encode");
-  hipLaunchKernelGGL(k_bwt_part, dim3(1), dim3(LBZ_BWT_WG), 0, s, (const u8 *)c->T, c->meta, c->L, 0u, 1u, c->ws, (u64)c->slot_bytes,
-                     c->ws + c->slot_bytes, (u64)c->spill_bytes);
-  hipLaunchKernelGGL(k_bwt_batch, dim3(1), dim3(LBZ_BWT_WG), 0, s, (const u8 *)c->T, c->B, c->meta, c->L, 0u, 1u, c->ws, (u64)c->slot_bytes,
-                     c->ws + c->slot_bytes, (u64)c->spill_bytes);
-  hipLaunchKernelGGL(k_bwt_fix, dim3(1), dim3(LBZ_BWT_WG), 0, s, (const u8 *)c->T, c->B, c->meta, c->L, 0u, 1u, c->ws, (u64)c->slot_bytes,
-                     c->ws + c->slot_bytes, (u64)c->spill_bytes);
-  hipLaunchKernelGGL(k_mtf, dim3(1), dim3(LBZ_WG), 0, s, (const u8 *)c->B, c->R, c->V, c->freq, c->meta, c->L, 0u, 1u);
-  hipLaunchKernelGGL(k_encode, dim3(1), dim3(LBZ_WG), 0, s, (const u16 *)c->V, (const u32 *)c->freq, c->O, c->meta, c->L, 0u, 1u);
-  if (hipStreamSynchronize(s) != hipSuccess || hipGetLastError() != hipSuccess) { g_err = "kernel failure"; die("encode"); }
-  lbzamd_block_info bi;
-  if (lbzamd_block_info_get(c, 0, &bi) || bi.err) { g_err = "device pipeline error"; die("encode"); }
-  e->out_len = bi.out_len;
-  e->crc = bi.crc;
-  *crc = bi.crc;
-  return bi.out_len;
+  if (!e || e->magic != ENC_MAGIC || !e->pool || !crc) { g_err = "encode() before collect()"; die("encode"); }
+  wu_pool *p = e->pool;
+  wu_req r = { e->slab, 0u, nullptr, 1, false };
+  pool_submit(p, &r);
+  const lbz_block_meta &m = p->h_meta[2u * e->slab];
+  if (m.err) { g_err = "device pipeline error"; die("encode"); }
+  e->out_len = m.out_len;
+  e->crc = m.crc;
+  *crc = m.crc;
+  return m.out_len;
+}
+
+static void pool_release(encoder_state *e)
+{
+  wu_pool *p = e->pool;
+  {
+    std::lock_guard<std::mutex> lk(p->mu);
+    p->free_slabs.push_back(e->slab);
+  }
+  p->cv.notify_all();
+  e->pool = nullptr;
 }
 
 extern "C" void *lbzamd_transmit(encoder_state *e, void *buf)
 {
-  if (!e || e->magic != ENC_MAGIC || !e->ctx) { g_err = "transmit() before encode()"; die("transmit"); }
-  lbzamd_ctx *c = e->ctx;
+  if (!e || e->magic != ENC_MAGIC || !e->pool) { g_err = "transmit() before encode()"; die("transmit"); }
+  wu_pool *p = e->pool;
+  lbzamd_ctx *c = p->c;
   if (!buf) buf = (void *)(e + 1);
   const size_t bytes = ((size_t)e->out_len + 3u) / 4u * 4u;          /* whole words, compress.c:220 */
-  if (hipSetDevice(c->device) != hipSuccess ||
-      hipMemcpy(buf, c->O, bytes, hipMemcpyDeviceToHost) != hipSuccess) { g_err = "D2H failed"; die("transmit"); }
-  e->ctx = nullptr;
-  release(c);
+  HIPDIE(hipSetDevice(c->device), "transmit");
+  hipEvent_t ev;                                                      /* this copy only: other threads share the stream */
+  HIPDIE(hipEventCreateWithFlags(&ev, hipEventDisableTiming), "transmit");
+  HIPDIE(hipMemcpyAsync(buf, c->O + lbz_out_off(c->L, 2u * e->slab), bytes, hipMemcpyDeviceToHost, p->copyq), "transmit");
+  HIPDIE(hipEventRecord(ev, p->copyq), "transmit");
+  HIPDIE(hipEventSynchronize(ev), "transmit");
+  (void)hipEventDestroy(ev);
+  pool_release(e);
   return buf;
 }
 
 extern "C" void lbzamd_encoder_abandon(encoder_state *e)
 {
-  if (e && e->magic == ENC_MAGIC && e->ctx) { release(e->ctx); e->ctx = nullptr; }
+  if (e && e->magic == ENC_MAGIC && e->pool) pool_release(e);
 }
 
 /* the reference's own symbol names (encode.h:29-33) */

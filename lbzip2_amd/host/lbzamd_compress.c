@@ -20,8 +20,16 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <time.h>
 
 #include "../../include/lbzip2_amd.h"
+
+static double now_s(void)
+{
+  struct timespec ts;
+  clock_gettime(CLOCK_MONOTONIC, &ts);
+  return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
+}
 
 static unsigned char *read_all(FILE *f, size_t *len)
 {
@@ -46,6 +54,10 @@ static void do_slab(struct unit *u, unsigned long mbs)
   const unsigned char *p = u->p;
   size_t left = u->len;
   struct unit *cur = u;
+  for (struct unit *m = u->more; m;) { struct unit *nx = m->more; free(m->out); free(m); m = nx; }   /* a repeated pass (-r) */
+  u->more = NULL;
+  free(u->out);
+  u->out = NULL;
   while (left > 0) {
     struct encoder_state *e = malloc(encoder_alloc_size(mbs));
     size_t before = left;
@@ -74,11 +86,13 @@ static void *worker(void *arg)
 
 int main(int argc, char **argv)
 {
-  unsigned level = 9, nworkers = 0;
+  unsigned level = 9, nworkers = 0, timing = 0, repeat = 1;
   for (int i = 1; i < argc; i++) {
+    if (!strcmp(argv[i], "-t")) { timing = 1; continue; }            /* phase times on stderr */
+    if (!strcmp(argv[i], "-r") && i + 1 < argc) { repeat = (unsigned)atoi(argv[++i]); continue; }   /* run the codec phase N times */
     if (argv[i][0] == '-' && argv[i][1] >= '1' && argv[i][1] <= '9' && !argv[i][2]) level = argv[i][1] - '0';
     else if (!strcmp(argv[i], "-w") && i + 1 < argc) nworkers = (unsigned)atoi(argv[++i]);
-    else { fprintf(stderr, "usage: %s [-1..-9] [-w N] < in > out.bz2\n", argv[0]); return 2; }
+    else { fprintf(stderr, "usage: %s [-1..-9] [-w N] [-t] [-r N] < in > out.bz2\n", argv[0]); return 2; }
   }
   size_t len;
   unsigned char *in = read_all(stdin, &len);
@@ -88,10 +102,17 @@ int main(int argc, char **argv)
     lbzamd_ctx *ctx;
     size_t nslabs = (len + mbs - 1) / mbs, cap = lbzamd_bound(len), n = 0;
     unsigned char *out = malloc(cap);
-    if (lbzamd_create(&ctx, -1, level, nslabs ? (unsigned)(nslabs > 1200 ? 1200 : nslabs) : 1, 0) ||
-        lbzamd_compress_host(ctx, in, len, out, cap, &n)) {
+    double t0 = now_s();
+    if (lbzamd_create(&ctx, -1, level, nslabs ? (unsigned)(nslabs > 1200 ? 1200 : nslabs) : 1, 0)) {
       fprintf(stderr, "lbzamd: %s\n", lbzamd_last_error());
       return 1;
+    }
+    double t1 = now_s();
+    for (unsigned r = 0; r < repeat; r++) {
+      if (lbzamd_compress_host(ctx, in, len, out, cap, &n)) { fprintf(stderr, "lbzamd: %s\n", lbzamd_last_error()); return 1; }
+      const double t2 = now_s();
+      if (timing) fprintf(stderr, "batch interface: context %.3f s, pass %u: %.3f s = %.0f MB/s\n", t1 - t0, r, t2 - t1, (double)len / (t2 - t1) / 1e6);
+      t1 = t2;
     }
     fwrite(out, 1, n, stdout);
     lbzamd_destroy(ctx);
@@ -107,8 +128,14 @@ int main(int argc, char **argv)
       j.units[i].len = (i + 1) * mbs <= len ? mbs : len - i * mbs;
     }
     pthread_t *th = malloc(nworkers * sizeof *th);
-    for (unsigned t = 0; t < nworkers; t++) pthread_create(&th[t], NULL, worker, &j);
-    for (unsigned t = 0; t < nworkers; t++) pthread_join(th[t], NULL);
+    for (unsigned r = 0; r < repeat; r++) {
+      const double t0 = now_s();
+      j.next = 0;
+      for (unsigned t = 0; t < nworkers; t++) pthread_create(&th[t], NULL, worker, &j);
+      for (unsigned t = 0; t < nworkers; t++) pthread_join(th[t], NULL);
+      const double t1 = now_s();
+      if (timing) fprintf(stderr, "work-unit interface, %u threads, pass %u: %.3f s = %.0f MB/s\n", nworkers, r, t1 - t0, (double)len / (t1 - t0) / 1e6);
+    }
     /* in-order mux, compress.c:238-250 */
     unsigned char hdr[HEADER_SIZE] = { 'B', 'Z', 'h', (unsigned char)('0' + level) };
     uint32_t cc = 0;

@@ -186,6 +186,8 @@ static inline hipError_t hipGetLastError() { return hipSuccess; }
 static inline hipError_t hipPeekAtLastError() { return hipSuccess; }
 static inline const char *hipGetErrorString(hipError_t e) { return e == hipSuccess ? "hipSuccess" : "hipError(emu)"; }
 #define hipStreamNonBlocking 1
+#define hipEventDisableTiming 2
+static inline hipError_t hipEventCreateWithFlags(hipEvent_t *e, unsigned) { return hipEventCreate(e); }
 #define hipHostMallocDefault 0
 
 #endif
