@@ -496,8 +496,9 @@ struct wu_req {
 struct wu_pool {
   lbzamd_ctx *c = nullptr;    /* P resident slabs, staging for P slabs of input */
   uint32_t P = 0;
-  hipStream_t q = nullptr, copyq = nullptr;   /* non-blocking: no ties to the null stream */
+  hipStream_t q = nullptr;    /* non-blocking: no ties to the null stream */
   u32 *d_list[2] = { nullptr, nullptr }, *d_len = nullptr;
+  u8 *h_in = nullptr, *h_out = nullptr;   /* pinned staging, one slab each: callers fill / drain it in parallel, the leader's copies are pure DMA */
   std::mutex mu;
   std::condition_variable cv;
   std::vector<uint32_t> free_slabs;
@@ -521,9 +522,10 @@ static wu_pool *pool_for(unsigned bs100k)
   lbzamd_ctx *c = p->c;
   if (ensure_staging(c, (size_t)p->P * c->L.M, 0)) die("work-unit pool staging");
   HIPDIE(hipStreamCreateWithFlags(&p->q, hipStreamNonBlocking), "pool");
-  HIPDIE(hipStreamCreateWithFlags(&p->copyq, hipStreamNonBlocking), "pool");
   for (int i = 0; i < 2; i++) HIPDIE(hipMalloc((void **)&p->d_list[i], p->P * sizeof(u32)), "pool");
   HIPDIE(hipMalloc((void **)&p->d_len, p->P * sizeof(u32)), "pool");
+  HIPDIE(hipHostMalloc((void **)&p->h_in, (size_t)p->P * c->L.M, hipHostMallocDefault), "pool");
+  HIPDIE(hipHostMalloc((void **)&p->h_out, (size_t)p->P * c->L.out_a, hipHostMallocDefault), "pool");
   p->h_meta.resize(2u * (size_t)p->P);
   for (uint32_t i = p->P; i-- > 0;) p->free_slabs.push_back(i);
   g_pools[bs100k] = p;
@@ -540,7 +542,7 @@ static void pool_round(wu_pool *p, const std::vector<wu_req *> &batch)
   for (wu_req *r : batch) {
     if (r->stage == 0) {
       la.push_back(r->slab); len.push_back(r->len);
-      HIPDIE(hipMemcpyAsync(c->d_in + (size_t)r->slab * c->L.M, r->buf, r->len, hipMemcpyHostToDevice, p->q), "collect");
+      HIPDIE(hipMemcpyAsync(c->d_in + (size_t)r->slab * c->L.M, p->h_in + (size_t)r->slab * c->L.M, r->len, hipMemcpyHostToDevice, p->q), "collect");
     } else {
       lb.push_back(r->slab);
     }
@@ -576,6 +578,14 @@ static void pool_round(wu_pool *p, const std::vector<wu_req *> &batch)
   HIPDIE(hipMemcpyAsync(p->h_meta.data(), c->meta, p->h_meta.size() * sizeof(lbz_block_meta), hipMemcpyDeviceToHost, p->q), "round");
   HIPDIE(hipStreamSynchronize(p->q), "round");
   HIPDIE(hipGetLastError(), "round");
+  if (!lb.empty()) {
+    /* the packed blocks, now that their sizes are known: DMA into the pinned staging area */
+    for (u32 sl : lb) {
+      const size_t bytes = ((size_t)p->h_meta[2u * sl].out_len + 3u) / 4u * 4u;
+      HIPDIE(hipMemcpyAsync(p->h_out + (size_t)sl * c->L.out_a, c->O + lbz_out_off(c->L, 2u * sl), bytes, hipMemcpyDeviceToHost, p->q), "round");
+    }
+    HIPDIE(hipStreamSynchronize(p->q), "round");
+  }
 }
 
 /* post a request and return when it is done; whoever finds no leader leads */
@@ -630,6 +640,7 @@ extern "C" int lbzamd_collect(encoder_state *e, const uint8_t *buf, size_t *buf_
     p->free_slabs.pop_back();
   }
   e->pool = p;
+  memcpy(p->h_in + (size_t)e->slab * p->c->L.M, buf, avail);            /* in the caller's thread */
   wu_req r = { e->slab, (uint32_t)avail, buf, 0, false };
   pool_submit(p, &r);
   const lbz_block_meta &m = p->h_meta[2u * e->slab];
@@ -670,13 +681,7 @@ extern "C" void *lbzamd_transmit(encoder_state *e, void *buf)
   lbzamd_ctx *c = p->c;
   if (!buf) buf = (void *)(e + 1);
   const size_t bytes = ((size_t)e->out_len + 3u) / 4u * 4u;          /* whole words, compress.c:220 */
-  HIPDIE(hipSetDevice(c->device), "transmit");
-  hipEvent_t ev;                                                      /* this copy only: other threads share the stream */
-  HIPDIE(hipEventCreateWithFlags(&ev, hipEventDisableTiming), "transmit");
-  HIPDIE(hipMemcpyAsync(buf, c->O + lbz_out_off(c->L, 2u * e->slab), bytes, hipMemcpyDeviceToHost, p->copyq), "transmit");
-  HIPDIE(hipEventRecord(ev, p->copyq), "transmit");
-  HIPDIE(hipEventSynchronize(ev), "transmit");
-  (void)hipEventDestroy(ev);
+  memcpy(buf, p->h_out + (size_t)e->slab * c->L.out_a, bytes);          /* staged by the round that encoded it */
   pool_release(e);
   return buf;
 }
