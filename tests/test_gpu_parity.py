@@ -154,6 +154,18 @@ def test_workunit_interface_threads(lib):
         assert o == L.orc_compress(d, 5)
 
 
+def test_workunit_pool_smaller_than_threads(lib, monkeypatch):
+    """More caller threads than the shared pool has slabs: states wait for a slab, rounds stay
+    small, nothing deadlocks (the pool of a block size is created once per process: -2 is used
+    by no other test, so the environment still applies)."""
+    monkeypatch.setenv("LBZAMD_POOL_SLABS", "3")
+    datas = [gen("text", 150000 + 7000 * i, 200 + i) + gen("runs", 90000, i) for i in range(12)]
+    with ThreadPoolExecutor(12) as ex:
+        outs = list(ex.map(lambda d: lib.compress_workunits(d, 2), datas))
+    for d, o in zip(datas, outs):
+        assert o == L.orc_compress(d, 2)
+
+
 def test_c_host_driver(lib, tmp_path):
     """The C program that drives the work-unit interface from pthreads the way compress.c does
     (lbzip2_amd/host/lbzamd_compress.c), and its batch mode."""
