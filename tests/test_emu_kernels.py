@@ -79,6 +79,18 @@ def test_workunit_interface(emu):
     assert emu.compress_workunits(data, 1) == L.orc_compress(data, 1)
 
 
+def test_workunit_interface_threads(emu, monkeypatch):
+    """The combining of work-unit requests across caller threads (lbz_api.hip, pool_submit): more
+    threads than pool slabs, so states also wait for slabs."""
+    from concurrent.futures import ThreadPoolExecutor
+    monkeypatch.setenv("LBZAMD_POOL_SLABS", "2")
+    datas = [gen("text", 30000 + 3000 * i, 40 + i) + gen("runs", 20000, i) for i in range(5)]
+    with ThreadPoolExecutor(5) as ex:
+        outs = list(ex.map(lambda d: emu.compress_workunits(d, 2), datas))      # -2: a pool no other test has created
+    for d, o in zip(datas, outs):
+        assert o == L.orc_compress(d, 2)
+
+
 def test_reference_suite_sample(emu):
     """A slice of the reference's own compress corpora (small members only: emulation is slow)."""
     inputs = suite_inputs()
