@@ -597,8 +597,19 @@ static void pool_submit(wu_pool *p, wu_req *r)
   while (!r->done) {
     if (!p->leader) {
       p->leader = true;
+      /* Collects first, on their own: they are short, and every caller whose collect returns
+         posts its encode right away -- so by the time no collect is waiting, the encode round
+         (which costs the same for one block as for a few hundred) has filled up.           */
       std::vector<wu_req *> batch;
-      batch.swap(p->pending);
+      bool any_collect = false;
+      for (wu_req *x : p->pending) any_collect |= x->stage == 0;
+      if (any_collect) {
+        std::vector<wu_req *> rest;
+        for (wu_req *x : p->pending) (x->stage == 0 ? batch : rest).push_back(x);
+        p->pending.swap(rest);
+      } else {
+        batch.swap(p->pending);
+      }
       lk.unlock();
       pool_round(p, batch);
       lk.lock();
