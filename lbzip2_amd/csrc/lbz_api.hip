@@ -125,6 +125,9 @@ extern "C" int lbzamd_create(lbzamd_ctx **out, int device, unsigned bs100k, unsi
       nslots = (unsigned)atoi(env);
     } else {
       nslots = (max_slabs + c->nstreams - 1u) / c->nstreams;
+      /* two streams: a slightly uneven deal (54 : 46, the shorter round is issued first and has
+         the device to itself for a moment) measured 1 % faster than an even one */
+      if (c->nstreams == 2u) nslots = (max_slabs * 27u + 49u) / 50u;
       if (nslots < cus) nslots = cus;
       size_t free_b = 0, total_b = 0;
       if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
