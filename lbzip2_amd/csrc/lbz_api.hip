@@ -494,6 +494,7 @@ struct wu_req {
   const uint8_t *buf;         /* collect: the caller's bytes (it is blocked until the round is done) */
   int stage;                  /* 0 = collect, 1 = encode */
   bool done;
+  uint32_t consumed, out_len, crc, err;       /* the block record as of the round that served the request */
 };
 
 struct wu_pool {
@@ -616,7 +617,12 @@ static void pool_submit(wu_pool *p, wu_req *r)
       lk.unlock();
       pool_round(p, batch);
       lk.lock();
-      for (wu_req *b : batch) b->done = true;
+      for (wu_req *b : batch) {
+        /* taken here, under the lock: the next round's copy of the records may already be under way */
+        const lbz_block_meta &m = p->h_meta[2u * b->slab];
+        b->consumed = m.consumed; b->out_len = m.out_len; b->crc = m.crc; b->err = m.err;
+        b->done = true;
+      }
       p->leader = false;
       p->cv.notify_all();
     } else {
@@ -655,26 +661,24 @@ extern "C" int lbzamd_collect(encoder_state *e, const uint8_t *buf, size_t *buf_
   }
   e->pool = p;
   memcpy(p->h_in + (size_t)e->slab * p->c->L.M, buf, avail);            /* in the caller's thread */
-  wu_req r = { e->slab, (uint32_t)avail, buf, 0, false };
+  wu_req r = { e->slab, (uint32_t)avail, buf, 0, false, 0u, 0u, 0u, 0u };
   pool_submit(p, &r);
-  const lbz_block_meta &m = p->h_meta[2u * e->slab];
-  e->collected = m.consumed;
-  *buf_sz -= m.consumed;
-  return m.consumed < avail;
+  e->collected = r.consumed;
+  *buf_sz -= r.consumed;
+  return r.consumed < avail;
 }
 
 extern "C" size_t lbzamd_encode(encoder_state *e, uint32_t *crc)
 {
   if (!e || e->magic != ENC_MAGIC || !e->pool || !crc) { g_err = "encode() before collect()"; die("encode"); }
   wu_pool *p = e->pool;
-  wu_req r = { e->slab, 0u, nullptr, 1, false };
+  wu_req r = { e->slab, 0u, nullptr, 1, false, 0u, 0u, 0u, 0u };
   pool_submit(p, &r);
-  const lbz_block_meta &m = p->h_meta[2u * e->slab];
-  if (m.err) { g_err = "device pipeline error"; die("encode"); }
-  e->out_len = m.out_len;
-  e->crc = m.crc;
-  *crc = m.crc;
-  return m.out_len;
+  if (r.err) { g_err = "device pipeline error"; die("encode"); }
+  e->out_len = r.out_len;
+  e->crc = r.crc;
+  *crc = r.crc;
+  return r.out_len;
 }
 
 static void pool_release(encoder_state *e)
