@@ -216,7 +216,7 @@ def main():
         achieved = per_kernel[dom]["achieved_GBps"]
         pipe_alg = st.n_in + 13.0 * st.n_rle + 20.0 * st.n_mtf + st.n_out  # SURVEY 8(d), per step
         res = {
-            "metric": "compress MB/s (whole node), enwik9-style text -9", "value": round(total_in * args.steps / elapsed / 1e6, 1),
+            "metric": "compress MB/s (whole node) + ratio, enwik9 -9, at 1/2/4/8 MI355X", "value": round(total_in * args.steps / elapsed / 1e6, 1),
             "unit": "MB/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 2), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic" if "synthetic" in source else "enwik9",
