@@ -99,6 +99,23 @@ const char *lbzamd_last_error(void);
  * Work is enqueued on the context's stream and waited for.  0 on success.              */
 int  lbzamd_compress_device(lbzamd_ctx *ctx, const void *d_in, size_t len,
                             void *d_out, size_t out_cap, size_t *out_len);
+/* Multi-GPU shards: the blocks of a slab-aligned range only (no "BZh9", no trailer), plus the
+ * range's block count and CRC fold from zero.  A muxer splices ranges in order into ONE stream that
+ * is byte-identical to the single-device (and the reference's) stream: header (compress.c:291-302),
+ * bodies in range order (compress.c:238-250), trailer with lbzamd_fold_parts() (compress.c:304-321,
+ * combine_crc encode.h:38 -- the fold is GF(2)-linear, so 12 bytes per range suffice).        */
+typedef struct lbzamd_part {
+  uint64_t bytes;       /* body bytes written */
+  uint32_t nblocks;     /* blocks in the range */
+  uint32_t crc_fold;    /* combine_crc over the range's blocks, started from 0 */
+} lbzamd_part;
+int  lbzamd_compress_device_body(lbzamd_ctx *ctx, const void *d_in, size_t len,
+                                 void *d_out, size_t out_cap, size_t *out_len, lbzamd_part *part);
+int  lbzamd_compress_host_body(lbzamd_ctx *ctx, const uint8_t *in, size_t len,
+                               uint8_t *out, size_t out_cap, size_t *out_len, lbzamd_part *part);
+/* cc after appending the ranges parts[0..nparts) to a stream whose combined CRC so far is cc:
+ * cc = rotl32(cc, nblocks mod 32) ^ crc_fold, range by range. */
+uint32_t lbzamd_fold_parts(uint32_t cc, const lbzamd_part *parts, size_t nparts);
 /* Same with host buffers (H2D + compress + D2H). */
 int  lbzamd_compress_host(lbzamd_ctx *ctx, const uint8_t *in, size_t len,
                           uint8_t *out, size_t out_cap, size_t *out_len);

@@ -13,8 +13,8 @@ lbzip2_amd/csrc/liblbzamd.so (built by hipcc for gfx950) and has no CPU implemen
 import os
 
 from ._binding import (CLUSTER_FACTOR, HEADER_SIZE, TRAILER_SIZE, STAGE_BWT, STAGE_MTFV, STAGE_OUT,
-                       STAGE_RLE, BlockInfo, Context, Encoder, EXPORTS, LbzError, Library, Stats,
-                       combine_crc)
+                       STAGE_RLE, BlockInfo, Context, Encoder, EXPORTS, LbzError, Library, Part, Stats,
+                       combine_crc, fold_parts)
 
 LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", "liblbzamd.so")
 _lib = None

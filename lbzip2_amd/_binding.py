@@ -21,6 +21,7 @@ EXPORTS = [
     "lbzamd_create", "lbzamd_destroy", "lbzamd_last_error", "lbzamd_compress_device",
     "lbzamd_compress_host", "lbzamd_bound", "lbzamd_get_stats", "lbzamd_stream", "lbzamd_slots",
     "lbzamd_block_slots", "lbzamd_block_info_get", "lbzamd_read_stage", "lbzamd_run_stages",
+    "lbzamd_compress_device_body", "lbzamd_compress_host_body", "lbzamd_fold_parts",
 ]
 
 
@@ -36,6 +37,19 @@ class Stats(C.Structure):
                 ("ms_collect", C.c_float), ("ms_bwt", C.c_float), ("ms_mtf", C.c_float),
                 ("ms_encode", C.c_float), ("ms_finish", C.c_float), ("ms_total", C.c_float),
                 ("ms_bwt_part", C.c_float), ("ms_bwt_batch", C.c_float), ("ms_bwt_fix", C.c_float)]
+
+
+class Part(C.Structure):
+    """lbzamd_part: what the muxer of a multi-GPU job needs from a range (include/lbzip2_amd.h)."""
+    _fields_ = [("bytes", C.c_uint64), ("nblocks", C.c_uint32), ("crc_fold", C.c_uint32)]
+
+
+def fold_parts(cc, parts):
+    """cc = rotl32(cc, nblocks mod 32) ^ crc_fold, range by range (parts: (nblocks, crc_fold) pairs)."""
+    for nblocks, fold in parts:
+        r = nblocks & 31
+        cc = (((cc << r) | (cc >> (32 - r))) & 0xFFFFFFFF if r else cc) ^ fold
+    return cc
 
 
 class BlockInfo(C.Structure):
@@ -85,6 +99,12 @@ class Library:
         lib.lbzamd_compress_device.restype = C.c_int
         lib.lbzamd_compress_host.argtypes = [vp, vp, sz, vp, sz, szp]
         lib.lbzamd_compress_host.restype = C.c_int
+        lib.lbzamd_compress_device_body.argtypes = [vp, vp, sz, vp, sz, szp, C.POINTER(Part)]
+        lib.lbzamd_compress_device_body.restype = C.c_int
+        lib.lbzamd_compress_host_body.argtypes = [vp, vp, sz, vp, sz, szp, C.POINTER(Part)]
+        lib.lbzamd_compress_host_body.restype = C.c_int
+        lib.lbzamd_fold_parts.argtypes = [C.c_uint32, C.POINTER(Part), sz]
+        lib.lbzamd_fold_parts.restype = C.c_uint32
         lib.lbzamd_bound.argtypes = [sz]
         lib.lbzamd_bound.restype = sz
         lib.lbzamd_get_stats.argtypes = [vp, C.POINTER(Stats)]
@@ -169,6 +189,26 @@ class Context:
             self.close()
         except Exception:
             pass
+
+    def compress_body(self, data):
+        """bytes-like -> (body bytes, nblocks, crc_fold): the blocks of the range only, for a muxer."""
+        cap = self.L.bound(len(data))
+        out = C.create_string_buffer(cap)
+        n = C.c_size_t()
+        part = Part()
+        buf = (C.c_char * len(data)).from_buffer_copy(bytes(data)) if len(data) else None
+        if self.L.lib.lbzamd_compress_host_body(self.h, buf, len(data), out, cap, C.byref(n), C.byref(part)):
+            raise LbzError("lbzamd_compress_host_body: " + self.L.error())
+        return out.raw[:n.value], part.nblocks, part.crc_fold
+
+    def compress_device_body(self, d_in, length, d_out, out_cap):
+        """Device-resident range -> (bytes written, nblocks, crc_fold)."""
+        n = C.c_size_t()
+        part = Part()
+        if self.L.lib.lbzamd_compress_device_body(self.h, C.c_void_p(d_in), length, C.c_void_p(d_out),
+                                                  out_cap, C.byref(n), C.byref(part)):
+            raise LbzError("lbzamd_compress_device_body: " + self.L.error())
+        return n.value, part.nblocks, part.crc_fold
 
     def compress(self, data):
         """bytes-like -> .bz2 bytes.  No copy on the way in (the C ABI reads the object's own buffer);

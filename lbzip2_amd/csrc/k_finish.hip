@@ -16,7 +16,7 @@
  * prefix-summed by the whole workgroup (tiles of LBZ_WG blocks); the CRC fold, which is order
  * dependent (rotate, then xor), runs on one lane over values staged in LDS.               */
 __global__ void __launch_bounds__(LBZ_WG)
-k_offsets(const lbz_block_meta *meta, u32 nblk, u32 bs100k, u32 first, u32 last,
+k_offsets(const lbz_block_meta *meta, u32 nblk, u32 bs100k, u32 first, u32 last, u32 body,
           u64 *offs, lbz_stream_state *st, u8 *out, u64 out_cap)
 {
   __shared__ wg_scratch sc;
@@ -24,7 +24,7 @@ k_offsets(const lbz_block_meta *meta, u32 nblk, u32 bs100k, u32 first, u32 last,
   __shared__ u32 live[LBZ_WG];
   __shared__ u32 fold;
   const u32 tid = threadIdx.x;
-  u64 pos = first ? 4ull : st->pos;
+  u64 pos = first ? (body ? 0ull : 4ull) : st->pos;     /* body: blocks only, no header/trailer (multi-GPU shards) */
   u32 nb = 0, nper = 0, err = 0;
   u64 nrle = 0, nmtf = 0, nsort = 0;
   if (tid == 0) fold = first ? 0u : st->crc;
@@ -60,7 +60,7 @@ k_offsets(const lbz_block_meta *meta, u32 nblk, u32 bs100k, u32 first, u32 last,
   if (tid != 0) return;
   if (first) {
     st->nblocks = 0; st->n_rle = 0; st->n_mtf = 0; st->sort_elems = 0; st->nperiodic = 0; st->err = 0;
-    if (out_cap >= 4) { out[0] = 'B'; out[1] = 'Z'; out[2] = 'h'; out[3] = (u8)('0' + bs100k); }
+    if (!body && out_cap >= 4) { out[0] = 'B'; out[1] = 'Z'; out[2] = 'h'; out[3] = (u8)('0' + bs100k); }
   }
   st->nblocks += tnb; st->nperiodic += tper;
   st->n_rle += ((u64)rle_hi << 20) + rle_lo;
@@ -68,8 +68,8 @@ k_offsets(const lbz_block_meta *meta, u32 nblk, u32 bs100k, u32 first, u32 last,
   st->sort_elems += ((u64)srt_hi << 20) + srt_lo;
   if (terr) st->err = terr;
   const u32 cc = fold;
-  if (pos + (last ? 10u : 0u) > out_cap) { st->err = 100u; st->pos = pos; st->crc = cc; return; }
-  if (last) {
+  if (pos + ((last && !body) ? 10u : 0u) > out_cap) { st->err = 100u; st->pos = pos; st->crc = cc; return; }
+  if (last && !body) {
     const u8 tr[6] = { 0x17, 0x72, 0x45, 0x38, 0x50, 0x90 };
     for (u32 i = 0; i < 6; i++) out[pos + i] = tr[i];
     out[pos + 6] = (u8)(cc >> 24); out[pos + 7] = (u8)(cc >> 16);

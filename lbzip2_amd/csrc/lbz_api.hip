@@ -304,8 +304,28 @@ static int add_times(lbzamd_ctx *c, float *acc)
   return 0;
 }
 
+static int compress_device(lbzamd_ctx *c, const void *d_in_v, size_t len, void *d_out_v, size_t out_cap,
+                           size_t *out_len, bool body, lbzamd_part *part);
+
 extern "C" int lbzamd_compress_device(lbzamd_ctx *c, const void *d_in_v, size_t len,
                                       void *d_out_v, size_t out_cap, size_t *out_len)
+{
+  return compress_device(c, d_in_v, len, d_out_v, out_cap, out_len, false, nullptr);
+}
+
+/* The blocks of a slab range only -- no stream header, no trailer -- plus what the muxer of a
+ * multi-GPU job needs to splice the ranges into ONE stream (compress.c:238-250, :291-321): the
+ * number of blocks and the CRC fold of the range started from zero.  The fold cc' = rotl(cc,1) ^ ~c
+ * (encode.h:38) is linear over GF(2): after a range of m blocks, cc = rotl(cc_before, m mod 32) ^ fold. */
+extern "C" int lbzamd_compress_device_body(lbzamd_ctx *c, const void *d_in_v, size_t len,
+                                           void *d_out_v, size_t out_cap, size_t *out_len, lbzamd_part *part)
+{
+  if (!part) { g_err = "lbzamd_compress_device_body: bad argument"; return -1; }
+  return compress_device(c, d_in_v, len, d_out_v, out_cap, out_len, true, part);
+}
+
+static int compress_device(lbzamd_ctx *c, const void *d_in_v, size_t len, void *d_out_v, size_t out_cap,
+                           size_t *out_len, bool body, lbzamd_part *part)
 {
   if (!c || !d_out_v || !out_len || (len && !d_in_v)) { g_err = "lbzamd_compress_device: bad argument"; return -1; }
   HIPCHK(hipSetDevice(c->device));
@@ -331,7 +351,7 @@ extern "C" int lbzamd_compress_device(lbzamd_ctx *c, const void *d_in_v, size_t 
       for (int i = 0; i <= 2; i++) HIPCHK(hipEventRecord(c->ev[i], s));
     }
     hipLaunchKernelGGL(k_offsets, dim3(1), dim3(LBZ_WG), 0, s, (const lbz_block_meta *)c->meta, (u32)(2u * nsl),
-                       (u32)c->bs100k, (u32)first, (u32)last, c->offs, c->st, d_out, (u64)out_cap);
+                       (u32)c->bs100k, (u32)first, (u32)last, (u32)body, c->offs, c->st, d_out, (u64)out_cap);
     if (nsl)
       hipLaunchKernelGGL(k_gather, dim3((u32)(2u * nsl)), dim3(LBZ_WG), 0, s, (const u8 *)c->O,
                          (const lbz_block_meta *)c->meta, c->L, (const u64 *)c->offs,
@@ -362,7 +382,17 @@ extern "C" int lbzamd_compress_device(lbzamd_ctx *c, const void *d_in_v, size_t 
     return -2;
   }
   *out_len = (size_t)st.pos;
+  if (part) { part->nblocks = st.nblocks; part->crc_fold = st.crc; part->bytes = st.pos; }
   return 0;
+}
+
+extern "C" uint32_t lbzamd_fold_parts(uint32_t cc, const lbzamd_part *parts, size_t nparts)
+{
+  for (size_t i = 0; i < nparts; i++) {
+    const uint32_t r = parts[i].nblocks & 31u;
+    cc = (r ? ((cc << r) | (cc >> (32u - r))) : cc) ^ parts[i].crc_fold;
+  }
+  return cc;
 }
 
 static int ensure_staging(lbzamd_ctx *c, size_t in_bytes, size_t out_bytes)
@@ -380,8 +410,21 @@ static int ensure_staging(lbzamd_ctx *c, size_t in_bytes, size_t out_bytes)
   return 0;
 }
 
+static int compress_host(lbzamd_ctx *c, const uint8_t *in, size_t len, uint8_t *out, size_t out_cap, size_t *out_len,
+                         bool body, lbzamd_part *part);
 extern "C" int lbzamd_compress_host(lbzamd_ctx *c, const uint8_t *in, size_t len,
                                     uint8_t *out, size_t out_cap, size_t *out_len)
+{
+  return compress_host(c, in, len, out, out_cap, out_len, false, nullptr);
+}
+extern "C" int lbzamd_compress_host_body(lbzamd_ctx *c, const uint8_t *in, size_t len,
+                                         uint8_t *out, size_t out_cap, size_t *out_len, lbzamd_part *part)
+{
+  if (!part) { g_err = "lbzamd_compress_host_body: bad argument"; return -1; }
+  return compress_host(c, in, len, out, out_cap, out_len, true, part);
+}
+static int compress_host(lbzamd_ctx *c, const uint8_t *in, size_t len, uint8_t *out, size_t out_cap, size_t *out_len,
+                         bool body, lbzamd_part *part)
 {
   if (!c || !out || !out_len || (len && !in)) { g_err = "lbzamd_compress_host: bad argument"; return -1; }
   HIPCHK(hipSetDevice(c->device));
@@ -389,7 +432,7 @@ extern "C" int lbzamd_compress_host(lbzamd_ctx *c, const uint8_t *in, size_t len
   if (ensure_staging(c, len ? len : 1, bound)) return -1;
   size_t n = 0;
   c->h2d_host = in;                           /* run_chunk copies round by round */
-  const int rc = lbzamd_compress_device(c, c->d_in, len, c->d_out, bound, &n);
+  const int rc = compress_device(c, c->d_in, len, c->d_out, bound, &n, body, part);
   c->h2d_host = nullptr;
   if (rc) return rc;
   if (n > out_cap) { g_err = "lbzamd_compress_host: output buffer too small"; return -2; }

@@ -33,7 +33,7 @@ __global__ void k_bwt_fix(const u8 *Tbase, u8 *Bbase, lbz_block_meta *meta, lbz_
                           u32 count, u8 *ws, u64 slot_bytes, u8 *ws_spill, u64 spill_bytes, const u32 *slabs);
 __global__ void k_mtf(const u8 *Bbase, u8 *Rbase, u16 *Vbase, u32 *freq_out, lbz_block_meta *meta, lbz_layout L, u32 first, u32 count, const u32 *slabs);
 __global__ void k_encode(const u16 *Vbase, const u32 *freq_in, u8 *Obase, lbz_block_meta *meta, lbz_layout L, u32 first, u32 count, const u32 *slabs);
-__global__ void k_offsets(const lbz_block_meta *meta, u32 nblk, u32 bs100k, u32 first, u32 last,
+__global__ void k_offsets(const lbz_block_meta *meta, u32 nblk, u32 bs100k, u32 first, u32 last, u32 body,
                           u64 *offs, lbz_stream_state *st, u8 *out, u64 out_cap);
 __global__ void k_gather(const u8 *Obase, const lbz_block_meta *meta, lbz_layout L, const u64 *offs,
                          const lbz_stream_state *st, u8 *out, u32 nslabs);

@@ -650,3 +650,44 @@ orc_gen_text(uint8_t *out, size_t n, uint32_t seed)
     if (o < n) out[o++] = (xs32(&x) % 16 == 0) ? '\n' : ' ';
   }
 }
+
+/* ------------------------------------------------------------------------- */
+/* pthreads driver on the restatement (cpu_mt.h): bench.py's cpu_baseline "port" */
+/* ------------------------------------------------------------------------- */
+struct orc_mt_state { uint8_t *block; uint16_t *mtfv; orc_block_t *b; };
+static struct orc_mt_state *orc_mt_new(size_t mbs)
+{
+  struct orc_mt_state *s = malloc(sizeof *s);
+  s->block = malloc(mbs);
+  s->mtfv = malloc((mbs + 1 + ORC_GROUP) * sizeof *s->mtfv);
+  s->b = malloc(sizeof *s->b);
+  return s;
+}
+static void orc_mt_free(struct orc_mt_state *s) { free(s->block); free(s->mtfv); free(s->b); free(s); }
+typedef struct { uint32_t out_len, crc, bwt_idx, copies, slab, pad_; } cpu_mt_blk;
+#define CPU_MT_BLK_DEFINED
+static size_t orc_mt_slab(struct orc_mt_state *s, const uint8_t *in, size_t len, size_t mbs, uint8_t *out,
+                          cpu_mt_blk *blk, unsigned *nblk)
+{
+  size_t o = 0, left = len;
+  const uint8_t *p = in;
+  unsigned nb = 0;
+  while (left > 0) {
+    orc_collect_t c;
+    orc_collect(p, left, (uint32_t)mbs, s->block, &c);
+    p += c.consumed; left -= c.consumed;
+    orc_encode_block(s->block, &c, 8, s->mtfv, s->b);
+    orc_transmit(s->b, s->mtfv, out + o);
+    o += s->b->out_len;
+    if (nb < 2) { blk[nb].out_len = s->b->out_len; blk[nb].crc = c.crc; blk[nb].bwt_idx = s->b->bwt_idx; blk[nb].copies = orc_is_periodic(s->block, (int32_t)c.nblock) ? 2u : 1u; }
+    nb++;
+  }
+  *nblk = nb;
+  return o;
+}
+#define CPU_MT_NAME orc_compress_mt
+#define CPU_MT_WORKER_STATE struct orc_mt_state
+#define cpu_mt_state_new orc_mt_new
+#define cpu_mt_state_free orc_mt_free
+#define cpu_mt_slab orc_mt_slab
+#include "cpu_mt.h"

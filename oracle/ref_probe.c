@@ -92,3 +92,75 @@ ref_bwt(const uint8_t *T, int32_t n, uint8_t *out)
   free(t); free(SA); free(bucket);
   return idx;
 }
+
+/* ---- pthreads driver on the reference encoder (cpu_mt.h): fixtures + bench.py's cpu_baseline ---- */
+struct ref_mt_state { struct encoder_state *e; uint32_t *buf; };
+static struct ref_mt_state *ref_mt_new(size_t mbs)
+{
+  struct ref_mt_state *s = malloc(sizeof *s);
+  s->e = malloc(encoder_alloc_size(mbs));             /* one reusable encoder per thread */
+  s->buf = malloc(((mbs + mbs / 4 + 65536) + 3) / 4 * 4);
+  return s;
+}
+static void ref_mt_free(struct ref_mt_state *s) { free(s->e); free(s->buf); free(s); }
+#ifndef CPU_MT_BLK_DEFINED
+#define CPU_MT_BLK_DEFINED
+typedef struct { uint32_t out_len, crc, bwt_idx, copies, slab, pad_; } cpu_mt_blk;
+#endif
+/* k such that T[0..n) = u^k with |u| minimal (1 if T is not a repetition): failure function */
+static uint32_t block_copies(const uint8_t *T, uint32_t n)
+{
+  if (n < 2) return 1;
+  uint32_t *f = malloc((size_t)n * sizeof *f), k = 0, r;
+  f[0] = 0;
+  for (uint32_t i = 1; i < n; i++) {
+    while (k && T[i] != T[k]) k = f[k - 1];
+    if (T[i] == T[k]) k++;
+    f[i] = k;
+  }
+  r = n - f[n - 1];
+  free(f);
+  return (n % r == 0) ? n / r : 1;
+}
+/* ref_canon != 0: the origin pointer of an exactly periodic block (k equal rows per rotation class,
+ * classes start at multiples of k) is rewritten to the smallest equal row -- the documented
+ * convention of this repository; every other bit is the reference's. */
+int ref_canon = 0;
+static size_t ref_mt_slab(struct ref_mt_state *s, const uint8_t *in, size_t len, size_t mbs, uint8_t *out,
+                          cpu_mt_blk *blk, unsigned *nblk)
+{
+  size_t o = 0, left = len;
+  const uint8_t *p = in;
+  unsigned nb = 0;
+  while (left > 0) {                                  /* compress.c:93-104: leftovers are the slab's next block */
+    uint32_t crc;
+    size_t before = left, size;
+    encoder_init(s->e, mbs, CLUSTER_FACTOR);
+    collect(s->e, p, &left);
+    p += before - left;
+    size = encode(s->e, &crc);
+    const uint32_t copies = block_copies(ref_block(s->e), s->e->nblock);
+    transmit(s->e, s->buf);
+    memcpy(out + o, s->buf, size);
+    if (copies > 1 && ref_canon) {
+      /* bits 81..104 of the block (encode.c:1185-1193: 48 magic, 32 crc, 1 randomised, 24 origin) */
+      uint8_t *q = out + o + 10;
+      uint32_t w = ((uint32_t)q[0] << 24) | ((uint32_t)q[1] << 16) | ((uint32_t)q[2] << 8) | q[3];
+      uint32_t idx = (w >> 7) & 0xFFFFFFu;
+      idx -= idx % copies;
+      w = (w & ~(0xFFFFFFu << 7)) | (idx << 7);
+      q[0] = (uint8_t)(w >> 24); q[1] = (uint8_t)(w >> 16); q[2] = (uint8_t)(w >> 8); q[3] = (uint8_t)w;
+    }
+    o += size;
+    if (nb < 2) { blk[nb].out_len = (uint32_t)size; blk[nb].crc = crc; blk[nb].bwt_idx = s->e->bwt_idx; blk[nb].copies = copies; }
+    nb++;
+  }
+  *nblk = nb;
+  return o;
+}
+#define CPU_MT_NAME ref_compress_mt
+#define CPU_MT_WORKER_STATE struct ref_mt_state
+#define cpu_mt_state_new ref_mt_new
+#define cpu_mt_state_free ref_mt_free
+#define cpu_mt_slab ref_mt_slab
+#include "cpu_mt.h"

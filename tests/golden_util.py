@@ -53,7 +53,14 @@ def gen(kind, n, seed):
             else:
                 out += pool[(k >> 4) % len(pool)] + b"\n"
         return bytes(out[:n])
+    if kind in ("wiki", "mixed", "tar"):          # lbzip2_amd/host/gen_inputs.c: the BASELINE.json stand-ins
+        return L.gen_kind(kind, n, seed)
     raise ValueError(kind)
+
+
+def bench_fixtures(max_n=None, min_n=0):
+    """Records of tests/golden/bench_fixtures.json (reference streams of the BASELINE configs)."""
+    return [r for r in load("bench_fixtures.json") if (max_n is None or r["n"] <= max_n) and r["n"] >= min_n]
 
 
 _suite_cache = None

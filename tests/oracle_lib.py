@@ -136,6 +136,67 @@ def ref_compress(data: bytes, level: int = 9) -> bytes:
     return out.raw[:n]
 
 
+class MtBlk(C.Structure):
+    _fields_ = [("out_len", C.c_uint32), ("crc", C.c_uint32), ("bwt_idx", C.c_uint32), ("copies", C.c_uint32), ("slab", C.c_uint32), ("pad_", C.c_uint32)]
+
+
+def _compress_mt(fn, data, level, nthreads):
+    """The pthreads driver of oracle/cpu_mt.h: (stream bytes, [(out_len, crc)], seconds)."""
+    M = level * 100000
+    n = len(data)
+    cap = _cap(n) + (n // M + 2) * 64
+    out = C.create_string_buffer(cap)
+    blocks = (MtBlk * (2 * (n // M + 2)))()
+    nb = C.c_uint32()
+    sec = C.c_double()
+    if isinstance(data, (bytes, bytearray)) and not isinstance(data, bytes):
+        src = (C.c_char * n).from_buffer(data)
+    else:
+        src = data
+    fn.argtypes = [C.c_void_p if not isinstance(src, bytes) else C.c_char_p, C.c_size_t, C.c_uint, C.c_void_p, C.c_size_t,
+                   C.c_uint, C.c_void_p, C.POINTER(C.c_uint32), C.POINTER(C.c_double)]
+    fn.restype = C.c_size_t
+    m = fn(src, n, level, out, cap, nthreads, blocks, C.byref(nb), C.byref(sec))
+    assert m > 0
+    return out.raw[:m], [(blocks[i].out_len, blocks[i].crc, blocks[i].bwt_idx, blocks[i].copies, blocks[i].slab) for i in range(nb.value)], sec.value
+
+
+def ref_compress_mt(data, level=9, nthreads=1, canon=False):
+    """canon: origin pointers of exactly periodic blocks rewritten to the smallest equal row."""
+    C.c_int.in_dll(ref(), "ref_canon").value = 1 if canon else 0
+    try:
+        return _compress_mt(ref().ref_compress_mt, data, level, nthreads)
+    finally:
+        C.c_int.in_dll(ref(), "ref_canon").value = 0
+
+
+def orc_compress_mt(data, level=9, nthreads=1):
+    return _compress_mt(oracle().orc_compress_mt, data, level, nthreads)
+
+
+_gen = None
+
+
+def gen_kind(kind, n, seed):
+    """Workload generators of lbzip2_amd/host/gen_inputs.c (plain C, built with gcc): wiki, mixed, tar, text, rand."""
+    global _gen
+    if _gen is None:
+        path = os.path.join(ROOT, "lbzip2_amd", "host", "libgen_inputs.so")
+        if not os.path.exists(path):
+            subprocess.check_call(["gcc", "-O2", "-fPIC", "-shared", "-o", path,
+                                   os.path.join(ROOT, "lbzip2_amd", "host", "gen_inputs.c")])
+        _gen = C.CDLL(path)
+    buf = bytearray(n)
+    if n:
+        cb = (C.c_uint8 * n).from_buffer(buf)
+        f = getattr(_gen, "lbzgen_" + kind)
+        f.argtypes = [C.c_void_p, C.c_size_t, C.c_uint32]
+        f.restype = None
+        f(cb, n, seed)
+        del cb
+    return buf
+
+
 def gen_rand(n, seed):
     b = C.create_string_buffer(n)
     oracle().orc_gen_rand(b, n, seed)

@@ -19,17 +19,18 @@ def pysrc(n):
 def gen(kind, n, seed):
     if kind == "pysrc": return pysrc(n)
     buf = bytearray(n); cb = (C.c_uint8 * n).from_buffer(buf)
-    f = g.lbzgen_text if kind == "text" else g.lbzgen_rand
+    f = getattr(g, "lbzgen_" + kind)
     f.argtypes = [C.c_void_p, C.c_size_t, C.c_uint32]; f(cb, n, seed); del cb
     return buf
 slabs = int(sys.argv[1]) if len(sys.argv) > 1 else 512
+LEVEL = int(os.environ.get("LBZ_LEVEL", "9"))
 for kind in (sys.argv[2].split(",") if len(sys.argv) > 2 else ("text", "rand")):
-    n = slabs * 900000
-    data = gen(kind, n, 2)
+    n = slabs * LEVEL * 100000
+    data = gen(kind, n, int(os.environ.get('LBZ_SEED', '2')))
     src = torch.frombuffer(data, dtype=torch.uint8).cuda()
     dst = torch.empty(lib.bound(n), dtype=torch.uint8, device="cuda")
     for slots in ([int(x) for x in os.environ.get('LBZ_SLOTS', '256').split(',')]):
-        ctx = lib.context(9, slabs, slots)
+        ctx = lib.context(LEVEL, slabs, slots)
         for it in range(2):
             t = time.time()
             m = ctx.compress_device(src.data_ptr(), n, dst.data_ptr(), dst.numel())
