@@ -5,79 +5,129 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 One "step" = one pass of the hot path (RLE1+CRC -> BWT -> MTF/ZRLE -> prefix codes -> bit
-packing -> stream assembly) over the workload, input already resident in HBM, the complete
-.bz2 stream left in HBM.  Workload (BASELINE.json configs[1]): enwik9-sized text, 10^9 bytes,
-level -9, per GPU; the real enwik9 is used if $LBZ_ENWIK9 points at it, else the seeded
-stand-in text(10^9, seed 2+rank) of SURVEY.md 8d.  With N GPUs every rank compresses its own
-10^9-byte shard into its own complete stream (independent slabs, no data-path collective;
-concatenated streams are a valid .bz2 file) -> weak scaling; value = all ranks' input bytes
-over the max-over-ranks time.
+packing -> stream assembly) over the workload, input already resident in HBM, the .bz2 bytes
+left in HBM.  Workload (BASELINE.json configs[1]): enwik9-sized text, 10^9 bytes, level -9, per
+GPU.  The real enwik9 is used if $LBZ_ENWIK9 points at it; otherwise the seeded ENWIK-LIKE
+stand-in `wiki(10^9, seed 2+rank)` of lbzip2_amd/host/gen_inputs.c: XML page wrappers, wiki markup,
+Zipf words and phrases, UTF-8 interwiki text (191 distinct bytes -> 8-bit sort symbols) and verbatim
+passage repeats (deep ties) -- the profile of real English text (tied rows by depth within a few
+points of a GNU-manual corpus, bzip2 ratio 4.3 vs enwik9's 3.9).  `--kind text` is round 1's
+28-letter word soup (kept as a second workload: it is the sorter's best case).
 
-Prints ONE JSON line on rank 0.  Extra objects:
+--scaling weak (default)   every rank compresses its own 10^9-byte input into its own stream.
+--scaling strong           ONE 10^9-byte input, slab ranges dealt over the ranks, bodies gathered
+                           to rank 0 into ONE stream that is byte-identical to the single-GPU
+                           (and the reference's) stream (lbzip2_amd/shard.py, RCCL send/recv).
+
+After the timed region the stream is copied to the host, hashed and compared with the fixture
+generated from the compiled reference (tests/golden/bench_fixtures.json): "verified": true/false,
+null if no fixture exists for the workload.  Nothing in the timed region touches the host.
+
+Extra objects in the JSON line:
   roofline      the kernel with the largest share of device time, timed live in the timed region
-                (HIP events on the stream each launch goes to; rounds of blocks run on two streams
-                and their launches overlap, so per-launch time includes sharing the device).
-                roofline.isolated repeats the per-kernel table from one extra untimed pass on a
-                single stream (nothing overlaps).  SURVEY 8(d) prices the path at
-                N_in + 13 N_rle + 20 N_mtf + N_out algorithmic bytes; per kernel that is
-                collect N_in+N_rle | bwt_part 5 N_rle | bwt_batch 6 N_rle | mtf N_rle+2 N_mtf |
-                encode 18 N_mtf+N_out.  achieved = bytes per launch / mean launch time from HIP
-                events recorded on the library's own stream; peak 8000 GB/s (MI355X HBM3E)
-  cpu_baseline  reference lbzip2's block codec (oracle/_ref, "reference") or the bit-exact
-                restatement (oracle/, "port") on the box's host cores over a bounded sample
+                with HIP events on the stream each launch goes to.  SURVEY 8(d) prices the path at
+                N_in + 13 N_rle + 20 N_mtf + N_out algorithmic bytes; per kernel:
+                collect N_in+N_rle | bwt_part 5 N_rle | bwt_batch+fix 6 N_rle | mtf N_rle+2 N_mtf |
+                encode 18 N_mtf+N_out.  peak 8000 GB/s (MI355X HBM3E).  roofline.isolated: the same
+                table from one extra untimed single-stream pass (no overlap between rounds).
+  value_host    host buffer in -> .bz2 bytes in host memory (pinned, PCIe-inclusive), same input.
+  cpu_baseline  reference lbzip2's block codec (oracle/_ref: "reference") or the restatement
+                (oracle/: "port") on the box's host cores through the pthreads driver of
+                oracle/cpu_mt.h, over a bounded sample of the same workload.
 """
 import argparse
 import ctypes as C
+import hashlib
 import json
 import os
 import sys
 import time
-from concurrent.futures import ThreadPoolExecutor
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8 TB/s HBM3E
+KINDS = ["wiki", "text", "rand", "mixed", "tar"]
+KERNELS = ["k_collect", "k_bwt_part", "k_bwt_batch", "k_bwt_fix", "k_mtf", "k_encode"]
 
 
 def gen_input(kind, n, seed):
     g = C.CDLL(os.path.join(ROOT, "lbzip2_amd", "host", "libgen_inputs.so"))
     buf = bytearray(n)
     cbuf = (C.c_uint8 * n).from_buffer(buf)
-    fn = g.lbzgen_text if kind == "text" else g.lbzgen_rand
+    fn = getattr(g, "lbzgen_" + kind)
     fn.argtypes = [C.c_void_p, C.c_size_t, C.c_uint32]
+    fn.restype = None
     fn(cbuf, n, seed)
     del cbuf
     return buf
 
 
-def cpu_baseline(data, level, seconds_budget=1.0):
-    """Time the CPU codec on all host cores over a bounded sample of the same workload
-    (at most seconds_budget seconds of wall time at the single-thread rate, i.e. ~cores x that of CPU work)."""
+def usable_cpus():
+    """CPUs this process may run on, and the cgroup CPU quota if there is one."""
+    try:
+        aff = len(os.sched_getaffinity(0))
+    except AttributeError:
+        aff = os.cpu_count() or 1
+    quota = None
+    for p in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            t = open(p).read().split()
+            if p.endswith("cpu.max"):
+                quota = None if t[0] == "max" else float(t[0]) / float(t[1])
+            else:
+                q = float(t[0])
+                quota = None if q <= 0 else q / float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            break
+        except (OSError, ValueError, IndexError):
+            continue
+    return aff, quota
+
+
+def cpu_baseline(data, level, seconds_budget=12.0):
+    """The CPU codec on the host cores through the C/pthreads driver (one reusable encoder per thread,
+    slabs handed out from a shared counter, in-order mux), on a bounded sample of the same workload:
+    1, 16, 64 and all usable threads, each at least two slabs per thread."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_lib as L   # test infrastructure: only used here as the timed CPU baseline
     kind = "reference" if L.have_ref() else "port"
-    fn = L.ref_compress if kind == "reference" else L.orc_compress
+    fn = L.ref_compress_mt if kind == "reference" else L.orc_compress_mt
     M = level * 100000
-    cores = os.cpu_count() or 1
-    # single thread: ~20 MB/s -> 3 slabs ~ 0.15 s; probe the rate first
-    t0 = time.perf_counter()
-    fn(bytes(data[:3 * M]), level)
-    t1 = time.perf_counter() - t0
-    rate1 = 3 * M / t1
-    # every host core gets the same number of whole slabs; the sample is bounded by the budget of CPU seconds
+    aff, quota = usable_cpus()
     nslabs = max(1, len(data) // M)
-    nthreads = min(cores, nslabs)
-    per_thread = max(1, min(nslabs // nthreads, int(seconds_budget * cores * rate1 / M / nthreads)))
-    pieces = [bytes(data[i * per_thread * M:(i + 1) * per_thread * M]) for i in range(nthreads)]
-    with ThreadPoolExecutor(nthreads) as ex:
-        t0 = time.perf_counter()
-        list(ex.map(lambda p: fn(p, level), pieces))     # ctypes releases the GIL
-        t = time.perf_counter() - t0
-    total = sum(len(p) for p in pieces)
-    return {"value": round(total / t / 1e6, 2), "unit": "MB/s", "cores": nthreads, "kind": kind,
-            "sample": f"{nthreads} threads x {per_thread} slabs of {M} B ({total} B) of the same workload, level -{level}",
-            "single_thread_MBps": round(rate1 / 1e6, 2), "host_cpus": cores}
+    t1 = min(fn(data[:min(3, nslabs) * M], level, 1)[2] for _ in range(2))
+    rate1 = min(3, nslabs) * M / t1
+    table = {"1": round(rate1 / 1e6, 2)}
+    best, best_nt, best_sample = rate1, 1, min(3, nslabs) * M
+    for nt in sorted({min(16, aff), min(64, aff), aff}):
+        if nt <= 1:
+            continue
+        # ~seconds_budget/3 seconds of wall time per point at perfect scaling, >= 2 slabs per thread
+        per = max(2, int(seconds_budget / 3 * rate1 / M))
+        ns = min(nslabs, nt * per)
+        t = min(fn(data[:ns * M], level, nt)[2] for _ in range(2))     # best of two: the first call warms pages and threads
+        r = ns * M / t
+        table[str(nt)] = round(r / 1e6, 2)
+        if r > best:
+            best, best_nt, best_sample = r, nt, ns * M
+    note = None
+    if best < 0.5 * rate1 * best_nt:
+        note = ("throughput does not scale with threads: the lease's CPU quota"
+                + (f" (cgroup cpu.max = {quota:.1f} CPUs)" if quota else " or shared cores") + " caps it")
+    return {"value": round(best / 1e6, 2), "unit": "MB/s", "cores": best_nt, "kind": kind,
+            "sample": f"{best_sample} B ({best_sample // M} slabs of {M} B) of the same workload, level -{level}, "
+                      f"{best_nt} pthreads over oracle/cpu_mt.h",
+            "MBps_by_threads": table, "usable_cpus": aff, "cgroup_cpu_quota": quota, "note": note}
+
+
+def find_fixture(kind, n, seed, level):
+    try:
+        for r in json.load(open(os.path.join(ROOT, "tests", "golden", "bench_fixtures.json"))):
+            if (r["kind"], r["n"], r["seed"], r["level"]) == (kind, n, seed, level):
+                return r
+    except (OSError, ValueError):
+        pass
+    return None
 
 
 def main():
@@ -85,12 +135,15 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--bytes", type=int, default=1_000_000_000, help="input bytes per GPU")
+    ap.add_argument("--bytes", type=int, default=1_000_000_000, help="input bytes per GPU (weak) or in all (strong)")
     ap.add_argument("--level", type=int, default=9)
-    ap.add_argument("--kind", default="text", choices=["text", "rand"])
+    ap.add_argument("--kind", default="wiki", choices=KINDS)
+    ap.add_argument("--seed", type=int, default=2)
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"])
     ap.add_argument("--slabs", type=int, default=0, help="resident slabs per chunk (0 = all)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
-    ap.add_argument("--verify", action="store_true", help="decode the stream with Python's bz2 (untimed)")
+    ap.add_argument("--no-verify", action="store_true", help="skip the untimed md5 check against the reference fixture")
+    ap.add_argument("--no-host", action="store_true", help="skip the host-to-host leg (value_host)")
     ap.add_argument("--no-isolated", action="store_true", help="skip the extra single-stream pass (profiling runs)")
     args = ap.parse_args()
 
@@ -107,26 +160,38 @@ def main():
         dist.init_process_group("nccl", device_id=torch.device("cuda", local))
 
     import lbzip2_amd
+    from lbzip2_amd import shard
     lib = lbzip2_amd.library()
 
-    n = args.bytes
     M = args.level * 100000
+    strong = args.scaling == "strong"
+    seed = args.seed if strong else args.seed + rank
     path = os.environ.get("LBZ_ENWIK9")
-    if path and os.path.exists(path) and args.kind == "text":
-        data = bytearray(open(path, "rb").read()[:n])
-        source = "enwik9 file"
+    if path and os.path.exists(path) and args.kind == "wiki":
+        full = bytearray(open(path, "rb").read()[:args.bytes])
+        source, fixture = "enwik9 file", None
     else:
-        data = gen_input(args.kind, n, 2 + rank)
-        source = f"synthetic {args.kind}({n}, seed {2 + rank})"
+        full = gen_input(args.kind, args.bytes, seed)
+        source = f"synthetic {args.kind}({args.bytes}, seed {seed})"
+        fixture = find_fixture(args.kind, args.bytes, seed, args.level)
+    if strong:
+        off, ln = shard.shard_plan(len(full), world, args.level)[rank]
+        data = full[off:off + ln]
+    else:
+        data = full
     n = len(data)
-    nslabs = (n + M - 1) // M
+    nslabs = max(1, (n + M - 1) // M)
     slabs = args.slabs or nslabs
 
-    src = torch.frombuffer(data, dtype=torch.uint8).cuda()
+    src = torch.frombuffer(data, dtype=torch.uint8).cuda() if n else torch.empty(0, dtype=torch.uint8, device="cuda")
     dst = torch.empty(lib.bound(n), dtype=torch.uint8, device="cuda")
     ctx = lib.context(args.level, slabs, 0, local)
+    mux = shard.StreamMux(dist if world > 1 else None, args.level, lib.bound(len(full)), "cuda") if strong else None
 
     def step():
+        if strong:
+            m, nb, fold = ctx.compress_device_body(src.data_ptr(), n, dst.data_ptr(), dst.numel())
+            return mux.gather(dst, m, nb, fold)        # rank 0: length of the single stream (in mux.out)
         return ctx.compress_device(src.data_ptr(), n, dst.data_ptr(), dst.numel())
 
     def barrier():
@@ -140,8 +205,7 @@ def main():
         out_len = step()
     barrier()
     t0 = time.perf_counter()
-    kms = {"k_collect": 0.0, "k_bwt_part": 0.0, "k_bwt_batch": 0.0, "k_bwt_fix": 0.0, "k_mtf": 0.0,
-           "k_encode": 0.0, "finish": 0.0}
+    kms = {k: 0.0 for k in KERNELS + ["finish"]}
     tot_ms = 0.0
     st = None
     for _ in range(args.steps):
@@ -158,88 +222,132 @@ def main():
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-        o = torch.tensor([out_len, n], dtype=torch.int64, device="cuda")
+        o = torch.tensor([0 if strong and rank else out_len, n], dtype=torch.int64, device="cuda")
         dist.all_reduce(o)
         total_out, total_in = int(o[0].item()), int(o[1].item())
     else:
         total_out, total_in = out_len, n
 
-    if args.verify:
-        import bz2
-        assert bz2.decompress(bytes(dst[:out_len].cpu().numpy())) == bytes(data)
+    # ---- untimed: is the stream the reference's? ----
+    verified, verified_against = None, None
+    if not args.no_verify and (rank == 0 or not strong):
+        stream = (mux.out if strong else dst)[:out_len].cpu().numpy().tobytes() if (rank == 0 or not strong) else b""
+        ok = None
+        if fixture is not None:
+            ok = len(stream) == fixture["out_len"] and hashlib.md5(stream).hexdigest() == fixture["canon_md5"]
+            verified_against = (f"tests/golden/bench_fixtures.json {args.kind}({args.bytes}, seed {seed}) -{args.level}: "
+                                f"reference stream md5 {fixture['canon_md5']}, {fixture['out_len']} B")
+        elif len(full) <= 300_000_000:
+            import bz2
+            ok = bz2.decompress(stream) == bytes(full)
+            verified_against = "round trip through Python's bz2 (no reference fixture for this workload)"
+        verified = ok
+    if world > 1 and not strong:
+        v = torch.tensor([1 if verified else 0, 1 if verified is None else 0], dtype=torch.int64, device="cuda")
+        dist.all_reduce(v)
+        verified = None if int(v[1].item()) == world else int(v[0].item()) + int(v[1].item()) == world
 
+    # ---- untimed extras on rank 0 ----
     iso = None
+    value_host = None
     if rank == 0 and not args.no_isolated:
-        # the same per-kernel figures with nothing overlapped: one untimed pass, one stream
         os.environ["LBZAMD_STREAMS"] = "1"
         try:
             with lib.context(args.level, slabs, 0, local) as c1:
-                c1.compress_device(src.data_ptr(), n, dst.data_ptr(), dst.numel())
-                c1.compress_device(src.data_ptr(), n, dst.data_ptr(), dst.numel())
+                for _ in range(2):
+                    c1.compress_device(src.data_ptr(), n, dst.data_ptr(), dst.numel())
                 s1 = c1.stats()
-                iso = {"slots": c1.nslots, "ms": {"k_collect": s1.ms_collect, "k_bwt_part": s1.ms_bwt_part, "k_bwt_batch": s1.ms_bwt_batch,
-                                                  "k_mtf": s1.ms_mtf, "k_encode": s1.ms_encode}, "ms_total": s1.ms_total}
+                iso = {"slots": c1.nslots, "ms_total": s1.ms_total,
+                       "ms": {"k_collect": s1.ms_collect, "k_bwt_part": s1.ms_bwt_part, "k_bwt_batch": s1.ms_bwt_batch,
+                              "k_bwt_fix": s1.ms_bwt_fix, "k_mtf": s1.ms_mtf, "k_encode": s1.ms_encode}}
         finally:
             del os.environ["LBZAMD_STREAMS"]
+    if rank == 0 and not args.no_host and world == 1:
+        hin = torch.frombuffer(data, dtype=torch.uint8).pin_memory()
+        hout = torch.empty(lib.bound(n), dtype=torch.uint8).pin_memory()
+        best = None
+        for _ in range(3):
+            th = time.perf_counter()
+            m = ctx.compress_host_ptr(hin.data_ptr(), n, hout.data_ptr(), hout.numel())
+            dt = time.perf_counter() - th
+            best = dt if best is None or dt < best else best
+        ok = m == out_len and bytes(hout[:64].numpy()) == dst[:64].cpu().numpy().tobytes()
+        value_host = {"value": round(n / best / 1e6, 1), "unit": "MB/s", "ms": round(best * 1e3, 2), "same_stream": bool(ok),
+                      "what": "pinned host buffer in -> .bz2 bytes in pinned host memory: per-round H2D and D2H overlapped with the kernels of the other stream's round"}
+
     if rank == 0:
         nchunks = (nslabs + slabs - 1) // slabs
         nslots = ctx.nslots
-        rounds = sum(-(-min(slabs, nslabs - i * slabs) // nslots) for i in range(nchunks))   # rounds (launches of every per-round kernel) per step
-        alg = {"k_collect": st.n_in + st.n_rle, "k_bwt_part": 5.0 * st.n_rle, "k_bwt_batch": 6.0 * st.n_rle,
+        rounds = sum(-(-min(slabs, nslabs - i * slabs) // nslots) for i in range(nchunks))
+        alg = {"k_collect": st.n_in + st.n_rle, "k_bwt_part": 5.0 * st.n_rle, "k_bwt_batch": 6.0 * st.n_rle, "k_bwt_fix": 6.0 * st.n_rle,
                "k_mtf": st.n_rle + 2.0 * st.n_mtf, "k_encode": 18.0 * st.n_mtf + st.n_out}     # bytes per step
-        nlaunch = {"k_collect": nchunks, "k_bwt_part": rounds, "k_bwt_batch": rounds, "k_mtf": rounds, "k_encode": rounds}
-        per_kernel = {k: {"ms_per_step": round(kms[k] / args.steps, 3), "launches_per_step": nlaunch[k],
+        # k_bwt_batch and k_bwt_fix share the 6 N_rle of "read rows, gather the preceding byte, write BWT": priced on their sum
+        kms_sort = dict(kms)
+        kms_sort["k_bwt_batch"] = kms["k_bwt_batch"] + kms["k_bwt_fix"]
+        names = ["k_collect", "k_bwt_part", "k_bwt_batch", "k_mtf", "k_encode"]
+        per_kernel = {k: {"ms_per_step": round(kms_sort[k] / args.steps, 3), "launches_per_step": rounds,
                           "alg_GB_per_step": round(alg[k] / 1e9, 3),
-                          "achieved_GBps": round(alg[k] * args.steps / (kms[k] * 1e-3) / 1e9, 2) if kms[k] > 0 else 0.0}
-                      for k in alg}
+                          "achieved_GBps": round(alg[k] * args.steps / (kms_sort[k] * 1e-3) / 1e9, 2) if kms_sort[k] > 0 else 0.0}
+                      for k in names}
+        per_kernel["k_bwt_batch"]["includes"] = "k_bwt_fix (deep ties): %.3f ms per step" % (kms["k_bwt_fix"] / args.steps)
+        iso_tab = None
         if iso:
+            im = dict(iso["ms"])
+            im["k_bwt_batch"] += im.pop("k_bwt_fix")
             iso_rounds = sum(-(-min(slabs, nslabs - i * slabs) // iso["slots"]) for i in range(nchunks))
-            iso_nl = {"k_collect": nchunks, "k_bwt_part": iso_rounds, "k_bwt_batch": iso_rounds, "k_mtf": iso_rounds, "k_encode": iso_rounds}
-            iso_tab = {k: {"ms_per_step": round(iso["ms"][k], 3), "launches_per_step": iso_nl[k],
-                           "achieved_GBps": round(alg[k] / (iso["ms"][k] * 1e-3) / 1e9, 2) if iso["ms"][k] > 0 else 0.0,
-                           "frac": round(alg[k] / (iso["ms"][k] * 1e-3) / 1e9 / HBM_PEAK_GBS, 5) if iso["ms"][k] > 0 else 0.0}
-                       for k in alg}
-        dom = max(alg, key=lambda k: kms[k])
-        launches = nlaunch[dom] * args.steps
+            iso_tab = {k: {"ms_per_step": round(im[k], 3), "launches_per_step": iso_rounds,
+                           "achieved_GBps": round(alg[k] / (im[k] * 1e-3) / 1e9, 2) if im[k] > 0 else 0.0,
+                           "frac": round(alg[k] / (im[k] * 1e-3) / 1e9 / HBM_PEAK_GBS, 5) if im[k] > 0 else 0.0}
+                       for k in names}
+        dom = max(names, key=lambda k: kms_sort[k])
+        launches = rounds * args.steps
         # HBM traffic of the dominant kernel from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE /
-        # WRITE_SIZE, separate runs; profiles/pmc_traffic.json holds KB per slab of the same workload).
+        # WRITE_SIZE, separate runs of this command; profiles/pmc_traffic.json holds KB per slab).
         # FETCH_SIZE is doubled (gfx950 tallies wide reads at half, MI355X_MICROARCH.md, HBM).
         traffic = None
         try:
             pt = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
-            if pt.get("workload") == f"{args.kind} -{args.level}" and dom in pt["kernels"]:
-                e = pt["kernels"][dom]
-                slabs_per_launch = nslabs * args.steps / launches
-                traffic = round((2.0 * e["fetch_kb_per_slab"] + e["write_kb_per_slab"]) * 1024.0 * slabs_per_launch)
+            if pt.get("workload") == f"{args.kind} -{args.level}":
+                tk = pt["kernels"]
+                cand = {"k_bwt_part": ["k_bwt_part2", "k_bwt_part"], "k_bwt_batch": ["k_bwt_batch", "k_bwt_fix"]}.get(dom, [dom])
+                kb = sum(2.0 * tk[c]["fetch_kb_per_slab"] + tk[c]["write_kb_per_slab"] for c in cand if c in tk)
+                if kb > 0:
+                    traffic = round(kb * 1024.0 * nslabs * args.steps / launches)
         except (OSError, ValueError, KeyError):
             traffic = None
         achieved = per_kernel[dom]["achieved_GBps"]
         pipe_alg = st.n_in + 13.0 * st.n_rle + 20.0 * st.n_mtf + st.n_out  # SURVEY 8(d), per step
         res = {
-            "metric": "compress MB/s (whole node) + ratio, enwik9 -9, at 1/2/4/8 MI355X", "value": round(total_in * args.steps / elapsed / 1e6, 1),
+            "metric": "compress MB/s (whole node) + ratio, enwik9 -9, at 1/2/4/8 MI355X",
+            "value": round((len(full) if strong else total_in) * args.steps / elapsed / 1e6, 1),
             "unit": "MB/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 2), "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic" if "synthetic" in source else "enwik9",
+            "scaling": args.scaling, "vs_baseline": None, "dtype": "u8",
+            "data": "synthetic" if "synthetic" in source else "enwik9",
             "config": {"workload": f"{source}, level -{args.level}, {nslabs} slabs of {M} B per GPU, "
-                                   f"{slabs} resident per chunk, one bzip2 block per workgroup, rounds of {nslots} slabs on two streams",
-                       "bytes_per_gpu": n, "level": args.level, "parallelism": f"{world} independent shard(s)"},
-            "ratio": round(total_in / total_out, 4), "out_bytes": total_out,
-            "bit_exact": "vs reference lbzip2 (tests/test_gpu_parity.py); periodic blocks: origin pointer only",
-            "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
+                                   f"{slabs} resident per chunk, one bzip2 block per workgroup, rounds of {nslots} slabs on two streams"
+                                   + ("; ONE stream gathered on rank 0 (RCCL send/recv of block bytes + 12-byte CRC partials)" if strong else ""),
+                       "bytes_per_gpu": n, "level": args.level,
+                       "parallelism": f"{world} slab range(s) of one input -> one stream" if strong else f"{world} independent shard(s)"},
+            "ratio": round((len(full) if strong else total_in) / max(1, total_out), 4), "out_bytes": total_out,
+            "verified": verified, "verified_against": verified_against,
+            "roofline": {"bound": "hbm", "kernel": dom + (" (+k_bwt_fix)" if dom == "k_bwt_batch" else ""),
+                         "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
                          "alg_bytes_per_launch": round(alg[dom] * args.steps / launches), "launches": launches,
-                         "avg_launch_ms": round(kms[dom] / launches, 3), "per_kernel": per_kernel,
+                         "avg_launch_ms": round(kms_sort[dom] / launches, 3), "per_kernel": per_kernel,
                          "pipeline_alg_bytes_per_step": round(pipe_alg),
                          "pipeline_achieved_GBps": round(pipe_alg * args.steps / (tot_ms * 1e-3) / 1e9, 2),
                          "pipeline_frac": round(pipe_alg * args.steps / (tot_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
                          "isolated": ({"note": "one untimed single-stream pass, no overlap", "slots": iso["slots"],
                                        "ms_total": round(iso["ms_total"], 2), "per_kernel": iso_tab} if iso else None)},
             "kernel_ms_per_step": {k: round(v / args.steps, 2) for k, v in kms.items()},
-            "sorter": {"elements_per_block_byte": round(st.sort_elems / max(1, st.n_rle), 3), "blocks": st.nblocks,
-                       "periodic_blocks": st.nperiodic},
+            "sorter": {"blocks": st.nblocks, "periodic_blocks": st.nperiodic},
         }
+        if value_host:
+            res["value_host"] = value_host
         if not args.no_cpu:
-            res["cpu_baseline"] = cpu_baseline(data, args.level)
+            res["cpu_baseline"] = cpu_baseline(full, args.level)
         print(json.dumps(res), flush=True)
     ctx.close()
     if world > 1:

@@ -131,7 +131,7 @@ void *lbzamd_stream(lbzamd_ctx *ctx);
 /* ---- stage access for parity tests (valid for the last chunk of the last call) ---- */
 typedef struct lbzamd_block_info {
   uint32_t n, crc, consumed, bwt_idx, periodic, nmtf, alpha, num_trees, num_sel, out_len, err, rounds;
-  uint32_t sort_elems, ticks[8];   /* diagnostics of the BWT stage */
+  uint32_t sort_elems, ticks[8], fticks[16];   /* diagnostics of the BWT stage (batch kernel, deep-tie kernel) */
   uint8_t inuse[256];
 } lbzamd_block_info;
 enum { LBZAMD_STAGE_RLE = 0, LBZAMD_STAGE_BWT = 1, LBZAMD_STAGE_MTFV = 2, LBZAMD_STAGE_OUT = 3 };

@@ -55,7 +55,7 @@ def fold_parts(cc, parts):
 class BlockInfo(C.Structure):
     _fields_ = [(n, C.c_uint32) for n in ("n", "crc", "consumed", "bwt_idx", "periodic", "nmtf",
                                            "alpha", "num_trees", "num_sel", "out_len", "err",
-                                           "rounds", "sort_elems")] + [("ticks", C.c_uint32 * 8),
+                                           "rounds", "sort_elems")] + [("ticks", C.c_uint32 * 8), ("fticks", C.c_uint32 * 16),
                                                                         ("inuse", C.c_uint8 * 256)]
 
 
@@ -231,6 +231,14 @@ class Context:
         if self.L.lib.lbzamd_compress_host(self.h, buf, len(data), self._out, cap, C.byref(n)):
             raise LbzError("lbzamd_compress_host: " + self.L.error())
         return C.string_at(self._out, n.value)
+
+    def compress_host_ptr(self, h_in, length, h_out, out_cap):
+        """Host buffers by address (e.g. pinned torch tensors' .data_ptr()): H2D per round on the round's
+        stream, kernels, one D2H of the stream.  Returns the stream length."""
+        n = C.c_size_t()
+        if self.L.lib.lbzamd_compress_host(self.h, C.c_void_p(h_in), length, C.c_void_p(h_out), out_cap, C.byref(n)):
+            raise LbzError("lbzamd_compress_host: " + self.L.error())
+        return n.value
 
     def compress_device(self, d_in, length, d_out, out_cap):
         """d_in/d_out: integer device addresses (e.g. torch tensor .data_ptr())."""

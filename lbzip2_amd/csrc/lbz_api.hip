@@ -474,6 +474,7 @@ extern "C" int lbzamd_block_info_get(lbzamd_ctx *c, uint32_t blk, lbzamd_block_i
   info->periodic = m.periodic; info->nmtf = m.nmtf; info->alpha = m.alpha; info->num_trees = m.num_trees;
   info->num_sel = m.num_sel; info->out_len = m.out_len; info->err = m.err; info->rounds = m.rounds;
   info->sort_elems = m.sort_elems; for (int i = 0; i < 8; i++) info->ticks[i] = m.ticks[i];
+  for (int i = 0; i < 16; i++) info->fticks[i] = m.fticks[i];
   memcpy(info->inuse, m.inuse, 256);
   return 0;
 }

@@ -1,6 +1,6 @@
-"""CPU: the parts of bench.py that do not need a GPU -- the input generator (the SURVEY.md 8d
-stand-in text) and the cpu_baseline leg (the only place outside tests/ and smoke() that may call
-into oracle/)."""
+"""CPU: the parts of bench.py that do not need a GPU -- the input generators (the BASELINE.json
+stand-ins of lbzip2_amd/host/gen_inputs.c), the fixture lookup and the cpu_baseline leg (the only
+place outside tests/ and smoke() that may call into oracle/)."""
 import hashlib
 import os
 import sys
@@ -9,6 +9,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 import bench  # noqa: E402
 import oracle_lib as L  # noqa: E402
+from golden_util import bench_fixtures  # noqa: E402
 
 
 def test_generator_matches_oracle_generator():
@@ -19,9 +20,34 @@ def test_generator_matches_oracle_generator():
     assert L.gen_rand(8, 1).hex() == "00049d128e2c2519"
 
 
+def test_generators_match_fixture_inputs():
+    """The small fixtures pin the generators: same bytes here as when the reference compressed them;
+    a prefix of a longer run of the same seed is the same text (strong-scaling slices are prefixes)."""
+    for r in bench_fixtures(max_n=3_000_000):
+        data = bench.gen_input(r["kind"], r["n"], r["seed"])
+        assert hashlib.md5(data).hexdigest() == r["in_md5"], (r["kind"], r["n"])
+        assert bench.find_fixture(r["kind"], r["n"], r["seed"], r["level"])["ref_md5"] == r["ref_md5"]
+    big = bench.gen_input("wiki", 2_000_000, 2)
+    assert bytes(big[:350000]) == bytes(bench.gen_input("wiki", 350000, 2))
+    assert len(set(big)) >= 190                      # byte alphabet: 8-bit sort symbols
+    assert bench.find_fixture("wiki", 1_000_000_000, 2, 9)["out_len"] > 2 * 10**8
+
+
 def test_cpu_baseline_leg():
-    data = bench.gen_input("text", 4 * 900000, 2)
-    r = bench.cpu_baseline(data, 9)
+    data = bench.gen_input("wiki", 24 * 900000, 2)
+    r = bench.cpu_baseline(data, 9, seconds_budget=3.0)
     assert r["kind"] in ("reference", "port") and r["unit"] == "MB/s"
-    assert r["value"] > 0 and 1 <= r["cores"] <= (os.cpu_count() or 1)
-    assert "slabs of 900000 B" in r["sample"]
+    assert r["value"] > 0 and 1 <= r["cores"] <= r["usable_cpus"]
+    assert "slabs of 900000 B" in r["sample"] and "1" in r["MBps_by_threads"]
+    if r["usable_cpus"] >= 4 and r["cgroup_cpu_quota"] is None:
+        assert r["value"] > 1.5 * r["MBps_by_threads"]["1"], r    # the pthreads driver scales
+
+
+def test_reference_driver_equals_single_thread_driver():
+    """oracle/cpu_mt.h on N threads == the single-thread reference stream == the oracle."""
+    data = bytes(bench.gen_input("mixed", 1_300_000, 3))
+    if L.have_ref():
+        a = L.ref_compress_mt(data, 1, 4)[0]
+        assert a == L.ref_compress(data, 1)
+        assert a == L.orc_compress_mt(data, 1, 3)[0]
+    assert L.orc_compress_mt(data, 1, 2)[0] == L.orc_compress(data, 1)
