@@ -1,0 +1,76 @@
+"""The drop-in boundary, proven with the reference's own program: every source file of lbzip2 except
+encode.c and divbwt.c -- main.c, process.c (splitter / muxer threads), compress.c (work units),
+signals.c, timespec.c, expand.c, decode.c, parse.c, crctab.c -- compiled UNCHANGED where it lies under
+/root/reference/src (oracle/Makefile: `stock`, `dropin`) and linked against this repository's library
+in place of the block codec.  compress.c then drives GPU blocks through encode.h
+(encoder_alloc_size / encoder_init / collect / encode / transmit, compress.c:89-94,113,220-223).
+
+CPU (here): linked against the emulator build of the kernels; output must equal stock lbzip2's byte for
+byte at several levels and worker counts, and the reference fixture.
+GPU: the same program linked against the product library (built here by hipcc, travels with the
+repository under oracle/_ref/) compresses the enwik8-sized stand-in on the MI355X."""
+import hashlib
+import os
+import subprocess
+
+import pytest
+
+from golden_util import bench_fixtures, gen
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REFDIR = os.path.join(ROOT, "oracle", "_ref")
+HAVE_SRC = os.path.exists("/root/reference/src/compress.c")
+
+
+def _make(*args):
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle")] + list(args))
+
+
+@pytest.fixture(scope="module")
+def programs():
+    if not HAVE_SRC:
+        pytest.skip("reference sources absent (GPU box): the CPU link test runs in the build container")
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "tests", "emu"), "WG=1024"])
+    _make("stock")
+    _make("dropin", "DROPIN=../tests/emu/_build/liblbzamd_emu_1024.so", "OUT=lbzip2_dropin_emu")
+    return os.path.join(REFDIR, "lbzip2_stock"), os.path.join(REFDIR, "lbzip2_dropin_emu")
+
+
+def _run(exe, args, data, env=None, timeout=900):
+    p = subprocess.run([exe] + args, input=data, capture_output=True, timeout=timeout,
+                       env=dict(os.environ, **(env or {})))
+    assert p.returncode == 0, p.stderr[-500:]
+    return p.stdout
+
+
+@pytest.mark.parametrize("level,workers,kind,n,seed", [(1, 1, "wiki", 350000, 2), (1, 4, "wiki", 350000, 2),
+                                                       (2, 3, "runs", 410000, 9), (1, 2, "text", 99999, 4)])
+def test_unmodified_reference_cli_drives_the_library(programs, level, workers, kind, n, seed):
+    stock, dropin = programs
+    data = bytes(gen(kind, n, seed))
+    args = [f"-{level}", "-n", str(workers)]
+    want = _run(stock, args, data)
+    got = _run(dropin, args, data, env={"LBZAMD_POOL_SLABS": "8", "LBZ_EMU_THREADS": "2"})
+    assert got == want
+    for r in bench_fixtures(max_n=400000):
+        if (r["kind"], r["n"], r["seed"], r["level"]) == (kind, n, seed, level):
+            assert hashlib.md5(got).hexdigest() == r["ref_md5"]
+    assert _run(stock, ["-d"], got) == data                      # and the reference's decompressor takes it
+
+
+def test_empty_input_through_the_cli(programs):
+    stock, dropin = programs
+    assert _run(dropin, ["-9"], b"", env={"LBZAMD_POOL_SLABS": "2"}) == _run(stock, ["-9"], b"")
+
+
+@pytest.mark.gpu
+def test_reference_cli_on_the_gpu():
+    """oracle/_ref/lbzip2_dropin_gpu = the reference's unmodified CLI + process.c splitter/muxer, linked
+    against lbzip2_amd/csrc/liblbzamd.so: 64 worker threads feed GPU blocks; stream == reference fixture."""
+    exe = os.path.join(REFDIR, "lbzip2_dropin_gpu")
+    if not os.path.exists(exe):
+        pytest.skip("oracle/_ref/lbzip2_dropin_gpu not built (needs the reference sources at build time)")
+    rec = [r for r in bench_fixtures() if r["kind"] == "wiki" and r["n"] == 100_000_000][0]
+    data = bytes(gen(rec["kind"], rec["n"], rec["seed"]))
+    out = _run(exe, ["-9", "-n", "64"], data, timeout=300)
+    assert len(out) == rec["out_len"] and hashlib.md5(out).hexdigest() == rec["ref_md5"]

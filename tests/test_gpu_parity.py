@@ -80,7 +80,6 @@ def test_baseline_configs_vs_reference(lib, rec):
     assert m == rec["out_len"] and st.nblocks == rec["blocks"]
     if md5(out) != rec["canon_md5"]:
         # localise: the body cut at every 100th slab is in the fixture
-        bad = []
         assert out[:4] == b"BZh" + bytes([48 + lvl])
         pytest.fail(f"stream md5 differs from the reference's ({rec['config']}); combined CRC "
                     f"{int.from_bytes(out[-4:], 'big'):#x} vs {rec['combined_crc']:#x}")
@@ -173,6 +172,26 @@ def test_periodic_blocks_documented_divergence(lib):
             assert len(r) == len(g)
             r[14:18] = g[14:18] = b"\0" * 4       # stream header 4 + block bytes 10..13
             assert r == g
+
+
+def test_periodic_corpus_blocks_enumerated(lib):
+    """Every exactly periodic block of the reference's corpora (tests/golden/periodic_blocks.json: the
+    reference's origin pointer, k, the smallest equal row): the GPU emits the smallest equal row and
+    flags the block periodic; all other blocks are bit-exact (test_reference_suite_corpora)."""
+    pb = load("periodic_blocks.json")
+    inputs = suite_inputs()
+    by_input = {}
+    for e in pb:
+        by_input.setdefault((e["input"], e["level"]), []).append(e)
+    for (name, lvl), entries in sorted(by_input.items()):
+        raw = inputs[name]
+        M = lvl * 100000
+        with lib.context(lvl, max(1, (len(raw) + M - 1) // M)) as ctx:
+            blocks = ctx.blocks(raw, 1)
+        for e in entries:
+            b = blocks[e["block"]]
+            assert b["periodic"] and b["bwt_idx"] == e["canon_bwt_idx"], e
+            assert e["canon_bwt_idx"] == e["ref_bwt_idx"] - e["ref_bwt_idx"] % e["copies"]
 
 
 def test_workunit_interface(lib):

@@ -82,3 +82,27 @@ def test_reference_suite_corpora():
     with ProcessPoolExecutor(min(8, os.cpu_count() or 1)) as ex:
         bad = [b for r in ex.map(_suite_chunk, chunks) for b in r]
     assert not bad, bad[:10]
+
+
+def test_periodic_blocks_enumerated():
+    """The one documented divergence, enumerated: tests/golden/periodic_blocks.json lists every exactly
+    periodic block (T = u^k) of the reference's own compress corpora with the reference's origin
+    pointer and the smallest equal row (the reference's row rounded down to a multiple of k: the k equal
+    rows of a rotation class are consecutive and classes start at multiples of k).  The oracle must
+    emit exactly that row; with the compiled reference present, its row must be the listed one."""
+    from golden_util import load, suite_inputs
+    pb = load("periodic_blocks.json")
+    assert len(pb) >= 100
+    inputs = suite_inputs()
+    seen = 0
+    for e in pb:
+        raw = inputs[e["input"]]
+        assert e["copies"] >= 2 and e["canon_bwt_idx"] == e["ref_bwt_idx"] - e["ref_bwt_idx"] % e["copies"]
+        if len(raw) > 120000:
+            continue
+        blk = L.orc_blocks(raw, e["level"])[e["block"]]
+        assert blk["periodic"] and blk["bwt_idx"] == e["canon_bwt_idx"], e
+        if L.have_ref():
+            assert L.ref_blocks(raw, e["level"])[e["block"]]["bwt_idx"] == e["ref_bwt_idx"], e
+        seen += 1
+    assert seen >= 12
