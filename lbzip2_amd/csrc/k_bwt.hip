@@ -1188,7 +1188,8 @@ __device__ u32 doubling_round(const u8 *T, u32 n, u8 *bwt, bwt_slot s, bwt_lds *
         if (ok) {
           const u32 row = (u32)B->kB[j], sf = B->vA[j];
           const u32 newrank = (u32)B->kB[B->gh[j]];
-          s.sa[row] = sf;
+          /* the suffix array itself is not read again: ranks (isa) and the list carry the rounds, the
+             BWT byte of a row that became unique is written below */
           s.isa[sf] = newrank;
           if (td) {
             const u32 o = off + (u32)__popcll(mask & lanes_below());
