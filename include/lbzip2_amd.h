@@ -119,6 +119,10 @@ uint32_t lbzamd_fold_parts(uint32_t cc, const lbzamd_part *parts, size_t nparts)
 /* Same with host buffers (H2D + compress + D2H). */
 int  lbzamd_compress_host(lbzamd_ctx *ctx, const uint8_t *in, size_t len,
                           uint8_t *out, size_t out_cap, size_t *out_len);
+/* Page-locked host buffers for a host-side splitter/muxer (process.c:260-307 reads, :351-417 writes):
+ * H2D/D2H of pinned memory run at link rate and overlap with kernels. */
+void *lbzamd_pinned_alloc(size_t bytes);
+void  lbzamd_pinned_free(void *p);
 /* Upper bound of the stream size for len input bytes. */
 size_t lbzamd_bound(size_t len);
 int  lbzamd_get_stats(lbzamd_ctx *ctx, lbzamd_stats *st);

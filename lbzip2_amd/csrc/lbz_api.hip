@@ -441,6 +441,15 @@ static int compress_host(lbzamd_ctx *c, const uint8_t *in, size_t len, uint8_t *
   return 0;
 }
 
+/* page-locked host memory for the splitter/muxer of a host program (DMA at link rate, async copies) */
+extern "C" void *lbzamd_pinned_alloc(size_t bytes)
+{
+  void *p = nullptr;
+  if (hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault) != hipSuccess) return nullptr;
+  return p;
+}
+extern "C" void lbzamd_pinned_free(void *p) { if (p) (void)hipHostFree(p); }
+
 extern "C" int lbzamd_get_stats(lbzamd_ctx *c, lbzamd_stats *st)
 {
   if (!c || !st) return -1;

@@ -100,3 +100,16 @@ def test_reference_suite_sample(emu):
         raw = inputs[n]
         if raw:
             assert emu.compress(raw, 9) == L.orc_compress(raw, 9), n
+
+
+def test_file_splitter_muxer(emu, tmp_path):
+    """lbzamd_compress -f/-o: reader thread -> ring of chunk buffers -> pipeline threads with
+    their own contexts (body-only slab ranges) -> writer thread in order, CRC folded from the 12-byte
+    partials.  Sizes: several chunks with a ragged tail, an exact multiple of the chunk, one slab, empty."""
+    exe = os.path.join(EMU_DIR, "_build", "lbzamd_compress_emu")
+    for n, chunk, pipes in ((527000, 2, 2), (400000, 2, 3), (99000, 4, 1), (0, 2, 2)):
+        data = bytes(gen("wiki", n, 3)) if n else b""
+        src, dst = tmp_path / "in.bin", tmp_path / "out.bz2"
+        src.write_bytes(data)
+        subprocess.check_call([exe, "-1", "-f", str(src), "-o", str(dst), "-c", str(chunk), "-p", str(pipes)], timeout=600)
+        assert dst.read_bytes() == L.orc_compress(data, 1), (n, chunk, pipes)

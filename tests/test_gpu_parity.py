@@ -240,24 +240,56 @@ def test_c_host_driver(lib, tmp_path):
         assert out.stdout == want, extra
 
 
+def test_file_splitter_muxer_full_size(lib, tmp_path):
+    """SURVEY 8f-1 on the device: the enwik9-sized stand-in goes file -> reader thread -> pinned ring ->
+    two pipelines (own contexts, body-only slab ranges of 256 slabs) -> writer thread -> file, never resident
+    as a whole; the file must be the reference's stream (fixture md5)."""
+    import hashlib
+    import subprocess
+    exe = os.path.join(os.path.dirname(lib.path), "..", "host", "lbzamd_compress")
+    if not os.path.exists(exe):
+        pytest.skip("C driver not built")
+    rec = [r for r in bench_fixtures() if r["kind"] == "wiki" and r["n"] == 1_000_000_000 and r["seed"] == 2][0]
+    src, dst = tmp_path / "wiki.bin", tmp_path / "wiki.bz2"
+    src.write_bytes(gen(rec["kind"], rec["n"], rec["seed"]))
+    env = dict(os.environ, LD_LIBRARY_PATH="/opt/rocm/lib:" + os.environ.get("LD_LIBRARY_PATH", ""))
+    p = subprocess.run([exe, "-9", "-f", str(src), "-o", str(dst), "-c", "256", "-p", "2", "-t"], capture_output=True, env=env, timeout=300)
+    assert p.returncode == 0, p.stderr[-500:]
+    print(p.stderr.decode()[-300:])
+    out = dst.read_bytes()
+    assert len(out) == rec["out_len"] and hashlib.md5(out).hexdigest() == rec["ref_md5"]
+
+
 def test_full_size_property(lib):
     """BASELINE-sized behaviour by properties: 60 MB of text at -9 with chunked streaming
     (resident capacity smaller than the input) round-trips through an independent decoder,
-    equals the CPU reference, and the stream CRC is the fold of the block CRCs."""
+    equals the CPU reference, and the stream CRC is the fold of the block CRCs (refolded here)."""
     data = gen("text", 60_000_000, 2)
     with lib.context(9, 24) as ctx:
         out = ctx.compress(data)
         st = ctx.stats()
     assert st.n_in == len(data) and st.n_out == len(out) and st.nblocks >= 67
     assert bz2.decompress(out) == data
-    with ThreadPoolExecutor(os.cpu_count()) as ex:        # reference per 9 MB piece, in parallel
-        M = 900000 * 10
-        pieces = list(ex.map(lambda o: cpu_reference(data[o:o + M], 9)[0], range(0, len(data), M)))
-    body = b"".join(p[4:-10] for p in pieces)
-    assert out[4:-10] == body
-    cc = 0
-    for p in pieces:                                       # refold piece CRCs is not possible; check ours
-        pass
+    if L.have_ref():
+        # the reference on all host cores (oracle/cpu_mt.h): same bytes, and the stream CRC is the fold of
+        # the block CRCs in order (encode.h:38), block by block and range by range
+        want, blocks, _ = L.ref_compress_mt(data, 9, os.cpu_count() or 1)
+        assert out == want
+        import lbzip2_amd
+        cc = 0
+        for _olen, crc, _idx, _k, _slab in blocks:
+            cc = lbzip2_amd.combine_crc(cc, crc)
+        assert cc == int.from_bytes(out[-4:], "big")
+        half = len(blocks) // 2
+        parts = []
+        for rng in (blocks[:half], blocks[half:]):
+            f = 0
+            for _olen, crc, _idx, _k, _slab in rng:
+                f = lbzip2_amd.combine_crc(f, crc)
+            parts.append((len(rng), f))
+        assert lbzip2_amd.fold_parts(0, parts) == cc
+    else:
+        assert out == L.orc_compress_mt(data, 9, os.cpu_count() or 1)[0]
     assert out[:4] == b"BZh9" and out[-10:-4] == bytes([0x17, 0x72, 0x45, 0x38, 0x50, 0x90])
 
 
