@@ -103,6 +103,7 @@ struct batch_lds {                      /* one batch resident in LDS */
 struct bwt_lds {
   wg_scratch sc;
   u32 bc[16];
+  u32 isa_from, pad_;                 /* k_bwt_batch: rows from here on get their rank written with them */
   u8 cmap[256];                       /* byte -> dense code */
   u8 inv[256];                        /* dense code -> byte */
   union {
@@ -231,7 +232,7 @@ __device__ u32 wg_radix_sort(u64 *k0, u32 *v0, u64 *k1, u32 *v1, u32 m, u32 nbit
  * the number of still-tied entries.                                                       */
 template <bool FLAGS>
 __device__ u32 wg_regroup(const u64 *key, const u32 *val, u32 rowbase, u32 out_base, u32 m,
-                          bwt_slot s, bwt_lds *S, const u8 *T, u32 n, u8 *bwt)
+                          bwt_slot s, bwt_lds *S, const u8 *T, u32 n, u8 *bwt, u32 isa_below = 0xFFFFFFFFu)
 {
   const u32 tid = threadIdx.x;
   u32 carry_rank = 0, carry_cnt = out_base;
@@ -292,8 +293,8 @@ __device__ u32 wg_regroup(const u64 *key, const u32 *val, u32 rowbase, u32 out_b
       const u32 k = k0 + i;
       if (k < m) {
         if ((headmask >> i) & 1u) rank1 = row[i] + 1u;
-        s.sa[row[i]] = vv[i];
-        s.isa[vv[i]] = rank1 - 1u;
+        if (!FLAGS) s.sa[row[i]] = vv[i];
+        if (row[i] < isa_below) s.isa[vv[i]] = rank1 - 1u;       /* rows from isa_below on got their rank in k_bwt_batch */
         if ((actmask >> i) & 1u) {
           s.sufx[o] = vv[i];
           s.grp[o] = rank1 - 1u;
@@ -812,7 +813,7 @@ __device__ u32 wave_runs(batch_lds *B, u32 cs, u32 ce, u32 sh = 0u)
  * already are), refine runs of equal keys with further symbols of the text, emit.  No workgroup
  * barrier inside: the 16 waves of a batch run their chunks independently.                   */
 __device__ void wave_finish_chunk(batch_lds *B, u32 cs, u32 ce, bool need_sort, const u8 *T, u32 n, keycfg c,
-                                  u8 *bwt, u32 *sa, u32 lo, lbz_block_meta *meta, bwt_lds *S)
+                                  u8 *bwt, u32 *sa, u32 *isa, u32 lo, lbz_block_meta *meta, bwt_lds *S)   /* isa == nullptr: ranks not wanted yet */
 {
   const u32 lane = lane_id();
   u32 ntied;
@@ -866,9 +867,15 @@ __device__ void wave_finish_chunk(batch_lds *B, u32 cs, u32 ce, bool need_sort, 
     const bool flagged = B->tied[j] && B->gh[j] != j;
     bwt[lo + j] = S->inv[v >> 24];
     sa[lo + j] = idx | (flagged ? TIE_FLAG : 0u);
+    /* rank of the rotation = first row of its run.  k_bwt_fix needs it for every rotation of a block
+       with deep ties; written here, these scattered stores ride under a kernel that is bound by LDS work,
+       instead of being a pass of their own in a kernel that is bound by scattered HBM traffic.  Only once
+       the block has shown that it will need k_bwt_fix (batch_process decides): text whose ties are
+       shallow never pays for it.                                                                   */
+    if (isa) isa[idx] = lo + (u32)B->gh[j];
     if (idx == 0u) meta->bwt_idx = lo + j;
   }
-  if (ntied && lane == 0u) S->bc[8] = 1u;
+  if (ntied && lane == 0u) { S->bc[8] = 1u; atomicAdd(&S->bc[2], ntied); }
   if (lane == 0u) {
     const u64 tw2 = wall_clock64();
     atomicAdd(&S->bc[13], (u32)(tw2 - tw0));
@@ -1012,7 +1019,7 @@ __device__ u32 batch_process(const u8 *T, u32 n, u8 *bwt, lbz_block_meta *meta, 
     if (t >= nwin) break;
     const u32 k = B->corder[t];
     const u32 cs = B->cstart[k], ce = B->cstart[k + 1u];
-    if (cs < ce) wave_finish_chunk(B, cs, ce, need_sort, T, n, c, bwt, s.sa, lo, meta, S);
+    if (cs < ce) wave_finish_chunk(B, cs, ce, need_sort, T, n, c, bwt, s.sa, lo >= S->isa_from ? s.isa : nullptr, lo, meta, S);
   }
   __syncthreads();
   if (tid == 0) {
@@ -1029,6 +1036,7 @@ __device__ void emit_tied_rows(u8 *bwt, bwt_slot s, bwt_lds *S, u32 lo, u32 hi)
     const u32 v = s.v0[j];
     bwt[j] = S->inv[v >> 24];
     s.sa[j] = (v & 0x00FFFFFFu) | (j > lo ? TIE_FLAG : 0u);
+    s.isa[v & 0x00FFFFFFu] = lo;
   }
   if (threadIdx.x == 0) S->bc[8] = 1u;
   __syncthreads();
@@ -1217,7 +1225,7 @@ __device__ void finish_by_doubling(const u8 *T, u32 n, u8 *bwt, lbz_block_meta *
 {
   const u32 tid = threadIdx.x;
   const u64 tk0 = wall_clock64();
-  u32 m = wg_regroup<true>(nullptr, s.sa, 0u, 0u, n, s, S, T, n, nullptr);
+  u32 m = wg_regroup<true>(nullptr, s.sa, 0u, 0u, n, s, S, T, n, nullptr, meta->isa_from);
   if (tid == 0) { meta->ticks[6] = (u32)(wall_clock64() - tk0); meta->ticks[1] = m; }
   u32 rounds = 0, work = 0;
   for (u32 h = h0; m > 0u && h < n; h <<= 1) {
@@ -1266,6 +1274,7 @@ __device__ keycfg bwt_setup(const lbz_block_meta *meta, bwt_lds *S)
 struct part_lds {
   wg_scratch sc;
   u32 bc[16];
+  u32 isa_from, pad_;
   u8 cmap[256];
   u8 inv[256];
   sort_lds X;
@@ -1343,6 +1352,8 @@ k_bwt_batch(const u8 *Tbase, u8 *Bbase, lbz_block_meta *meta, lbz_layout L, u32 
   }
   const u64 tk0 = wall_clock64();
   const keycfg c = bwt_setup(M, &S);
+  if (tid == 0) S.isa_from = n;
+  __syncthreads();
   if (n <= BATCH_CAP) {
     batch_lds *B = &S.u.B;
     for (u32 i = tid; i < n; i += LBZ_WG) {
@@ -1354,6 +1365,13 @@ k_bwt_batch(const u8 *Tbase, u8 *Bbase, lbz_block_meta *meta, lbz_layout L, u32 
   } else {
     u32 pos = 0;
     while (pos < n) {
+      /* a block whose rows keep tying (more than a fifth so far) will go through k_bwt_fix: from here on
+         the batches write the ranks along with the rows */
+      if (S.isa_from == n && pos >= 2u * BATCH_CAP && 5u * S.bc[2] > pos) {
+        __syncthreads();
+        if (tid == 0) S.isa_from = pos;
+        __syncthreads();
+      }
       const u32 want = n - pos < BATCH_CAP ? n - pos : BATCH_CAP;
       const u32 used = batch_process(T, n, bwt, M, s, &S, c, pos, want, false, false, true);
       if (used == 0u) {                          /* one group fills the batch: sort it in HBM first */
@@ -1368,6 +1386,7 @@ k_bwt_batch(const u8 *Tbase, u8 *Bbase, lbz_block_meta *meta, lbz_layout L, u32 
   __syncthreads();
   if (tid == 0) {
     M->periodic = S.bc[8] ? 2u : 0u;          /* 2 = ties left for k_bwt_fix */
+    M->isa_from = S.isa_from;
     M->rounds = 0;
     M->sort_elems = n;
     M->ticks[0] = (u32)(wall_clock64() - tk0);

@@ -50,6 +50,7 @@ typedef struct lbz_block_meta {
   uint32_t err;        /* non-zero: internal capacity problem */
   uint32_t rounds;     /* prefix-doubling rounds run (diagnostic) */
   uint32_t sort_elems; /* sum of elements passed through the radix sorter (diagnostic) */
+  uint32_t isa_from;   /* k_bwt_batch wrote the ranks (isa) of the rotations in rows >= isa_from; k_bwt_fix fills in the rest */
   uint32_t ticks[8];   /* wall_clock64 ticks of k_bwt_part / k_bwt_batch phases (diagnostic) */
   uint32_t fticks[16];  /* wall_clock64 ticks of k_bwt_fix phases (diagnostic) */
   uint8_t  inuse[256]; /* used-byte map (encode.c:63) */

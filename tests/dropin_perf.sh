@@ -7,7 +7,7 @@ MB=${1:-450}; shift
 python - <<PY
 import sys; sys.path.insert(0, "/root/repo")
 import bench
-open("/tmp/in.txt", "wb").write(bench.gen_input("text", $MB * 1000000, 2))
+open("/tmp/in.txt", "wb").write(bench.gen_input("wiki", $MB * 1000000, 2))
 PY
 for w in ${@:-16 64 256 512}; do
   ./lbzip2_amd/host/lbzamd_compress -9 -w $w -t -r 3 < /tmp/in.txt 2>&1 > /tmp/out_$w.bz2 | tail -2

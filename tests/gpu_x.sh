@@ -1,0 +1,5 @@
+#!/bin/bash
+cd /root/repo
+export PYTHONPATH=/root/repo:/root/repo/tests
+bash tests/gpu_var.sh wiki,tar,text 1112 default noisa 2>&1 | grep -v amdgpu
+timeout 300 python -m pytest tests/test_gpu_parity.py -x -q -m gpu -k "fuzz or corpora or repetitive or small or ragged or round_schedule or periodic or literal or seeded" 2>&1 | tail -2
