@@ -841,8 +841,11 @@ __device__ void wave_finish_chunk(batch_lds *B, u32 cs, u32 ce, bool need_sort, 
      here than to pay the doubling's full rank build for.                                    */
   u32 depth = c.sy;
   u32 before = ntied;
+  if (ntied && lane == 0u) atomicAdd(&S->bc[2], ntied);      /* rows tied on their first key: what batch_process judges the block by */
   const u64 tw1 = wall_clock64();
-  for (u32 r = 0; r < REFINE_ROUNDS && ntied && before; r++) {
+  /* a block that keeps tying (isa != nullptr: batch_process has switched the rank emission on) goes through
+     k_bwt_fix whatever is refined here, and a tied-row round costs the same on either side: skip it */
+  for (u32 r = 0; r < REFINE_ROUNDS && ntied && before && !isa; r++) {
     /* block-wide budget of tied-row rounds: a block that has burnt n/8 of them is a repetitive
        one that will need the doubling anyway -- stop refining its remaining chunks */
     if ((u32)__builtin_amdgcn_readfirstlane((int)S->bc[9]) > n / REFINE_BUDGET_DIV) break;
@@ -875,7 +878,7 @@ __device__ void wave_finish_chunk(batch_lds *B, u32 cs, u32 ce, bool need_sort, 
     if (isa) isa[idx] = lo + (u32)B->gh[j];
     if (idx == 0u) meta->bwt_idx = lo + j;
   }
-  if (ntied && lane == 0u) { S->bc[8] = 1u; atomicAdd(&S->bc[2], ntied); }
+  if (ntied && lane == 0u) S->bc[8] = 1u;
   if (lane == 0u) {
     const u64 tw2 = wall_clock64();
     atomicAdd(&S->bc[13], (u32)(tw2 - tw0));
