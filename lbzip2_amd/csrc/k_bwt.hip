@@ -99,6 +99,7 @@ struct batch_lds {                      /* one batch resident in LDS */
   u16 cstart[BATCH_CAP / 64u + 2u];     /* first row of the chunk that belongs to each claim window */
   u8 corder[BATCH_CAP / 64u + 2u];      /* chunks, longest first */
   u16 ctied[BATCH_CAP / 64u + 2u];      /* doubling: rows of each chunk that stay tied */
+  u32 oldhead[BATCH_CAP / 32u];         /* doubling: bit j = list position j was the first row of a run when the round began */
 };
 struct bwt_lds {
   wg_scratch sc;
@@ -1160,6 +1161,14 @@ __device__ u32 doubling_round(const u8 *T, u32 n, u8 *bwt, bwt_slot s, bwt_lds *
     const u64 td1 = wall_clock64();
     u32 maxrun;
     batch_runs(B, B->kB, cnt, 0u, &maxrun, S);            /* the runs as they stand */
+    /* remember the run heads: the first piece of a run that splits keeps the run's rank, so its rows need
+       no rank store (a third of the scattered stores of a block with deep ties) */
+    if (tid < BATCH_CAP / 32u) {
+      u32 bits = 0;
+#pragma unroll 8
+      for (u32 q = 0; q < 32u; q++) { const u32 j = tid * 32u + q; if (j < cnt && B->gh[j] == j) bits |= 1u << q; }
+      B->oldhead[tid] = bits;
+    }
     const u64 td2 = wall_clock64();
     /* sort phase: waves claim chunks, longest first (as in batch_process) */
     const u32 nwin = chunk_plan(B, cnt);
@@ -1201,7 +1210,8 @@ __device__ u32 doubling_round(const u8 *T, u32 n, u8 *bwt, bwt_slot s, bwt_lds *
           const u32 newrank = (u32)B->kB[B->gh[j]];
           /* the suffix array itself is not read again: ranks (isa) and the list carry the rounds, the
              BWT byte of a row that became unique is written below */
-          s.isa[sf] = newrank;
+          const u32 nh = B->gh[j];
+          if (!((B->oldhead[nh >> 5] >> (nh & 31u)) & 1u)) s.isa[sf] = newrank;
           if (td) {
             const u32 o = off + (u32)__popcll(mask & lanes_below());
             s.sufx[o] = sf; s.grp[o] = newrank; s.pos[o] = row;
