@@ -104,7 +104,7 @@ struct batch_lds {                      /* one batch resident in LDS */
 struct bwt_lds {
   wg_scratch sc;
   u32 bc[16];
-  u32 isa_from, pad_;                 /* k_bwt_batch: rows from here on get their rank written with them */
+  u32 isa_from, tied0;                /* k_bwt_batch: rows from isa_from on get their rank written with them; tied0 = rows tied on their first key so far */
   u8 cmap[256];                       /* byte -> dense code */
   u8 inv[256];                        /* dense code -> byte */
   union {
@@ -842,7 +842,7 @@ __device__ void wave_finish_chunk(batch_lds *B, u32 cs, u32 ce, bool need_sort, 
      here than to pay the doubling's full rank build for.                                    */
   u32 depth = c.sy;
   u32 before = ntied;
-  if (ntied && lane == 0u) atomicAdd(&S->bc[2], ntied);      /* rows tied on their first key: what batch_process judges the block by */
+  if (ntied && lane == 0u) atomicAdd(&S->tied0, ntied);      /* rows tied on their first key: what k_bwt_batch judges the block by */
   const u64 tw1 = wall_clock64();
   /* a block that keeps tying (isa != nullptr: batch_process has switched the rank emission on) goes through
      k_bwt_fix whatever is refined here, and a tied-row round costs the same on either side: skip it */
@@ -1287,7 +1287,7 @@ __device__ keycfg bwt_setup(const lbz_block_meta *meta, bwt_lds *S)
 struct part_lds {
   wg_scratch sc;
   u32 bc[16];
-  u32 isa_from, pad_;
+  u32 isa_from, tied0;
   u8 cmap[256];
   u8 inv[256];
   sort_lds X;
@@ -1365,7 +1365,7 @@ k_bwt_batch(const u8 *Tbase, u8 *Bbase, lbz_block_meta *meta, lbz_layout L, u32 
   }
   const u64 tk0 = wall_clock64();
   const keycfg c = bwt_setup(M, &S);
-  if (tid == 0) S.isa_from = n;
+  if (tid == 0) { S.isa_from = n; S.tied0 = 0; }
   __syncthreads();
   if (n <= BATCH_CAP) {
     batch_lds *B = &S.u.B;
@@ -1380,7 +1380,7 @@ k_bwt_batch(const u8 *Tbase, u8 *Bbase, lbz_block_meta *meta, lbz_layout L, u32 
     while (pos < n) {
       /* a block whose rows keep tying (more than a fifth so far) will go through k_bwt_fix: from here on
          the batches write the ranks along with the rows */
-      if (S.isa_from == n && pos >= 2u * BATCH_CAP && 5u * S.bc[2] > pos) {
+      if (S.isa_from == n && pos >= 2u * BATCH_CAP && 5u * S.tied0 > pos) {
         __syncthreads();
         if (tid == 0) S.isa_from = pos;
         __syncthreads();
