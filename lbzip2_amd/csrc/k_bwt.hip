@@ -988,12 +988,18 @@ __device__ u32 batch_process(const u8 *T, u32 n, u8 *bwt, lbz_block_meta *meta, 
     if (cnt == 0u) { __syncthreads(); return 0u; }
   }
   if (need_sort && maxrun > WAVE_GROUP) {
+#ifdef LDS_SORT_TICKS
+    const u64 tl0 = wall_clock64();
+#endif
     if (lds_radix_sort(B, cnt, S)) {
       for (u32 i = tid; i < cnt; i += LBZ_WG) { B->kA[i] = B->kB[i]; B->vA[i] = B->vB[i]; }
       __syncthreads();
     }
     need_sort = false;
     batch_runs(B, B->kA, cnt, 0u, &maxrun, S);
+#ifdef LDS_SORT_TICKS
+    if (tid == 0) { S->bc[15] += (u32)(wall_clock64() - tl0); S->bc[1] += 1u; }
+#endif
   }
   if (need_sort && maxrun > SPLIT_MIN) {
     /* A long group would be one wave's job from start to end and hold the whole batch up.  Cut
@@ -1414,6 +1420,9 @@ k_bwt_batch(const u8 *Tbase, u8 *Bbase, lbz_block_meta *meta, lbz_layout L, u32 
     M->ticks[2] = S.bc[4];
 #endif
     M->ticks[1] = S.bc[3];              /* summed over waves: busy, of which first sort */
+#ifdef LDS_SORT_TICKS
+    M->ticks[1] = S.bc[1]; M->ticks[2] = S.bc[15];    /* batches ordered by the whole workgroup, and the time that took */
+#endif
   }
 }
 

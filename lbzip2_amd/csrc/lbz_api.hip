@@ -246,7 +246,7 @@ static int run_chunk(lbzamd_ctx *c, const u8 *d_in, size_t len, uint32_t nsl, in
       hipLaunchKernelGGL(k_collect, dim3(count), dim3(LBZ_COLLECT_WG), 0, q, d_in, (u64)len, c->L, c->T, c->meta, first, nullptr, nullptr);
       if (timed_end(c, &nbev, q)) return -1;
       if (timed_begin(c, &nbev, 0, q)) return -1;
-      if (count > c->ncus)
+      if (LBZ_BWT_WG >= 1024 && count > c->ncus)      /* 512-thread workgroups share a CU two by two at 128 VGPRs already */
         hipLaunchKernelGGL(k_bwt_part2, dim3(grid), dim3(LBZ_BWT_WG), 0, q, (const u8 *)c->T, c->meta, c->L,
                            first, count, ws, (u64)c->slot_bytes, wsp, (u64)c->spill_bytes, nullptr);
       else
@@ -617,7 +617,7 @@ static void pool_round(wu_pool *p, const std::vector<wu_req *> &batch)
       /* primaries only (grid = count): what collect() left over went back to the caller */
       const u32 count = (u32)(lb.size() - o < c->nslots ? lb.size() - o : c->nslots);
       const u32 *lst = p->d_list[1] + o;
-      if (count > c->ncus)
+      if (LBZ_BWT_WG >= 1024 && count > c->ncus)
         hipLaunchKernelGGL(k_bwt_part2, dim3(count), dim3(LBZ_BWT_WG), 0, p->q, (const u8 *)c->T, c->meta, c->L, 0u, count,
                            ws, (u64)c->slot_bytes, wsp, (u64)c->spill_bytes, lst);
       else
