@@ -75,6 +75,11 @@
 #define REFINE_ROUNDS 12u                /* in-LDS refinements of a batch before rows are left to the doubling */
 #endif
 #define TIE_FLAG 0x80000000u
+/* a suffix-array / tie-list entry: rotation index (n < 2^20) | dense code of the byte before it << 20 | TIE_FLAG.
+   The byte rides along so that a row that becomes unique needs no look-up in the text.          */
+#define SA_IDX(v) ((v) & 0x000FFFFFu)
+#define SA_CODE(v) (((v) >> 20) & 255u)
+#define SA_ENTRY(idx, code) ((idx) | ((u32)(code) << 20))
 static_assert(BATCH_CAP == LBZ_WG * 4u, "a batch is one 4-rows-per-thread tile");
 
 struct sort_lds {                       /* HBM radix passes (partition, oversized groups, doubling) */
@@ -255,7 +260,7 @@ __device__ u32 wg_regroup(const u64 *key, const u32 *val, u32 rowbase, u32 out_b
         if (k < m && !(vv[i] & TIE_FLAG)) headmask |= 1u << i;
         const u32 vn = (i + 1u < SORT_IPT) ? vv[(i + 1u) % SORT_IPT] : vnext;
         if (k + 1u >= m || !(vn & TIE_FLAG)) nextmask |= 1u << i;
-        vv[i] &= 0x00FFFFFFu;
+        vv[i] &= 0x0FFFFFFFu;                                  /* index + code of the preceding byte */
       }
     } else {
       u64 kk[SORT_IPT + 2];
@@ -295,14 +300,14 @@ __device__ u32 wg_regroup(const u64 *key, const u32 *val, u32 rowbase, u32 out_b
       if (k < m) {
         if ((headmask >> i) & 1u) rank1 = row[i] + 1u;
         if (!FLAGS) s.sa[row[i]] = vv[i];
-        if (row[i] < isa_below) s.isa[vv[i]] = rank1 - 1u;       /* rows from isa_below on got their rank in k_bwt_batch */
+        if (row[i] < isa_below) s.isa[SA_IDX(vv[i])] = rank1 - 1u;       /* rows from isa_below on got their rank in k_bwt_batch */
         if ((actmask >> i) & 1u) {
           s.sufx[o] = vv[i];
           s.grp[o] = rank1 - 1u;
           s.pos[o] = row[i];
           o++;
         } else if (bwt) {
-          bwt[row[i]] = T[vv[i] ? vv[i] - 1u : n - 1u];
+          bwt[row[i]] = S->inv[SA_CODE(vv[i])];
         }
       }
     }
@@ -870,7 +875,7 @@ __device__ void wave_finish_chunk(batch_lds *B, u32 cs, u32 ce, bool need_sort, 
     const u32 idx = v & 0x00FFFFFFu;
     const bool flagged = B->tied[j] && B->gh[j] != j;
     bwt[lo + j] = S->inv[v >> 24];
-    sa[lo + j] = idx | (flagged ? TIE_FLAG : 0u);
+    sa[lo + j] = SA_ENTRY(idx, v >> 24) | (flagged ? TIE_FLAG : 0u);
     /* rank of the rotation = first row of its run.  k_bwt_fix needs it for every rotation of a block
        with deep ties; written here, these scattered stores ride under a kernel that is bound by LDS work,
        instead of being a pass of their own in a kernel that is bound by scattered HBM traffic.  Only once
@@ -1045,7 +1050,7 @@ __device__ void emit_tied_rows(u8 *bwt, bwt_slot s, bwt_lds *S, u32 lo, u32 hi)
   for (u32 j = lo + threadIdx.x; j < hi; j += LBZ_WG) {
     const u32 v = s.v0[j];
     bwt[j] = S->inv[v >> 24];
-    s.sa[j] = (v & 0x00FFFFFFu) | (j > lo ? TIE_FLAG : 0u);
+    s.sa[j] = SA_ENTRY(v & 0x00FFFFFFu, v >> 24) | (j > lo ? TIE_FLAG : 0u);
     s.isa[v & 0x00FFFFFFu] = lo;
   }
   if (threadIdx.x == 0) S->bc[8] = 1u;
@@ -1139,7 +1144,7 @@ __device__ u32 doubling_round(const u8 *T, u32 n, u8 *bwt, bwt_slot s, bwt_lds *
         __syncthreads();
         for (u32 i = tid; i < g; i += LBZ_WG) {
           const u32 sf = s.sufx[k0 + i];
-          u32 t = sf + h;
+          u32 t = SA_IDX(sf) + h;
           if (t >= n) t -= n;
           s.k0[i] = (u64)s.isa[t];
           s.v0[i] = sf;
@@ -1157,7 +1162,7 @@ __device__ u32 doubling_round(const u8 *T, u32 n, u8 *bwt, bwt_slot s, bwt_lds *
     if (tid == 0) { S->bc[7] = 0; S->bc[6] = 0; }        /* chunk tickets of the two phases */
     for (u32 i = tid; i < cnt; i += LBZ_WG) {
       const u32 sf = s.sufx[k0 + i];
-      u32 t = sf + h;
+      u32 t = SA_IDX(sf) + h;
       if (t >= n) t -= n;
       B->kA[i] = (u64)s.isa[t];
       B->vA[i] = sf;
@@ -1217,12 +1222,12 @@ __device__ u32 doubling_round(const u8 *T, u32 n, u8 *bwt, bwt_slot s, bwt_lds *
           /* the suffix array itself is not read again: ranks (isa) and the list carry the rounds, the
              BWT byte of a row that became unique is written below */
           const u32 nh = B->gh[j];
-          if (!((B->oldhead[nh >> 5] >> (nh & 31u)) & 1u)) s.isa[sf] = newrank;
+          if (!((B->oldhead[nh >> 5] >> (nh & 31u)) & 1u)) s.isa[SA_IDX(sf)] = newrank;
           if (td) {
             const u32 o = off + (u32)__popcll(mask & lanes_below());
             s.sufx[o] = sf; s.grp[o] = newrank; s.pos[o] = row;
           } else {
-            bwt[row] = T[sf ? sf - 1u : n - 1u];
+            bwt[row] = S->inv[SA_CODE(sf)];
           }
         }
         off += (u32)__popcll(mask);
@@ -1255,7 +1260,7 @@ __device__ void finish_by_doubling(const u8 *T, u32 n, u8 *bwt, lbz_block_meta *
   /* rows that are tied for good (exactly periodic block): their bytes are all equal anyway */
   for (u32 k = tid; k < m; k += LBZ_WG) {
     const u32 sf = s.sufx[k];
-    bwt[s.pos[k]] = T[sf ? sf - 1u : n - 1u];
+    bwt[s.pos[k]] = S->inv[SA_CODE(sf)];
   }
   if (tid == 0) {
     meta->bwt_idx = s.isa[0];
