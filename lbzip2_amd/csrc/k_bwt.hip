@@ -110,6 +110,7 @@ struct bwt_lds {
   wg_scratch sc;
   u32 bc[16];
   u32 isa_from, tied0;                /* k_bwt_batch: rows from isa_from on get their rank written with them; tied0 = rows tied on their first key so far */
+  u32 dbg[4];                         /* LDS_SORT_TICKS: whole-workgroup batch sorts (count, ticks), oversized groups (count, ticks) */
   u8 cmap[256];                       /* byte -> dense code */
   u8 inv[256];                        /* dense code -> byte */
   union {
@@ -1003,7 +1004,7 @@ __device__ u32 batch_process(const u8 *T, u32 n, u8 *bwt, lbz_block_meta *meta, 
     need_sort = false;
     batch_runs(B, B->kA, cnt, 0u, &maxrun, S);
 #ifdef LDS_SORT_TICKS
-    if (tid == 0) { S->bc[15] += (u32)(wall_clock64() - tl0); S->bc[1] += 1u; }
+    if (tid == 0) { S->dbg[1] += (u32)(wall_clock64() - tl0); S->dbg[0] += 1u; }
 #endif
   }
   if (need_sort && maxrun > SPLIT_MIN) {
@@ -1299,6 +1300,7 @@ struct part_lds {
   wg_scratch sc;
   u32 bc[16];
   u32 isa_from, tied0;
+  u32 dbg[4];
   u8 cmap[256];
   u8 inv[256];
   sort_lds X;
@@ -1376,7 +1378,7 @@ k_bwt_batch(const u8 *Tbase, u8 *Bbase, lbz_block_meta *meta, lbz_layout L, u32 
   }
   const u64 tk0 = wall_clock64();
   const keycfg c = bwt_setup(M, &S);
-  if (tid == 0) { S.isa_from = n; S.tied0 = 0; }
+  if (tid == 0) { S.isa_from = n; S.tied0 = 0; for (u32 i = 0; i < 4; i++) S.dbg[i] = 0; }
   __syncthreads();
   if (n <= BATCH_CAP) {
     batch_lds *B = &S.u.B;
@@ -1399,8 +1401,14 @@ k_bwt_batch(const u8 *Tbase, u8 *Bbase, lbz_block_meta *meta, lbz_layout L, u32 
       const u32 want = n - pos < BATCH_CAP ? n - pos : BATCH_CAP;
       const u32 used = batch_process(T, n, bwt, M, s, &S, c, pos, want, false, false, true);
       if (used == 0u) {                          /* one group fills the batch: sort it in HBM first */
+#ifdef LDS_SORT_TICKS
+        const u64 tg0 = wall_clock64();
+#endif
         const u32 end = find_run_end(s.k0, pos, pos + want, n, MSD_SHIFT, &S);
         big_group(T, n, bwt, M, s, &S, c, pos, end);
+#ifdef LDS_SORT_TICKS
+        if (tid == 0) { S.dbg[3] += (u32)(wall_clock64() - tg0); S.dbg[2] += end - pos; }
+#endif
         pos = end;
         continue;
       }
@@ -1426,7 +1434,7 @@ k_bwt_batch(const u8 *Tbase, u8 *Bbase, lbz_block_meta *meta, lbz_layout L, u32 
 #endif
     M->ticks[1] = S.bc[3];              /* summed over waves: busy, of which first sort */
 #ifdef LDS_SORT_TICKS
-    M->ticks[1] = S.bc[1]; M->ticks[2] = S.bc[15];    /* batches ordered by the whole workgroup, and the time that took */
+    M->ticks[1] = S.dbg[0]; M->ticks[2] = S.dbg[1]; M->ticks[6] = S.dbg[2]; M->ticks[7] = S.dbg[3];
 #endif
   }
 }

@@ -1,6 +1,18 @@
 #!/bin/bash
 cd /root/repo
 export PYTHONPATH=/root/repo:/root/repo/tests
-LBZ_SLOTS=601 bash tests/gpu_var.sh wiki,tar,text 1112 default 2>&1 | grep -v amdgpu | cut -c1-130
-LBZ_LEVEL=1 LBZ_SEED=3 LBZ_SLOTS=1024 timeout 200 python tests/quickperf.py 2000 mixed 2>&1 | grep "MB/s"
-timeout 300 python -m pytest tests/test_gpu_parity.py -x -q -m gpu -k "fuzz or corpora or repetitive or small or ragged or round_schedule or periodic or literal or seeded or levels" 2>&1 | tail -1
+cat > /tmp/t3.py <<'PY'
+import os, sys
+sys.path.insert(0, "/root/repo"); sys.path.insert(0, "/root/repo/tests")
+import lbzip2_amd, oracle_lib as L
+lbzip2_amd.LIB_PATH = "/root/repo/lbzip2_amd/csrc/variants/ldst.so"
+lib = lbzip2_amd.library()
+for kind in ("wiki", "tar", "text"):
+    data = bytes(L.gen_kind(kind, 512 * 900000, 2))
+    with lib.context(9, 512) as ctx:
+        ctx.run_stages(data, 1)
+        for b in (0, 2):
+            bi = ctx.block_info(b); t = list(bi.ticks)
+            print(kind, "blk", b, "batch: load %.2f scan %.2f waves %.2f | whole-workgroup sorts: %d batches %.2f ms | oversized groups: %d rows (%.1f%%) %.2f ms" % (t[3]/1e5, t[4]/1e5, t[5]/1e5, t[1], t[2]/1e5, t[6], 100.0*t[6]/bi.n, t[7]/1e5), flush=True)
+PY
+timeout 120 python /tmp/t3.py 2>&1 | grep blk
