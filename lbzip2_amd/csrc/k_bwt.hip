@@ -1075,18 +1075,31 @@ __device__ u32 find_cut(const K *keys, u32 pos, u32 e, u32 sh, bwt_lds *S)
   return found;
 }
 
-/* first q in [from, hi) whose key differs from row pos after `>> sh`; hi if none */
+/* first q in [from, hi) whose key differs from row pos after `>> sh`; hi if none.  The keys are sorted on
+ * the bits above sh, so this is a search for a boundary: LBZ_WG probes spread evenly over the range narrow
+ * it to 1/LBZ_WG per step (three steps for a whole block) instead of a scan of LBZ_WG rows per step.   */
 template <class K>
 __device__ u32 find_run_end(const K *keys, u32 pos, u32 from, u32 hi, u32 sh, bwt_lds *S)
 {
   const K k = keys[pos] >> sh;
-  for (u32 base = from; base < hi; base += LBZ_WG) {
-    const u32 q = base + threadIdx.x;
-    const u32 cand = (q < hi && (keys[q] >> sh) != k) ? q : 0xFFFFFFFFu;
-    const u32 f = wg_min(cand, &S->sc);
-    if (f != 0xFFFFFFFFu) return f;
+  u32 a = from, b = hi;                         /* invariant: rows < a belong to the run, row b (or hi) does not */
+  while (a < b) {
+    const u32 span = b - a;
+    const u32 step = (span + LBZ_WG - 1u) / LBZ_WG;           /* probe i looks at row a + i * step */
+    const u32 q = a + threadIdx.x * step;
+    const u32 cand = (q < b && (keys[q] >> sh) != k) ? threadIdx.x : 0xFFFFFFFFu;
+    const u32 f = wg_min(cand, &S->sc);                       /* first probe outside the run */
+    if (f == 0xFFFFFFFFu) {                                   /* every probe inside: the boundary is behind the last probe */
+      const u32 last = a + ((span - 1u) / step) * step;
+      a = last + 1u;
+    } else {
+      b = a + f * step;
+      a = f ? a + (f - 1u) * step + 1u : a;
+      if (f == 0u) { b = a; }
+    }
+    if (step == 1u) break;
   }
-  return hi;
+  return b < hi ? b : hi;
 }
 
 /* An oversized group [lo,hi) (> BATCH_CAP rows with equal top MSD_BITS): HBM radix sort on the
@@ -1251,7 +1264,7 @@ __device__ void finish_by_doubling(const u8 *T, u32 n, u8 *bwt, lbz_block_meta *
   const u32 tid = threadIdx.x;
   const u64 tk0 = wall_clock64();
   u32 m = wg_regroup<true>(nullptr, s.sa, 0u, 0u, n, s, S, T, n, nullptr, meta->isa_from);
-  if (tid == 0) { meta->ticks[6] = (u32)(wall_clock64() - tk0); meta->ticks[1] = m; }
+  if (tid == 0) { meta->fticks[6] = (u32)(wall_clock64() - tk0); meta->fticks[1] = m; }
   u32 rounds = 0, work = 0;
   for (u32 h = h0; m > 0u && h < n; h <<= 1) {
     work += m;
@@ -1266,7 +1279,7 @@ __device__ void finish_by_doubling(const u8 *T, u32 n, u8 *bwt, lbz_block_meta *
   if (tid == 0) {
     meta->bwt_idx = s.isa[0];
     meta->periodic = m > 0u ? 1u : 0u;
-    meta->ticks[7] = (u32)(wall_clock64() - tk0);
+    meta->fticks[7] = (u32)(wall_clock64() - tk0);
   }
   *rounds_out = rounds;
   *work_out = work;
@@ -1434,7 +1447,7 @@ k_bwt_batch(const u8 *Tbase, u8 *Bbase, lbz_block_meta *meta, lbz_layout L, u32 
 #endif
     M->ticks[1] = S.bc[3];              /* summed over waves: busy, of which first sort */
 #ifdef LDS_SORT_TICKS
-    M->ticks[1] = S.dbg[0]; M->ticks[2] = S.dbg[1]; M->ticks[6] = S.dbg[2]; M->ticks[7] = S.dbg[3];
+    M->ticks[1] = S.dbg[0]; M->ticks[2] = S.dbg[1]; M->ticks[6] = S.dbg[2]; M->ticks[7] = S.dbg[3]; M->rounds = S.bc[15];
 #endif
   }
 }
@@ -1456,7 +1469,7 @@ k_bwt_fix(const u8 *Tbase, u8 *Bbase, lbz_block_meta *meta, lbz_layout L, u32 fi
   finish_by_doubling(Tbase + off, n, Bbase + off, M, s, &S, c.sy, &rounds, &work);
   if (threadIdx.x == 0) {
     M->rounds = rounds; M->sort_elems = n + work;
-    M->ticks[0] = S.bc[14];                                   /* LDS batches of the doubling rounds */
-    for (u32 i = 0; i < 4; i++) M->ticks[2 + i] = S.bc[10 + i];  /* load, run scan, per-wave sort, write-back */
+    M->fticks[0] = S.bc[14];                                   /* LDS batches of the doubling rounds */
+    for (u32 i = 0; i < 4; i++) M->fticks[2 + i] = S.bc[10 + i];  /* load, run scan, per-wave sort, write-back */
   }
 }
