@@ -315,6 +315,13 @@ def test_fuzz_vs_oracle(lib):
     assert fuzz_gpu.run(lib, L.orc_compress, 12, 4, big=True) == []
 
 
+def test_fuzz_workload_slices_vs_reference(lib):
+    """Random slices and splices of the workload generators (deep ties, oversized groups, verbatim
+    duplicates) against the compiled reference (tests/fuzz_corpora_gpu.py)."""
+    import fuzz_corpora_gpu
+    assert fuzz_corpora_gpu.run(lib, L, 31, 10) == []
+
+
 def test_device_resident_api(lib):
     import torch
     data = gen("text", 3_000_000, 8)
