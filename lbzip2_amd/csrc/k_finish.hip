@@ -104,3 +104,14 @@ k_gather(const u8 *Obase, const lbz_block_meta *meta, lbz_layout L, const u64 *o
   const u32 done = h + 4u * nw;
   if (threadIdx.x < len - done) dst[done + threadIdx.x] = src[done + threadIdx.x];
 }
+
+/* work-unit rounds: the four words a caller waits for, of the listed slabs' primary blocks, packed for one
+ * small device-to-host copy (instead of the records of the whole pool) */
+__global__ void __launch_bounds__(256)
+k_meta_pick(const lbz_block_meta *meta, const u32 *slabs, u32 count, u32 *out)
+{
+  const u32 i = blockIdx.x * 256u + threadIdx.x;
+  if (i >= count) return;
+  const lbz_block_meta *m = &meta[2u * slabs[i]];
+  out[4u * i] = m->consumed; out[4u * i + 1u] = m->out_len; out[4u * i + 2u] = m->crc; out[4u * i + 3u] = m->err;
+}

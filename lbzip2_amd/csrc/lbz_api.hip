@@ -85,7 +85,16 @@ static int ctx_free(lbzamd_ctx *c)
 
 extern "C" void lbzamd_destroy(lbzamd_ctx *c) { ctx_free(c); }
 
+static int ctx_create(lbzamd_ctx **out, int device, unsigned bs100k, unsigned max_slabs, unsigned nslots, unsigned force_streams);
+
 extern "C" int lbzamd_create(lbzamd_ctx **out, int device, unsigned bs100k, unsigned max_slabs, unsigned nslots)
+{
+  return ctx_create(out, device, bs100k, max_slabs, nslots, 0u);
+}
+
+/* force_streams != 0: that many round streams (and slot sets) whatever the environment says -- the
+ * work-unit pool runs its rounds on one stream and must not pay for a second set of BWT workspaces */
+static int ctx_create(lbzamd_ctx **out, int device, unsigned bs100k, unsigned max_slabs, unsigned nslots, unsigned force_streams)
 {
   if (!out || bs100k < 1 || bs100k > 9 || max_slabs < 1) { g_err = "lbzamd_create: bad argument"; return -1; }
   int ndev = 0;
@@ -114,6 +123,7 @@ extern "C" int lbzamd_create(lbzamd_ctx **out, int device, unsigned bs100k, unsi
     c->nstreams = env ? (unsigned)atoi(env) : 2u;
     if (c->nstreams < 1u) c->nstreams = 1u;
     if (c->nstreams > 8u) c->nstreams = 8u;
+    if (force_streams) c->nstreams = force_streams;
   }
   if (nslots == 0) {
     /* Slabs per round.  At least one full-size block per CU; with several streams the slabs of a
@@ -550,18 +560,22 @@ struct wu_req {
   uint32_t consumed, out_len, crc, err;       /* the block record as of the round that served the request */
 };
 
+struct wu_lane {                      /* one kind of request (0 = collect, 1 = encode): its own queue, leader and stream */
+  hipStream_t q = nullptr;            /* non-blocking: no ties to the null stream */
+  u32 *d_list = nullptr, *d_len = nullptr, *d_pick = nullptr;
+  u32 *h_pick = nullptr;              /* pinned: {consumed, out_len, crc, err} per request of the round */
+  std::vector<wu_req *> pending;
+  bool leader = false;
+};
+
 struct wu_pool {
   lbzamd_ctx *c = nullptr;    /* P resident slabs, staging for P slabs of input */
   uint32_t P = 0;
-  hipStream_t q = nullptr;    /* non-blocking: no ties to the null stream */
-  u32 *d_list[2] = { nullptr, nullptr }, *d_len = nullptr;
+  wu_lane lane[2];
   u8 *h_in = nullptr, *h_out = nullptr;   /* pinned staging, one slab each: callers fill / drain it in parallel, the leader's copies are pure DMA */
   std::mutex mu;
   std::condition_variable cv;
   std::vector<uint32_t> free_slabs;
-  std::vector<wu_req *> pending;
-  bool leader = false;
-  std::vector<lbz_block_meta> h_meta;         /* block records as of the last round that touched them */
 };
 
 static std::mutex g_pools_mu;
@@ -573,110 +587,106 @@ static wu_pool *pool_for(unsigned bs100k)
   if (g_pools[bs100k]) return g_pools[bs100k];
   wu_pool *p = new wu_pool;
   const char *env = getenv("LBZAMD_POOL_SLABS");
-  p->P = env ? (uint32_t)atoi(env) : 512u;
+  p->P = env ? (uint32_t)atoi(env) : 1024u;
   if (p->P < 1u) p->P = 1u;
-  if (lbzamd_create(&p->c, -1, bs100k, p->P, p->P < 256u ? p->P : 256u)) die("cannot create the work-unit pool");
+  /* one slot set: encode rounds run one at a time, up to 512 blocks (two per CU) each */
+  if (ctx_create(&p->c, -1, bs100k, p->P, p->P < 512u ? p->P : 512u, 1u)) die("cannot create the work-unit pool");
   lbzamd_ctx *c = p->c;
   if (ensure_staging(c, (size_t)p->P * c->L.M, 0)) die("work-unit pool staging");
-  HIPDIE(hipStreamCreateWithFlags(&p->q, hipStreamNonBlocking), "pool");
-  for (int i = 0; i < 2; i++) HIPDIE(hipMalloc((void **)&p->d_list[i], p->P * sizeof(u32)), "pool");
-  HIPDIE(hipMalloc((void **)&p->d_len, p->P * sizeof(u32)), "pool");
+  for (wu_lane &l : p->lane) {
+    HIPDIE(hipStreamCreateWithFlags(&l.q, hipStreamNonBlocking), "pool");
+    HIPDIE(hipMalloc((void **)&l.d_list, p->P * sizeof(u32)), "pool");
+    HIPDIE(hipMalloc((void **)&l.d_len, p->P * sizeof(u32)), "pool");
+    HIPDIE(hipMalloc((void **)&l.d_pick, p->P * 4u * sizeof(u32)), "pool");
+    HIPDIE(hipHostMalloc((void **)&l.h_pick, p->P * 4u * sizeof(u32), hipHostMallocDefault), "pool");
+  }
   HIPDIE(hipHostMalloc((void **)&p->h_in, (size_t)p->P * c->L.M, hipHostMallocDefault), "pool");
   HIPDIE(hipHostMalloc((void **)&p->h_out, (size_t)p->P * c->L.out_a, hipHostMallocDefault), "pool");
-  p->h_meta.resize(2u * (size_t)p->P);
   for (uint32_t i = p->P; i-- > 0;) p->free_slabs.push_back(i);
   g_pools[bs100k] = p;
   return p;
 }
 
-/* One round: every posted collect, then every posted encode (a state's two calls never share a
- * round: encode() is only posted after collect() has returned).                             */
-static void pool_round(wu_pool *p, const std::vector<wu_req *> &batch)
+/* One round of one lane.  Collect rounds (H2D of the callers' slabs, k_collect) and encode rounds (the BWT,
+ * MTF and coding kernels over the listed blocks, then the packed blocks D2H) run on their own streams with
+ * their own leaders: a collect round touches only slabs whose states are in collect(), an encode round only
+ * slabs whose states are in encode(), so the two overlap -- while the device works through an encode round, the
+ * callers whose transmit() returned are already collecting, and the next encode round is full when this one ends. */
+static void pool_round(wu_pool *p, int stage, const std::vector<wu_req *> &batch)
 {
   lbzamd_ctx *c = p->c;
+  wu_lane &ln = p->lane[stage];
   HIPDIE(hipSetDevice(c->device), "work-unit round");
-  std::vector<u32> la, len, lb;
+  std::vector<u32> list, len;
   for (wu_req *r : batch) {
-    if (r->stage == 0) {
-      la.push_back(r->slab); len.push_back(r->len);
-      HIPDIE(hipMemcpyAsync(c->d_in + (size_t)r->slab * c->L.M, p->h_in + (size_t)r->slab * c->L.M, r->len, hipMemcpyHostToDevice, p->q), "collect");
-    } else {
-      lb.push_back(r->slab);
+    list.push_back(r->slab);
+    if (stage == 0) {
+      len.push_back(r->len);
+      HIPDIE(hipMemcpyAsync(c->d_in + (size_t)r->slab * c->L.M, p->h_in + (size_t)r->slab * c->L.M, r->len, hipMemcpyHostToDevice, ln.q), "collect");
     }
   }
-  if (!la.empty()) {
-    HIPDIE(hipMemcpyAsync(p->d_list[0], la.data(), la.size() * sizeof(u32), hipMemcpyHostToDevice, p->q), "collect");
-    HIPDIE(hipMemcpyAsync(p->d_len, len.data(), len.size() * sizeof(u32), hipMemcpyHostToDevice, p->q), "collect");
-    hipLaunchKernelGGL(k_collect, dim3((u32)la.size()), dim3(LBZ_COLLECT_WG), 0, p->q, (const u8 *)c->d_in,
-                       (u64)p->P * c->L.M, c->L, c->T, c->meta, 0u, (const u32 *)p->d_list[0], (const u32 *)p->d_len);
-  }
-  if (!lb.empty()) {
-    HIPDIE(hipMemcpyAsync(p->d_list[1], lb.data(), lb.size() * sizeof(u32), hipMemcpyHostToDevice, p->q), "encode");
+  const u32 cnt = (u32)list.size();
+  HIPDIE(hipMemcpyAsync(ln.d_list, list.data(), cnt * sizeof(u32), hipMemcpyHostToDevice, ln.q), "round");
+  if (stage == 0) {
+    HIPDIE(hipMemcpyAsync(ln.d_len, len.data(), cnt * sizeof(u32), hipMemcpyHostToDevice, ln.q), "collect");
+    hipLaunchKernelGGL(k_collect, dim3(cnt), dim3(LBZ_COLLECT_WG), 0, ln.q, (const u8 *)c->d_in,
+                       (u64)p->P * c->L.M, c->L, c->T, c->meta, 0u, (const u32 *)ln.d_list, (const u32 *)ln.d_len);
+  } else {
     u8 *ws = c->ws, *wsp = c->ws + (size_t)c->nslots * c->slot_bytes;
-    for (size_t o = 0; o < lb.size(); o += c->nslots) {
+    for (u32 o = 0; o < cnt; o += c->nslots) {
       /* primaries only (grid = count): what collect() left over went back to the caller */
-      const u32 count = (u32)(lb.size() - o < c->nslots ? lb.size() - o : c->nslots);
-      const u32 *lst = p->d_list[1] + o;
+      const u32 count = cnt - o < c->nslots ? cnt - o : c->nslots;
+      const u32 *lst = ln.d_list + o;
       if (LBZ_BWT_WG >= 1024 && count > c->ncus)
-        hipLaunchKernelGGL(k_bwt_part2, dim3(count), dim3(LBZ_BWT_WG), 0, p->q, (const u8 *)c->T, c->meta, c->L, 0u, count,
+        hipLaunchKernelGGL(k_bwt_part2, dim3(count), dim3(LBZ_BWT_WG), 0, ln.q, (const u8 *)c->T, c->meta, c->L, 0u, count,
                            ws, (u64)c->slot_bytes, wsp, (u64)c->spill_bytes, lst);
       else
-        hipLaunchKernelGGL(k_bwt_part, dim3(count), dim3(LBZ_BWT_WG), 0, p->q, (const u8 *)c->T, c->meta, c->L, 0u, count,
+        hipLaunchKernelGGL(k_bwt_part, dim3(count), dim3(LBZ_BWT_WG), 0, ln.q, (const u8 *)c->T, c->meta, c->L, 0u, count,
                            ws, (u64)c->slot_bytes, wsp, (u64)c->spill_bytes, lst);
-      hipLaunchKernelGGL(k_bwt_batch, dim3(count), dim3(LBZ_BWT_WG), 0, p->q, (const u8 *)c->T, c->B, c->meta, c->L, 0u, count,
+      hipLaunchKernelGGL(k_bwt_batch, dim3(count), dim3(LBZ_BWT_WG), 0, ln.q, (const u8 *)c->T, c->B, c->meta, c->L, 0u, count,
                          ws, (u64)c->slot_bytes, wsp, (u64)c->spill_bytes, lst);
-      hipLaunchKernelGGL(k_bwt_fix, dim3(count), dim3(LBZ_BWT_WG), 0, p->q, (const u8 *)c->T, c->B, c->meta, c->L, 0u, count,
+      hipLaunchKernelGGL(k_bwt_fix, dim3(count), dim3(LBZ_BWT_WG), 0, ln.q, (const u8 *)c->T, c->B, c->meta, c->L, 0u, count,
                          ws, (u64)c->slot_bytes, wsp, (u64)c->spill_bytes, lst);
-      hipLaunchKernelGGL(k_mtf, dim3(count), dim3(LBZ_WG), 0, p->q, (const u8 *)c->B, c->R, c->V, c->freq, c->meta, c->L, 0u, count, lst);
-      hipLaunchKernelGGL(k_encode, dim3(count), dim3(LBZ_WG), 0, p->q, (const u16 *)c->V, (const u32 *)c->freq, c->O, c->meta, c->L, 0u, count, lst);
+      hipLaunchKernelGGL(k_mtf, dim3(count), dim3(LBZ_WG), 0, ln.q, (const u8 *)c->B, c->R, c->V, c->freq, c->meta, c->L, 0u, count, lst);
+      hipLaunchKernelGGL(k_encode, dim3(count), dim3(LBZ_WG), 0, ln.q, (const u16 *)c->V, (const u32 *)c->freq, c->O, c->meta, c->L, 0u, count, lst);
     }
   }
-  /* the block records of the whole pool in one copy (a few hundred KB) */
-  HIPDIE(hipMemcpyAsync(p->h_meta.data(), c->meta, p->h_meta.size() * sizeof(lbz_block_meta), hipMemcpyDeviceToHost, p->q), "round");
-  HIPDIE(hipStreamSynchronize(p->q), "round");
+  /* the four words each caller waits for, packed on the device: one small copy */
+  hipLaunchKernelGGL(k_meta_pick, dim3((cnt + 255u) / 256u), dim3(256), 0, ln.q, (const lbz_block_meta *)c->meta, (const u32 *)ln.d_list, cnt, ln.d_pick);
+  HIPDIE(hipMemcpyAsync(ln.h_pick, ln.d_pick, (size_t)cnt * 4u * sizeof(u32), hipMemcpyDeviceToHost, ln.q), "round");
+  HIPDIE(hipStreamSynchronize(ln.q), "round");
   HIPDIE(hipGetLastError(), "round");
-  if (!lb.empty()) {
+  for (u32 i = 0; i < cnt; i++) {
+    wu_req *b = batch[i];
+    b->consumed = ln.h_pick[4u * i]; b->out_len = ln.h_pick[4u * i + 1u]; b->crc = ln.h_pick[4u * i + 2u]; b->err = ln.h_pick[4u * i + 3u];
+  }
+  if (stage == 1) {
     /* the packed blocks, now that their sizes are known: DMA into the pinned staging area */
-    for (u32 sl : lb) {
-      const size_t bytes = ((size_t)p->h_meta[2u * sl].out_len + 3u) / 4u * 4u;
-      HIPDIE(hipMemcpyAsync(p->h_out + (size_t)sl * c->L.out_a, c->O + lbz_out_off(c->L, 2u * sl), bytes, hipMemcpyDeviceToHost, p->q), "round");
+    for (wu_req *b : batch) {
+      const size_t bytes = ((size_t)b->out_len + 3u) / 4u * 4u;
+      HIPDIE(hipMemcpyAsync(p->h_out + (size_t)b->slab * c->L.out_a, c->O + lbz_out_off(c->L, 2u * b->slab), bytes, hipMemcpyDeviceToHost, ln.q), "round");
     }
-    HIPDIE(hipStreamSynchronize(p->q), "round");
+    HIPDIE(hipStreamSynchronize(ln.q), "round");
   }
 }
 
-/* post a request and return when it is done; whoever finds no leader leads */
+/* post a request and return when it is done; whoever finds its lane without a leader leads one round of it */
 static void pool_submit(wu_pool *p, wu_req *r)
 {
   std::unique_lock<std::mutex> lk(p->mu);
+  wu_lane &ln = p->lane[r->stage];
   r->done = false;
-  p->pending.push_back(r);
+  ln.pending.push_back(r);
   while (!r->done) {
-    if (!p->leader) {
-      p->leader = true;
-      /* Collects first, on their own: they are short, and every caller whose collect returns
-         posts its encode right away -- so by the time no collect is waiting, the encode round
-         (which costs the same for one block as for a few hundred) has filled up.           */
+    if (!ln.leader) {
+      ln.leader = true;
       std::vector<wu_req *> batch;
-      bool any_collect = false;
-      for (wu_req *x : p->pending) any_collect |= x->stage == 0;
-      if (any_collect) {
-        std::vector<wu_req *> rest;
-        for (wu_req *x : p->pending) (x->stage == 0 ? batch : rest).push_back(x);
-        p->pending.swap(rest);
-      } else {
-        batch.swap(p->pending);
-      }
+      batch.swap(ln.pending);
       lk.unlock();
-      pool_round(p, batch);
+      pool_round(p, r->stage, batch);
       lk.lock();
-      for (wu_req *b : batch) {
-        /* taken here, under the lock: the next round's copy of the records may already be under way */
-        const lbz_block_meta &m = p->h_meta[2u * b->slab];
-        b->consumed = m.consumed; b->out_len = m.out_len; b->crc = m.crc; b->err = m.err;
-        b->done = true;
-      }
-      p->leader = false;
+      for (wu_req *b : batch) b->done = true;
+      ln.leader = false;
       p->cv.notify_all();
     } else {
       p->cv.wait(lk);

@@ -38,6 +38,8 @@ __global__ void k_offsets(const lbz_block_meta *meta, u32 nblk, u32 bs100k, u32 
 __global__ void k_gather(const u8 *Obase, const lbz_block_meta *meta, lbz_layout L, const u64 *offs,
                          const lbz_stream_state *st, u8 *out, u32 nslabs);
 
+__global__ void k_meta_pick(const lbz_block_meta *meta, const u32 *slabs, u32 count, u32 *out);
+
 __device__ __forceinline__ u32 lbz_queue_block(u32 q, u32 nslabs)      /* whole chunk: k_gather */
 {
   return q < nslabs ? 2u * q : 2u * (q - nslabs) + 1u;
