@@ -140,6 +140,25 @@ uint32_t lbzamd_slots(lbzamd_ctx *ctx);
  * fan out to internal side streams and are joined before the call's last kernels).          */
 void *lbzamd_stream(lbzamd_ctx *ctx);
 
+/* ------------------------------------------------------------------ (C) the inverse path
+ * Block-parallel decompression of complete .bz2 streams (one or several concatenated), the device-side
+ * counterpart of the reference's scan() src/parse.c:282, retrieve() src/decode.c:519, decode() :852 and
+ * emit() :944.  Every block of the input is decoded at once, one block per workgroup; block CRCs and the
+ * stream CRCs are checked.  max_blocks: blocks decoded per pass (more are taken in several passes).      */
+typedef struct lbzamd_dctx lbzamd_dctx;
+typedef struct lbzamd_dstats {
+  uint64_t n_in, n_out;
+  uint32_t nblocks, nstreams;
+  float ms_scan, ms_huff, ms_sort, ms_walk, ms_emit, ms_total;
+} lbzamd_dstats;
+int  lbzamd_dcreate(lbzamd_dctx **ctx, int device, unsigned max_blocks);
+void lbzamd_ddestroy(lbzamd_dctx *ctx);
+/* 0 ok; -1 bad argument / HIP error; -2 output buffer too small (*out_len = bytes needed);
+ * -3 malformed stream or CRC mismatch (lbzamd_last_error() says which block).                        */
+int  lbzamd_decompress_device(lbzamd_dctx *ctx, const void *d_in, size_t len, void *d_out, size_t out_cap, size_t *out_len);
+int  lbzamd_decompress_host(lbzamd_dctx *ctx, const uint8_t *in, size_t len, uint8_t *out, size_t out_cap, size_t *out_len);
+int  lbzamd_dget_stats(lbzamd_dctx *ctx, lbzamd_dstats *st);
+
 /* ---- stage access for parity tests (valid for the last chunk of the last call) ---- */
 typedef struct lbzamd_block_info {
   uint32_t n, crc, consumed, bwt_idx, periodic, nmtf, alpha, num_trees, num_sel, out_len, err, rounds;

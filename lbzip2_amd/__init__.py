@@ -13,7 +13,7 @@ lbzip2_amd/csrc/liblbzamd.so (built by hipcc for gfx950) and has no CPU implemen
 import os
 
 from ._binding import (CLUSTER_FACTOR, HEADER_SIZE, TRAILER_SIZE, STAGE_BWT, STAGE_MTFV, STAGE_OUT,
-                       STAGE_RLE, BlockInfo, Context, Encoder, EXPORTS, LbzError, Library, Part, Stats,
+                       STAGE_RLE, BlockInfo, Context, Decoder, DStats, Encoder, EXPORTS, LbzError, Library, Part, Stats,
                        combine_crc, fold_parts)
 
 LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", "liblbzamd.so")
@@ -36,6 +36,10 @@ def library() -> Library:
 
 def compress(data: bytes, level: int = 9) -> bytes:
     return library().compress(data, level)
+
+
+def decompress(data: bytes) -> bytes:
+    return library().decompress(data)
 
 
 def encoder_alloc_size(mbs: int) -> int:

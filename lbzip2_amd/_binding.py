@@ -23,6 +23,7 @@ EXPORTS = [
     "lbzamd_block_slots", "lbzamd_block_info_get", "lbzamd_read_stage", "lbzamd_run_stages",
     "lbzamd_compress_device_body", "lbzamd_compress_host_body", "lbzamd_fold_parts",
     "lbzamd_pinned_alloc", "lbzamd_pinned_free",
+    "lbzamd_dcreate", "lbzamd_ddestroy", "lbzamd_decompress_device", "lbzamd_decompress_host", "lbzamd_dget_stats",
 ]
 
 
@@ -51,6 +52,12 @@ def fold_parts(cc, parts):
         r = nblocks & 31
         cc = (((cc << r) | (cc >> (32 - r))) & 0xFFFFFFFF if r else cc) ^ fold
     return cc
+
+
+class DStats(C.Structure):
+    _fields_ = [("n_in", C.c_uint64), ("n_out", C.c_uint64), ("nblocks", C.c_uint32), ("nstreams", C.c_uint32),
+                ("ms_scan", C.c_float), ("ms_huff", C.c_float), ("ms_sort", C.c_float), ("ms_walk", C.c_float),
+                ("ms_emit", C.c_float), ("ms_total", C.c_float)]
 
 
 class BlockInfo(C.Structure):
@@ -106,6 +113,16 @@ class Library:
         lib.lbzamd_compress_host_body.restype = C.c_int
         lib.lbzamd_fold_parts.argtypes = [C.c_uint32, C.POINTER(Part), sz]
         lib.lbzamd_fold_parts.restype = C.c_uint32
+        lib.lbzamd_dcreate.argtypes = [C.POINTER(vp), C.c_int, C.c_uint]
+        lib.lbzamd_dcreate.restype = C.c_int
+        lib.lbzamd_ddestroy.argtypes = [vp]
+        lib.lbzamd_ddestroy.restype = None
+        lib.lbzamd_decompress_device.argtypes = [vp, vp, sz, vp, sz, szp]
+        lib.lbzamd_decompress_device.restype = C.c_int
+        lib.lbzamd_decompress_host.argtypes = [vp, vp, sz, vp, sz, szp]
+        lib.lbzamd_decompress_host.restype = C.c_int
+        lib.lbzamd_dget_stats.argtypes = [vp, C.POINTER(DStats)]
+        lib.lbzamd_dget_stats.restype = C.c_int
         lib.lbzamd_bound.argtypes = [sz]
         lib.lbzamd_bound.restype = sz
         lib.lbzamd_get_stats.argtypes = [vp, C.POINTER(Stats)]
@@ -134,6 +151,14 @@ class Library:
 
     def encoder(self, max_block_size):
         return Encoder(self, max_block_size)
+
+    def decoder(self, max_blocks=64, device=-1):
+        return Decoder(self, max_blocks, device)
+
+    def decompress(self, data, max_blocks=None):
+        """.bz2 bytes (one or several streams) -> bytes, block-parallel on the device."""
+        with self.decoder(max_blocks or max(1, min(4096, len(data) // 20000 + 8))) as d:
+            return d.decompress(data)
 
     # ---- whole-stream helpers -------------------------------------------------
     def compress(self, data, level=9, max_slabs=None):
@@ -305,6 +330,59 @@ class Context:
                            out=self.read_stage(blk, STAGE_OUT, bi.out_len))
             out.append(rec)
         return out
+
+
+class Decoder:
+    """The inverse path: every block of a stream decoded at once, one block per workgroup."""
+
+    def __init__(self, library, max_blocks=64, device=-1):
+        self.L = library
+        self.h = C.c_void_p()
+        if library.lib.lbzamd_dcreate(C.byref(self.h), device, max_blocks):
+            raise LbzError("lbzamd_dcreate: " + library.error())
+
+    def close(self):
+        if self.h:
+            self.L.lib.lbzamd_ddestroy(self.h)
+            self.h = C.c_void_p()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def decompress(self, data, out_cap=None):
+        data = bytes(data)
+        n = C.c_size_t()
+        if out_cap is None:                                   # size pass: everything but the output copy
+            rc = self.L.lib.lbzamd_decompress_host(self.h, data, len(data), None, 0, C.byref(n))
+            if rc not in (0, -2):
+                raise LbzError("lbzamd_decompress_host: " + self.L.error())
+            out_cap = n.value
+        out = C.create_string_buffer(max(1, out_cap))
+        rc = self.L.lib.lbzamd_decompress_host(self.h, data, len(data), out, out_cap, C.byref(n))
+        if rc:
+            raise LbzError("lbzamd_decompress_host: " + self.L.error())
+        return out.raw[:n.value]
+
+    def decompress_device(self, d_in, length, d_out, out_cap):
+        n = C.c_size_t()
+        rc = self.L.lib.lbzamd_decompress_device(self.h, C.c_void_p(d_in), length, C.c_void_p(d_out), out_cap, C.byref(n))
+        if rc:
+            raise LbzError("lbzamd_decompress_device: " + self.L.error())
+        return n.value
+
+    def stats(self):
+        s = DStats()
+        self.L.lib.lbzamd_dget_stats(self.h, C.byref(s))
+        return s
 
 
 class Encoder:

@@ -519,6 +519,230 @@ extern "C" long lbzamd_read_stage(lbzamd_ctx *c, uint32_t blk, int stage, void *
   return (long)bytes;
 }
 
+/* ===================================================================== the inverse path (C) */
+#include <algorithm>
+
+struct lbzamd_dctx {
+  int device = 0;
+  uint32_t max_blocks = 0, cap = 0;          /* cap: elements per block in the per-block arrays */
+  hipStream_t q = nullptr;
+  hipEvent_t ev[7] = {};
+  u8 *tt8 = nullptr, *W = nullptr, *sel = nullptr;
+  u32 *tt = nullptr, *ftab = nullptr, *nmarks = nullptr;
+  u64 *marks = nullptr;
+  lbz_dblock *blocks = nullptr;
+  u8 *d_in = nullptr, *d_out = nullptr;
+  size_t d_in_cap = 0, d_out_cap = 0;
+  uint32_t marks_cap = 0;
+  lbzamd_dstats stats{};
+};
+
+extern "C" void lbzamd_ddestroy(lbzamd_dctx *c)
+{
+  if (!c) return;
+  (void)hipFree(c->tt8); (void)hipFree(c->W); (void)hipFree(c->sel); (void)hipFree(c->tt); (void)hipFree(c->ftab);
+  (void)hipFree(c->nmarks); (void)hipFree(c->marks); (void)hipFree(c->blocks); (void)hipFree(c->d_in); (void)hipFree(c->d_out);
+  for (auto &e : c->ev) if (e) (void)hipEventDestroy(e);
+  if (c->q) (void)hipStreamDestroy(c->q);
+  delete c;
+}
+
+extern "C" int lbzamd_dcreate(lbzamd_dctx **out, int device, unsigned max_blocks)
+{
+  if (!out || max_blocks < 1) { g_err = "lbzamd_dcreate: bad argument"; return -1; }
+  int ndev = 0;
+  HIPCHK(hipGetDeviceCount(&ndev));
+  if (ndev < 1) { g_err = "lbzamd_dcreate: no HIP device (this library has no CPU path)"; return -1; }
+  if (device < 0) HIPCHK(hipGetDevice(&device));
+  HIPCHK(hipSetDevice(device));
+  lbzamd_dctx *c = new lbzamd_dctx;
+  c->device = device;
+  c->max_blocks = max_blocks;
+  c->cap = round_up(LBZ_MAX_BLOCK + 64u, 256u);
+  c->marks_cap = 1u << 20;
+#define DALLOC(p, bytes) do { hipError_t e_ = hipMalloc((void **)&(p), (bytes)); \
+    if (e_ != hipSuccess) { lbzamd_ddestroy(c); return fail_msg("hipMalloc " #p, e_); } } while (0)
+  DALLOC(c->tt8, (size_t)max_blocks * c->cap);
+  DALLOC(c->W, (size_t)max_blocks * c->cap);
+  DALLOC(c->tt, (size_t)max_blocks * c->cap * sizeof(u32));
+  DALLOC(c->sel, (size_t)max_blocks * 18002u);
+  DALLOC(c->ftab, (size_t)max_blocks * 256u * sizeof(u32));
+  DALLOC(c->blocks, (size_t)max_blocks * sizeof(lbz_dblock));
+  DALLOC(c->marks, (size_t)c->marks_cap * sizeof(u64));
+  DALLOC(c->nmarks, sizeof(u32));
+#undef DALLOC
+  hipError_t e = hipStreamCreate(&c->q);
+  if (e != hipSuccess) { lbzamd_ddestroy(c); return fail_msg("hipStreamCreate", e); }
+  for (auto &ev : c->ev) { e = hipEventCreate(&ev); if (e != hipSuccess) { lbzamd_ddestroy(c); return fail_msg("hipEventCreate", e); } }
+  *out = c;
+  return 0;
+}
+
+static uint32_t rd_be32_bits(const std::vector<uint8_t> &h, uint64_t bit)
+{
+  /* 32 bits at an arbitrary bit position of a host copy (the stream trailers) */
+  uint64_t v = 0;
+  const uint64_t by = bit >> 3;
+  for (int i = 0; i < 5; i++) v = (v << 8) | (by + i < h.size() ? h[by + i] : 0u);
+  return (uint32_t)(v >> (8u - (bit & 7u)));
+}
+
+extern "C" int lbzamd_decompress_device(lbzamd_dctx *c, const void *d_in_v, size_t len, void *d_out_v, size_t out_cap, size_t *out_len)
+{
+  if (!c || !out_len || (len && !d_in_v)) { g_err = "lbzamd_decompress_device: bad argument"; return -1; }
+  HIPCHK(hipSetDevice(c->device));
+  const u8 *d_in = (const u8 *)d_in_v;
+  u8 *d_out = (u8 *)d_out_v;
+  hipStream_t q = c->q;
+  c->stats = lbzamd_dstats{};
+  c->stats.n_in = len;
+  if (len < 14) { g_err = "lbzamd_decompress: not a bzip2 stream (too short)"; return -3; }
+  /* 1. magics */
+  HIPCHK(hipEventRecord(c->ev[0], q));
+  HIPCHK(hipMemsetAsync(c->nmarks, 0, sizeof(u32), q));
+  hipLaunchKernelGGL(k_dscan, dim3((u32)((len + 255u) / 256u)), dim3(256), 0, q, d_in, (u64)len, c->marks, c->nmarks, c->marks_cap);
+  HIPCHK(hipEventRecord(c->ev[1], q));
+  u32 nm = 0;
+  HIPCHK(hipMemcpyAsync(&nm, c->nmarks, sizeof nm, hipMemcpyDeviceToHost, q));
+  HIPCHK(hipStreamSynchronize(q));
+  if (nm > c->marks_cap) { g_err = "lbzamd_decompress: too many block magics"; return -3; }
+  std::vector<u64> marks(nm);
+  if (nm) HIPCHK(hipMemcpy(marks.data(), c->marks, nm * sizeof(u64), hipMemcpyDeviceToHost));
+  std::sort(marks.begin(), marks.end());
+  /* 2. streams: "BZh" level | blocks | end-of-stream magic + CRC, then (byte aligned) maybe another stream */
+  std::vector<uint8_t> head(4);
+  std::vector<lbz_dblock> hb;
+  struct trailer { uint64_t bit; size_t first_block, nblocks; };
+  std::vector<trailer> trailers;
+  {
+    uint64_t sbyte = 0;                         /* where the current stream's header is */
+    size_t mi = 0;
+    while (sbyte + 14 <= len) {
+      HIPCHK(hipMemcpy(head.data(), d_in + sbyte, 4, hipMemcpyDeviceToHost));
+      if (head[0] != 'B' || head[1] != 'Z' || head[2] != 'h' || head[3] < '1' || head[3] > '9') {
+        if (sbyte == 0) { g_err = "lbzamd_decompress: not a bzip2 stream (bad header)"; return -3; }
+        break;                                  /* trailing garbage is ignored, as bzip2 does */
+      }
+      const u32 mbs = (u32)(head[3] - '0') * 100000u;
+      const uint64_t first_bit = (sbyte + 4) * 8;
+      while (mi < marks.size() && (marks[mi] >> 1) < first_bit) mi++;
+      const size_t fb = hb.size();
+      bool closed = false;
+      uint64_t expect = first_bit;
+      while (mi < marks.size()) {
+        const uint64_t bit = marks[mi] >> 1;
+        const int kind = (int)(marks[mi] & 1u);
+        if (fb == hb.size() && bit != expect) { g_err = "lbzamd_decompress: no block magic behind the stream header"; return -3; }
+        mi++;
+        if (kind == 1) {
+          trailers.push_back({ bit, fb, hb.size() - fb });
+          sbyte = (bit + 48 + 32 + 7) / 8;
+          closed = true;
+          break;
+        }
+        lbz_dblock b{};
+        b.bit_start = bit + 48;
+        b.max_block = mbs;
+        hb.push_back(b);
+      }
+      if (!closed) { g_err = "lbzamd_decompress: stream without end-of-stream marker (truncated?)"; return -3; }
+    }
+  }
+  c->stats.nblocks = (uint32_t)hb.size();
+  c->stats.nstreams = (uint32_t)trailers.size();
+  /* 3. blocks, max_blocks at a time */
+  float ms[5] = { 0, 0, 0, 0, 0 };
+  { float t = 0; HIPCHK(hipEventElapsedTime(&t, c->ev[0], c->ev[1])); ms[0] = t; }
+  uint64_t total = 0;
+  for (size_t b0 = 0; b0 < hb.size(); b0 += c->max_blocks) {
+    const u32 nb = (u32)std::min<size_t>(c->max_blocks, hb.size() - b0);
+    HIPCHK(hipMemcpyAsync(c->blocks, hb.data() + b0, nb * sizeof(lbz_dblock), hipMemcpyHostToDevice, q));
+    HIPCHK(hipEventRecord(c->ev[1], q));
+    hipLaunchKernelGGL(k_dhuff, dim3(nb), dim3(64), 0, q, d_in, (u64)len, c->blocks, nb, c->tt8, c->ftab, c->sel, c->cap);
+    HIPCHK(hipEventRecord(c->ev[2], q));
+    hipLaunchKernelGGL(k_dsort, dim3(nb), dim3(256), 0, q, (const lbz_dblock *)c->blocks, nb, (const u8 *)c->tt8, (const u32 *)c->ftab, c->tt, c->cap);
+    HIPCHK(hipEventRecord(c->ev[3], q));
+    hipLaunchKernelGGL(k_dwalk, dim3(nb), dim3(64), 0, q, c->blocks, nb, (const u32 *)c->tt, c->W, c->cap);
+    HIPCHK(hipEventRecord(c->ev[4], q));
+    HIPCHK(hipMemcpyAsync(hb.data() + b0, c->blocks, nb * sizeof(lbz_dblock), hipMemcpyDeviceToHost, q));
+    HIPCHK(hipStreamSynchronize(q));
+    HIPCHK(hipGetLastError());
+    for (u32 i = 0; i < nb; i++) {
+      lbz_dblock &b = hb[b0 + i];
+      if (b.err) {
+        char buf[128];
+        snprintf(buf, sizeof buf, "lbzamd_decompress: block %zu: %s (code %u)", b0 + i, b.err == 11 ? "CRC mismatch" : "malformed block", b.err);
+        g_err = buf;
+        return -3;
+      }
+      b.out_off = total;
+      total += b.out_len;
+    }
+    if (total <= out_cap && d_out) {
+      HIPCHK(hipMemcpyAsync(c->blocks, hb.data() + b0, nb * sizeof(lbz_dblock), hipMemcpyHostToDevice, q));
+      HIPCHK(hipEventRecord(c->ev[5], q));
+      hipLaunchKernelGGL(k_demit, dim3(nb), dim3(64), 0, q, (const lbz_dblock *)c->blocks, nb, (const u8 *)c->W, d_out, (u64)out_cap, c->cap);
+      HIPCHK(hipEventRecord(c->ev[6], q));
+      HIPCHK(hipStreamSynchronize(q));
+      HIPCHK(hipGetLastError());
+      float t = 0;
+      HIPCHK(hipEventElapsedTime(&t, c->ev[5], c->ev[6])); ms[4] += t;
+    }
+    float t = 0;
+    HIPCHK(hipEventElapsedTime(&t, c->ev[1], c->ev[2])); ms[1] += t;
+    HIPCHK(hipEventElapsedTime(&t, c->ev[2], c->ev[3])); ms[2] += t;
+    HIPCHK(hipEventElapsedTime(&t, c->ev[3], c->ev[4])); ms[3] += t;
+  }
+  /* 4. stream CRCs: the fold of the block CRCs as stored (encode.h:38 written for the inverted values) */
+  {
+    std::vector<uint8_t> tail(8);
+    for (const trailer &tr : trailers) {
+      uint32_t cc = 0;
+      for (size_t i = 0; i < tr.nblocks; i++) cc = ((cc << 1) | (cc >> 31)) ^ hb[tr.first_block + i].stored_crc;
+      const uint64_t by = (tr.bit + 48) >> 3;
+      const size_t nbytes = std::min<size_t>(8, len - by);
+      HIPCHK(hipMemcpy(tail.data(), d_in + by, nbytes, hipMemcpyDeviceToHost));
+      std::vector<uint8_t> h(tail.begin(), tail.begin() + nbytes);
+      const uint32_t want = rd_be32_bits(h, (tr.bit + 48) & 7u);
+      if (want != cc) { g_err = "lbzamd_decompress: stream CRC mismatch"; return -3; }
+    }
+  }
+  c->stats.n_out = total;
+  c->stats.ms_scan = ms[0]; c->stats.ms_huff = ms[1]; c->stats.ms_sort = ms[2]; c->stats.ms_walk = ms[3]; c->stats.ms_emit = ms[4];
+  c->stats.ms_total = ms[0] + ms[1] + ms[2] + ms[3] + ms[4];
+  *out_len = (size_t)total;
+  if (total > out_cap || (total && !d_out)) { g_err = "lbzamd_decompress: output buffer too small"; return -2; }
+  return 0;
+}
+
+extern "C" int lbzamd_decompress_host(lbzamd_dctx *c, const uint8_t *in, size_t len, uint8_t *out, size_t out_cap, size_t *out_len)
+{
+  if (!c || !out_len || (len && !in)) { g_err = "lbzamd_decompress_host: bad argument"; return -1; }
+  HIPCHK(hipSetDevice(c->device));
+  if (len + 16 > c->d_in_cap) {
+    (void)hipFree(c->d_in); c->d_in = nullptr; c->d_in_cap = 0;
+    HIPCHK(hipMalloc((void **)&c->d_in, len + 256));
+    c->d_in_cap = len + 16;
+  }
+  if (out_cap > c->d_out_cap) {
+    (void)hipFree(c->d_out); c->d_out = nullptr; c->d_out_cap = 0;
+    HIPCHK(hipMalloc((void **)&c->d_out, out_cap + 256));
+    c->d_out_cap = out_cap;
+  }
+  HIPCHK(hipMemcpy(c->d_in, in, len, hipMemcpyHostToDevice));
+  const int rc = lbzamd_decompress_device(c, c->d_in, len, out_cap ? c->d_out : nullptr, out_cap, out_len);
+  if (rc) return rc;
+  if (*out_len) HIPCHK(hipMemcpy(out, c->d_out, *out_len, hipMemcpyDeviceToHost));
+  return 0;
+}
+
+extern "C" int lbzamd_dget_stats(lbzamd_dctx *c, lbzamd_dstats *st)
+{
+  if (!c || !st) return -1;
+  *st = c->stats;
+  return 0;
+}
+
 /* ===================================================================== drop-in (A) */
 /* The reference calls collect / encode / transmit once per block, from many worker threads at
  * once (compress.c:81-115 runs them outside the scheduler lock).  One block per launch would

@@ -15,6 +15,24 @@ struct lbz_stream_state {
   u32 err;
 };
 
+/* one compressed block of a stream being decoded (k_decode.hip) */
+struct lbz_dblock {
+  u64 bit_start;      /* first bit after the block's 48-bit magic */
+  u64 bit_used;       /* bit position behind the block's last code (diagnostic) */
+  u64 out_off;        /* where the decoded bytes go */
+  u32 max_block;      /* bs100k * 100000 of the stream the block belongs to */
+  u32 stored_crc, computed_crc;
+  u32 randomised, orig_ptr;
+  u32 nblock;         /* length before inverse RLE1 */
+  u32 out_len;        /* decoded bytes */
+  u32 err;            /* 0 ok; 1..10 malformed block; 11 CRC mismatch */
+};
+__global__ void k_dscan(const u8 *in, u64 nbytes, u64 *marks, u32 *nmarks, u32 cap);
+__global__ void k_dhuff(const u8 *in, u64 nbytes, lbz_dblock *blocks, u32 nblk, u8 *tt8_base, u32 *ftab_base, u8 *sel_base, u32 cap);
+__global__ void k_dsort(const lbz_dblock *blocks, u32 nblk, const u8 *tt8_base, const u32 *ftab_base, u32 *tt_base, u32 cap);
+__global__ void k_dwalk(lbz_dblock *blocks, u32 nblk, const u32 *tt_base, u8 *W_base, u32 cap);
+__global__ void k_demit(const lbz_dblock *blocks, u32 nblk, const u8 *W_base, u8 *out, u64 out_cap, u32 cap);
+
 /* slabs [first, first + gridDim.x) of the chunk that starts at `in` */
 __global__ void k_collect(const u8 *in, u64 in_len, lbz_layout L, u8 *Tbase, lbz_block_meta *meta, u32 first,
                           const u32 *slabs, const u32 *slab_len);

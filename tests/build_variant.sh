@@ -4,7 +4,7 @@
 set -e
 cd /root/repo/lbzip2_amd/csrc
 mkdir -p variants/$1
-for f in k_collect k_bwt k_mtf k_encode k_finish lbz_api; do
+for f in k_collect k_bwt k_mtf k_encode k_finish k_decode lbz_api; do
   /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -I. -I../../include -Wno-unused-function -Wno-inline-asm $2 -c $f.hip -o variants/$1/$f.o &
 done
 wait

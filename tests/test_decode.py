@@ -1,0 +1,95 @@
+"""The inverse path: block-parallel decoding of .bz2 streams through the C ABI
+(lbzamd_decompress_*).  Oracles: the input itself (round trips of this library's, the reference's and Python
+bz2's compressors -- the latter two give bit-aligned blocks and multi-stream files) and error behaviour on
+damaged streams.  CPU: the kernel sources under the emulator; GPU: full-size configurations (C5's round trip)."""
+import bz2
+import os
+import subprocess
+
+import pytest
+
+import oracle_lib as L
+from golden_util import gen
+from lbzip2_amd._binding import LbzError, Library
+
+EMU_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "emu")
+
+
+@pytest.fixture(scope="module")
+def emu():
+    subprocess.check_call(["make", "-s", "-C", EMU_DIR, "WG=1024"])
+    return Library(os.path.join(EMU_DIR, "_build", "liblbzamd_emu_1024.so"))
+
+
+CASES = [("empty", b"", 9), ("one", b"a", 9), ("banana", b"banana", 9), ("aaaa", b"a" * 4, 9), ("run259", b"a" * 259 + b"b", 9),
+         ("runs", b"ab" * 3 + b"c" * 300 + b"d" + b"e" * 4, 1), ("zeros", bytes(10000), 9), ("all256", bytes(range(256)) * 3, 9),
+         ("text3k", bytes(gen("text", 3000, 5)), 1), ("rand30k", bytes(gen("rand", 30000, 3)), 9),
+         ("wiki260k", bytes(gen("wiki", 260000, 3)), 1), ("runs150k", bytes(gen("runs", 150000, 4)), 1),
+         ("abab", b"ab" * 5000, 9)]
+
+
+@pytest.mark.parametrize("name,data,level", CASES, ids=[c[0] for c in CASES])
+def test_round_trip_of_oracle_streams(emu, name, data, level):
+    assert emu.decompress(L.orc_compress(data, level)) == data
+
+
+def test_reference_and_python_streams(emu):
+    """bit-aligned blocks (bzip2's own compressor), several streams in one file, the reference's stream"""
+    d1, d2 = bytes(gen("text", 250000, 9)), bytes(gen("wiki", 120000, 4))
+    z = bz2.compress(d1, 1) + bz2.compress(b"tail" * 100, 9) + bz2.compress(b"", 5) + L.orc_compress(d2, 2)
+    assert emu.decompress(z) == d1 + b"tail" * 100 + d2
+    if L.have_ref():
+        assert emu.decompress(L.ref_compress(d2, 1)) == d2
+    assert emu.decompress(bz2.compress(d2, 9) + b"\0" * 7) == d2            # trailing garbage is ignored
+
+
+def test_damaged_streams_are_refused(emu):
+    z = bytearray(L.orc_compress(bytes(gen("text", 120000, 6)), 1))
+    for mutate in (lambda b: b.__setitem__(len(b) // 2, b[len(b) // 2] ^ 0x10),       # payload bit: block CRC or code error
+                   lambda b: b.__setitem__(len(b) - 1, b[-1] ^ 1),                      # stream CRC
+                   lambda b: b.__delitem__(slice(len(b) - 20, len(b))),                  # truncated
+                   lambda b: b.__setitem__(0, ord("X"))):                                # no header
+        bad = bytearray(z)
+        mutate(bad)
+        with pytest.raises(LbzError):
+            emu.decompress(bytes(bad))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind,n,seed,level", [("wiki", 100_000_000, 1, 9), ("rand", 30_000_000, 4, 9), ("mixed", 120_000_000, 3, 1),
+                                               ("tar", 175_000_000, 5, 9), ("text", 50_000_000, 2, 5)])
+def test_round_trip_full_size(kind, n, seed, level):
+    """compress on the device, decode on the device, compare on the device (C5: tar-like stream, round trip)"""
+    import torch
+    import lbzip2_amd
+    lib = lbzip2_amd.library()
+    data = L.gen_kind(kind, n, seed)
+    src = torch.frombuffer(data, dtype=torch.uint8).cuda()
+    z = torch.empty(lib.bound(n), dtype=torch.uint8, device="cuda")
+    M = level * 100000
+    with lib.context(level, min(2400, (n + M - 1) // M)) as ctx:
+        m = ctx.compress_device(src.data_ptr(), n, z.data_ptr(), z.numel())
+    out = torch.empty(n + 64, dtype=torch.uint8, device="cuda")
+    with lib.decoder(2400) as d:
+        k = d.decompress_device(z.data_ptr(), m, out.data_ptr(), out.numel())
+        st = d.stats()
+    assert k == n and bool(torch.equal(out[:n], src))
+    assert st.nblocks >= (n + M - 1) // M and st.nstreams == 1
+
+
+@pytest.mark.gpu
+def test_foreign_streams_on_the_gpu():
+    """the reference's and Python bz2's streams (bit-aligned blocks, several streams), and a damaged one"""
+    import lbzip2_amd
+    lib = lbzip2_amd.library()
+    d1, d2 = bytes(gen("wiki", 3_000_000, 7)), bytes(gen("text", 1_000_000, 8))
+    z = bz2.compress(d1, 9) + bz2.compress(d2, 1)
+    if L.have_ref():
+        z += L.ref_compress(d2, 3)
+        d2x = d2 + d2
+    else:
+        d2x = d2
+    assert lib.decompress(z) == d1 + d2x
+    bad = bytearray(z); bad[len(bad) // 3] ^= 4
+    with pytest.raises(lbzip2_amd.LbzError):
+        lib.decompress(bytes(bad))
