@@ -283,76 +283,263 @@ k_dsort(const lbz_dblock *blocks, u32 nblk, const u8 *tt8_base, const u32 *ftab_
 }
 
 /* ------------------------------------------------------------------ k_dwalk */
-__device__ __forceinline__ u32 dec_crc_step(const u32 *tab, u32 crc, u32 byte) { return (crc << 8) ^ tab[(crc >> 24) ^ byte]; }
+/* The walk (decode.c:944-1146 is one pointer chase per block: n dependent loads) done as LIST RANKING so
+ * that a block has hundreds of chases in flight instead of one:
+ *
+ *   1. every 512th list node (and the start node) is a splitter; from each splitter a lane follows the list
+ *      to the next splitter and records (steps, splitter reached).  Lanes take splitters from a counter,
+ *      so a long sublist does not hold the others up;
+ *   2. one lane ranks the <= 1760 splitters: sublist k starts at output offset off[k].  A list that closes
+ *      before n steps (the block is periodic: the BWT permutation has several cycles) gives the period;
+ *   3. the sublists are followed again, bytes go to W[off[k] + j]; a periodic block is filled from its
+ *      first period;
+ *   4. inverse RLE1 without the serial state machine: the state (bytes of the current run seen, 0..4; 4 =
+ *      "next byte is a count") moves by c -> c+1 mod 5 on a byte equal to its predecessor and by
+ *      c -> (c == 4 ? 0 : 1) otherwise, so a chunk of W is a map {0..4} -> {0..4}; the 256 chunk maps are
+ *      composed in order, then every lane re-reads its chunk with the right start state: decoded length,
+ *      CRC (from 0) and, per 16 bytes of W, the output offset + state that k_demit starts from;
+ *   5. CRC-32 is linear: crc(A|B) = crc(A) * x^(8|B|) + crc(B) over GF(2)[x]/P -- the chunk CRCs are
+ *      shifted by the decoded length behind them (square-and-multiply with x^(8 * 2^k)) and xor-ed.      */
+#define DW_T 256u
+#define DW_LOG 9u
+#define DW_STRIDE (1u << DW_LOG)
+#define DW_MAXS ((LBZ_MAX_BLOCK >> DW_LOG) + 4u)
+#define DW_NONE 0xFFFFFFFFu
+#define CRC_POLY 0x04C11DB7u
 
-/* One wave per block, lane 0 walks: n dependent loads.  The inverse-RLE1 state machine runs under the load
- * latency: decoded length and CRC-32 (poly 0x04C11DB7, MSB first) come out of the same loop; the RLE1'd bytes
- * are kept (W) so that the output pass needs no second chase.                                          */
-__global__ void __launch_bounds__(64)
-k_dwalk(lbz_dblock *blocks, u32 nblk, const u32 *tt_base, u8 *W_base, u32 cap)
+struct walk_lds {
+  u32 len[DW_MAXS], nxt[DW_MAXS], off[DW_MAXS];
+  u32 crctab[256];
+  u32 pow8[32];
+  u32 fn[DW_T];          /* chunk maps, 3 bits per start state */
+  u32 olen[DW_T];        /* decoded bytes of the chunk, then the exclusive prefix */
+  u32 ctr, ctr2, period, total;
+  u32 xr[4];
+};
+
+__device__ __forceinline__ u32 dec_crc_step(const u32 *tab, u32 crc, u32 byte) { return (crc << 8) ^ tab[(crc >> 24) ^ byte]; }
+__device__ __forceinline__ u32 gf2_mulmod(u32 a, u32 b)
 {
-  __shared__ u32 crctab[256];
-  const u32 lane = threadIdx.x;
+  u32 r = 0;
+  for (int i = 31; i >= 0; i--) {
+    r = (r << 1) ^ ((r & 0x80000000u) ? CRC_POLY : 0u);
+    if ((b >> i) & 1u) r ^= a;
+  }
+  return r;
+}
+__device__ __forceinline__ u32 crc_shift(const u32 *pow8, u32 v, u32 nbytes)     /* v * x^(8 nbytes) mod P */
+{
+  for (u32 k = 0; nbytes; k++, nbytes >>= 1) if (nbytes & 1u) v = gf2_mulmod(v, pow8[k]);
+  return v;
+}
+__device__ __forceinline__ u32 rle_step(u32 c, bool eq) { return eq ? (c == 4u ? 0u : c + 1u) : (c == 4u ? 0u : 1u); }
+
+__global__ void __launch_bounds__(DW_T)
+k_dwalk(lbz_dblock *blocks, u32 nblk, const u32 *tt_base, u8 *W_base, u32 *pinfo_base, u32 cap)
+{
+  __shared__ walk_lds S;
+  const u32 tid = threadIdx.x;
   const u32 blk = blockIdx.x;
   if (blk >= nblk) return;
-  for (u32 i = lane; i < 256u; i += 64u) {
-    u32 c = i << 24;
-    for (u32 k = 0; k < 8u; k++) c = (c & 0x80000000u) ? (c << 1) ^ 0x04C11DB7u : c << 1;
-    crctab[i] = c;
-  }
-  __syncthreads();
-  if (lane != 0u) return;
   lbz_dblock *D = &blocks[blk];
   const u32 n = D->nblock;
-  if (D->err || n == 0u) { D->out_len = 0; return; }
+  if (D->err || n == 0u) { if (tid == 0u) D->out_len = 0; return; }
   const u32 *tt = tt_base + (size_t)blk * cap;
   u8 *W = W_base + (size_t)blk * cap;
-  u32 tpos = tt[D->orig_ptr] >> 8;
-  u32 crc = 0xFFFFFFFFu, run = 0, prev = 256u;
-  u64 outlen = 0;
-  for (u32 k = 0; k < n; k++) {
-    const u32 x = tt[tpos];
-    const u32 ch = x & 255u;
-    tpos = x >> 8;
-    W[k] = (u8)ch;
-    if (run == 4u) {                                            /* a count byte: ch more copies of prev */
-      for (u32 r = 0; r < ch; r++) crc = dec_crc_step(crctab, crc, prev);
-      outlen += ch;
-      run = 0; prev = 256u;
-      continue;
-    }
-    if (ch == prev) run++; else { run = 1; prev = ch; }
-    crc = dec_crc_step(crctab, crc, ch);
-    outlen++;
+  u32 *pinfo = pinfo_base + (size_t)blk * (cap / 16u);
+
+  {
+    u32 c = tid << 24;
+    for (u32 k = 0; k < 8u; k++) c = (c & 0x80000000u) ? (c << 1) ^ CRC_POLY : c << 1;
+    S.crctab[tid] = c;
   }
-  D->computed_crc = ~crc;
-  D->out_len = outlen > 0xFFFFFFFFull ? 0xFFFFFFFFu : (u32)outlen;
-  if (D->computed_crc != D->stored_crc) D->err = 11;
+  if (tid == 0u) {
+    u32 p = 0x100u;                                   /* x^8 */
+    for (u32 k = 0; k < 32u; k++) { S.pow8[k] = p; p = gf2_mulmod(p, p); }
+    S.ctr = 0; S.ctr2 = 0;
+  }
+  const u32 t0 = tt[D->orig_ptr] >> 8;
+  const u32 ns0 = (n + DW_STRIDE - 1u) >> DW_LOG;    /* splitters k * 512 < n */
+  const bool extra = (t0 & (DW_STRIDE - 1u)) != 0u;
+  const u32 ns = ns0 + (extra ? 1u : 0u);
+  const u32 start_id = extra ? ns0 : t0 >> DW_LOG;
+  for (u32 i = tid; i < ns; i += DW_T) S.off[i] = DW_NONE;
+  __syncthreads();
+
+  /* 1. sublist lengths */
+  {
+    u32 k = atomicAdd(&S.ctr, 1u);
+    u32 node = k < ns0 ? k << DW_LOG : t0, cnt = 0;
+    while (k < ns) {
+      node = tt[node] >> 8;
+      cnt++;
+      if ((node & (DW_STRIDE - 1u)) == 0u || node == t0 || cnt >= n) {
+        S.len[k] = cnt;
+        S.nxt[k] = node == t0 ? start_id : node >> DW_LOG;
+        k = atomicAdd(&S.ctr, 1u);
+        node = k < ns0 ? k << DW_LOG : t0;
+        cnt = 0;
+      }
+    }
+  }
+  __syncthreads();
+  /* 2. rank the splitters */
+  if (tid == 0u) {
+    u32 k = start_id, total = 0, steps = 0;
+    do {
+      S.off[k] = total;
+      total += S.len[k];
+      k = S.nxt[k];
+    } while (k != start_id && total < n && ++steps < ns);
+    S.period = total < n ? total : n;
+  }
+  __syncthreads();
+  /* 3. bytes */
+  {
+    u32 k = DW_NONE, node = 0, o = 0, left = 0;
+    for (;;) {
+      if (left == 0u) {
+        k = atomicAdd(&S.ctr2, 1u);
+        if (k >= ns) break;
+        o = S.off[k];
+        if (o == DW_NONE) continue;
+        left = S.len[k];
+        if (o + left > n) left = n - o;
+        node = k < ns0 ? k << DW_LOG : t0;
+        if (left == 0u) continue;
+      }
+      const u32 x = tt[node];
+      W[o++] = (u8)x;
+      node = x >> 8;
+      left--;
+    }
+  }
+  __syncthreads();
+  const u32 period = S.period;
+  if (period < n) {
+    for (u32 j = period + tid; j < n; j += DW_T) W[j] = W[j % period];
+    __syncthreads();
+  }
+
+  /* 4. chunk maps */
+  const u32 npiece = (n + 15u) / 16u;
+  const u32 ppc = (npiece + DW_T - 1u) / DW_T;        /* 16-byte pieces per chunk */
+  const u32 cs = tid * ppc * 16u < n ? tid * ppc * 16u : n;
+  const u32 ce = cs + ppc * 16u < n ? cs + ppc * 16u : n;
+  {
+    u32 f0 = 0, f1 = 1, f2 = 2, f3 = 3, f4 = 4;
+    u32 pb = cs > 0u ? W[cs - 1u] : 256u;
+    for (u32 i = cs; i < ce; i += 16u) {
+      u32 wq[4];
+      if (i + 16u <= ce) { const uint4 q = *reinterpret_cast<const uint4 *>(W + i); wq[0] = q.x; wq[1] = q.y; wq[2] = q.z; wq[3] = q.w; }
+      else for (u32 j = 0; j < 16u; j++) { if ((j & 3u) == 0u) wq[j >> 2] = 0; if (i + j < ce) wq[j >> 2] |= (u32)W[i + j] << (8u * (j & 3u)); }
+      const u32 m = ce - i < 16u ? ce - i : 16u;
+      for (u32 j = 0; j < m; j++) {
+        const u32 b = (wq[j >> 2] >> (8u * (j & 3u))) & 255u;
+        const bool eq = b == pb;
+        f0 = rle_step(f0, eq); f1 = rle_step(f1, eq); f2 = rle_step(f2, eq); f3 = rle_step(f3, eq); f4 = rle_step(f4, eq);
+        pb = b;
+      }
+    }
+    S.fn[tid] = f0 | f1 << 3 | f2 << 6 | f3 << 9 | f4 << 12;
+  }
+  __syncthreads();
+  if (tid == 0u) {                                    /* start state of every chunk (kept in fn[]) */
+    u32 c = 0;
+    for (u32 t = 0; t < DW_T; t++) { const u32 f = S.fn[t]; S.fn[t] = c; c = (f >> (3u * c)) & 7u; }
+  }
+  __syncthreads();
+  /* decoded length, CRC from 0 and the per-piece records (offsets relative to the chunk for now) */
+  u32 crc = 0, outl = 0;
+  {
+    u32 c = S.fn[tid];
+    u32 pb = cs > 0u ? W[cs - 1u] : 256u;
+    for (u32 i = cs; i < ce; i += 16u) {
+      pinfo[i >> 4] = outl << 3 | c;
+      u32 wq[4];
+      if (i + 16u <= ce) { const uint4 q = *reinterpret_cast<const uint4 *>(W + i); wq[0] = q.x; wq[1] = q.y; wq[2] = q.z; wq[3] = q.w; }
+      else for (u32 j = 0; j < 16u; j++) { if ((j & 3u) == 0u) wq[j >> 2] = 0; if (i + j < ce) wq[j >> 2] |= (u32)W[i + j] << (8u * (j & 3u)); }
+      const u32 m = ce - i < 16u ? ce - i : 16u;
+      for (u32 j = 0; j < m; j++) {
+        const u32 b = (wq[j >> 2] >> (8u * (j & 3u))) & 255u;
+        if (c == 4u) {                                /* a count: b more copies of the run's byte */
+          for (u32 r = 0; r < b; r++) crc = dec_crc_step(S.crctab, crc, pb);
+          outl += b;
+          c = 0;
+        } else {
+          c = (c != 0u && b == pb) ? c + 1u : 1u;
+          crc = dec_crc_step(S.crctab, crc, b);
+          outl++;
+        }
+        pb = b;
+      }
+    }
+    S.olen[tid] = outl;
+  }
+  __syncthreads();
+  if (tid == 0u) {
+    u32 acc = 0;
+    for (u32 t = 0; t < DW_T; t++) { const u32 v = S.olen[t]; S.olen[t] = acc; acc += v; }
+    S.total = acc;
+    S.xr[0] = S.xr[1] = S.xr[2] = S.xr[3] = 0;
+  }
+  __syncthreads();
+  const u32 total = S.total, mybase = S.olen[tid];
+  for (u32 i = cs; i < ce; i += 16u) pinfo[i >> 4] += mybase << 3;
+  /* 5. the block CRC */
+  u32 term = crc_shift(S.pow8, crc, total - mybase - outl);
+  if (tid == 0u) term ^= crc_shift(S.pow8, 0xFFFFFFFFu, total);
+  for (u32 d = 32u; d >= 1u; d >>= 1) term ^= (u32)__shfl_xor((int)term, d);
+  if ((tid & 63u) == 0u) S.xr[tid >> 6] = term;
+  __syncthreads();
+  if (tid == 0u) {
+    const u32 cc = ~(S.xr[0] ^ S.xr[1] ^ S.xr[2] ^ S.xr[3]);
+    D->computed_crc = cc;
+    D->out_len = total;
+    if (cc != D->stored_crc) D->err = 11;
+  }
 }
 
 /* ------------------------------------------------------------------ k_demit */
-/* inverse RLE1 of W[] to out + out_off: lane 0 runs the state machine, the wave writes the long runs */
-__global__ void __launch_bounds__(64)
-k_demit(const lbz_dblock *blocks, u32 nblk, const u8 *W_base, u8 *out, u64 out_cap, u32 cap)
+/* inverse RLE1 of W[] to out + out_off: every lane owns 16 bytes of W and starts from the record k_dwalk
+ * left for them (output offset << 3 | state); neighbouring lanes write neighbouring bytes.            */
+#define DE_SPLIT 8u
+__global__ void __launch_bounds__(256)
+k_demit(const lbz_dblock *blocks, u32 nblk, const u8 *W_base, const u32 *pinfo_base, u8 *out, u64 out_cap, u32 cap)
 {
-  const u32 lane = threadIdx.x;
-  const u32 blk = blockIdx.x;
+  const u32 tid = threadIdx.x;
+  const u32 blk = blockIdx.x / DE_SPLIT, part = blockIdx.x % DE_SPLIT;
   if (blk >= nblk) return;
   const lbz_dblock *D = &blocks[blk];
   const u32 n = D->nblock;
-  if (D->err || n == 0u || lane != 0u) return;
+  if (D->err || n == 0u) return;
   if (D->out_off + D->out_len > out_cap) return;
   const u8 *W = W_base + (size_t)blk * cap;
-  u8 *o = out + D->out_off;
-  u32 run = 0, prev = 256u;
-  for (u32 k = 0; k < n; k++) {
-    const u32 ch = W[k];
-    if (run == 4u) {
-      for (u32 r = 0; r < ch; r++) *o++ = (u8)prev;
-      run = 0; prev = 256u;
-      continue;
+  const u32 *pinfo = pinfo_base + (size_t)blk * (cap / 16u);
+  u8 *ob = out + D->out_off;
+  const u32 npiece = (n + 15u) / 16u;
+  const u32 per = (npiece + DE_SPLIT - 1u) / DE_SPLIT;
+  const u32 p0 = part * per, p1 = p0 + per < npiece ? p0 + per : npiece;
+  for (u32 p = p0 + tid; p < p1; p += 256u) {
+    const u32 i = p * 16u;
+    const u32 rec = pinfo[p];
+    u32 c = rec & 7u;
+    u8 *o = ob + (rec >> 3);
+    u32 wq[4];
+    if (i + 16u <= n) { const uint4 q = *reinterpret_cast<const uint4 *>(W + i); wq[0] = q.x; wq[1] = q.y; wq[2] = q.z; wq[3] = q.w; }
+    else for (u32 j = 0; j < 16u; j++) { if ((j & 3u) == 0u) wq[j >> 2] = 0; if (i + j < n) wq[j >> 2] |= (u32)W[i + j] << (8u * (j & 3u)); }
+    u32 pb = i > 0u ? W[i - 1u] : 256u;
+    const u32 m = n - i < 16u ? n - i : 16u;
+    for (u32 j = 0; j < m; j++) {
+      const u32 b = (wq[j >> 2] >> (8u * (j & 3u))) & 255u;
+      if (c == 4u) {
+        for (u32 r = 0; r < b; r++) *o++ = (u8)pb;
+        c = 0;
+      } else {
+        c = (c != 0u && b == pb) ? c + 1u : 1u;
+        *o++ = (u8)b;
+      }
+      pb = b;
     }
-    if (ch == prev) run++; else { run = 1; prev = ch; }
-    *o++ = (u8)ch;
   }
 }

@@ -528,7 +528,7 @@ struct lbzamd_dctx {
   hipStream_t q = nullptr;
   hipEvent_t ev[7] = {};
   u8 *tt8 = nullptr, *W = nullptr, *sel = nullptr;
-  u32 *tt = nullptr, *ftab = nullptr, *nmarks = nullptr;
+  u32 *tt = nullptr, *ftab = nullptr, *nmarks = nullptr, *pinfo = nullptr;
   u64 *marks = nullptr;
   lbz_dblock *blocks = nullptr;
   u8 *d_in = nullptr, *d_out = nullptr;
@@ -541,7 +541,7 @@ extern "C" void lbzamd_ddestroy(lbzamd_dctx *c)
 {
   if (!c) return;
   (void)hipFree(c->tt8); (void)hipFree(c->W); (void)hipFree(c->sel); (void)hipFree(c->tt); (void)hipFree(c->ftab);
-  (void)hipFree(c->nmarks); (void)hipFree(c->marks); (void)hipFree(c->blocks); (void)hipFree(c->d_in); (void)hipFree(c->d_out);
+  (void)hipFree(c->pinfo); (void)hipFree(c->nmarks); (void)hipFree(c->marks); (void)hipFree(c->blocks); (void)hipFree(c->d_in); (void)hipFree(c->d_out);
   for (auto &e : c->ev) if (e) (void)hipEventDestroy(e);
   if (c->q) (void)hipStreamDestroy(c->q);
   delete c;
@@ -566,6 +566,7 @@ extern "C" int lbzamd_dcreate(lbzamd_dctx **out, int device, unsigned max_blocks
   DALLOC(c->W, (size_t)max_blocks * c->cap);
   DALLOC(c->tt, (size_t)max_blocks * c->cap * sizeof(u32));
   DALLOC(c->sel, (size_t)max_blocks * 18002u);
+  DALLOC(c->pinfo, (size_t)max_blocks * (c->cap / 16u) * sizeof(u32));
   DALLOC(c->ftab, (size_t)max_blocks * 256u * sizeof(u32));
   DALLOC(c->blocks, (size_t)max_blocks * sizeof(lbz_dblock));
   DALLOC(c->marks, (size_t)c->marks_cap * sizeof(u64));
@@ -662,7 +663,7 @@ extern "C" int lbzamd_decompress_device(lbzamd_dctx *c, const void *d_in_v, size
     HIPCHK(hipEventRecord(c->ev[2], q));
     hipLaunchKernelGGL(k_dsort, dim3(nb), dim3(256), 0, q, (const lbz_dblock *)c->blocks, nb, (const u8 *)c->tt8, (const u32 *)c->ftab, c->tt, c->cap);
     HIPCHK(hipEventRecord(c->ev[3], q));
-    hipLaunchKernelGGL(k_dwalk, dim3(nb), dim3(64), 0, q, c->blocks, nb, (const u32 *)c->tt, c->W, c->cap);
+    hipLaunchKernelGGL(k_dwalk, dim3(nb), dim3(256), 0, q, c->blocks, nb, (const u32 *)c->tt, c->W, c->pinfo, c->cap);
     HIPCHK(hipEventRecord(c->ev[4], q));
     HIPCHK(hipMemcpyAsync(hb.data() + b0, c->blocks, nb * sizeof(lbz_dblock), hipMemcpyDeviceToHost, q));
     HIPCHK(hipStreamSynchronize(q));
@@ -681,7 +682,7 @@ extern "C" int lbzamd_decompress_device(lbzamd_dctx *c, const void *d_in_v, size
     if (total <= out_cap && d_out) {
       HIPCHK(hipMemcpyAsync(c->blocks, hb.data() + b0, nb * sizeof(lbz_dblock), hipMemcpyHostToDevice, q));
       HIPCHK(hipEventRecord(c->ev[5], q));
-      hipLaunchKernelGGL(k_demit, dim3(nb), dim3(64), 0, q, (const lbz_dblock *)c->blocks, nb, (const u8 *)c->W, d_out, (u64)out_cap, c->cap);
+      hipLaunchKernelGGL(k_demit, dim3(nb * 8u), dim3(256), 0, q, (const lbz_dblock *)c->blocks, nb, (const u8 *)c->W, (const u32 *)c->pinfo, d_out, (u64)out_cap, c->cap);
       HIPCHK(hipEventRecord(c->ev[6], q));
       HIPCHK(hipStreamSynchronize(q));
       HIPCHK(hipGetLastError());
