@@ -20,56 +20,77 @@
 #include "lbz_kernels.h"
 
 #define DEC_MAX_SEL 18002u
+#define DEC_LUT_BITS 10u
 
 struct dec_lds {
+  u16 lut[LBZ_MAX_TREES][1u << DEC_LUT_BITS];   /* next 10 bits -> symbol << 5 | code length; 0: a longer code (or none) */
   int limit[LBZ_MAX_TREES][24];       /* per code length l: largest 20-bit window whose top l bits are a code of length <= l (-1: none) */
   int base[LBZ_MAX_TREES][24];        /* perm index = (window >> (20 - l)) - base */
   u16 perm[LBZ_MAX_TREES][LBZ_MAX_ALPHA + 2];
   u8 minlen[LBZ_MAX_TREES], maxlen[LBZ_MAX_TREES];
   u8 len[LBZ_MAX_TREES][LBZ_MAX_ALPHA + 2];
+  u32 sel[(DEC_MAX_SEL + 7u) / 8u + 1u];        /* tree of every 50-symbol group, 4 bits each */
   u8 seq2unseq[256];
-  u8 mtf[256];
-  u32 unzftab[256];
 };
 
-/* MSB-first bit cursor over the stream in global memory (one lane) */
-struct bitrd {
-  const u8 *in;
-  u64 nbytes;
-  u64 pos;        /* next byte to load */
-  u64 buf;        /* left-aligned */
+/* MSB-first bit cursor, the same in every lane of the wave (all its state is wave-uniform and lives in
+ * scalar registers): the stream is fetched 256 bytes at a time -- one aligned dword per lane, a chunk ahead --
+ * and the cursor takes its dwords out of the vector register with v_readlane, so the serial decoding chain
+ * never waits on memory.  Dwords are aligned to the allocation, not to `in`; bytes outside [in, in + nbytes)
+ * read as zero.                                                                                            */
+struct ubit {
+  const u32 *base;
+  u64 ndw, dw;        /* dwords covering the stream; next dword to take */
+  u32 tailmask;       /* valid bytes of the last dword */
+  u32 cur, nxt;       /* per lane: dword (chunk * 64 + lane) of the current / the next chunk */
+  u64 buf;            /* left-aligned */
   u32 live;
+  u32 lead;           /* bits in front of in[0] in dword 0 */
 };
-__device__ __forceinline__ void br_fill(bitrd *b)
+__device__ __forceinline__ u32 rfl(u32 v) { return (u32)__builtin_amdgcn_readfirstlane((int)v); }
+__device__ __forceinline__ u64 rfl64(u64 v) { return (u64)rfl((u32)v) | (u64)rfl((u32)(v >> 32)) << 32; }
+__device__ __forceinline__ u32 ub_chunk(const ubit *b, u64 chunk)
 {
-  while (b->live <= 56u) {
-    const u64 v = b->pos < b->nbytes ? b->in[b->pos] : 0u;
-    b->pos++;
-    b->buf |= v << (56u - b->live);
-    b->live += 8u;
+  const u64 i = chunk * 64u + lane_id();
+  u32 v = i < b->ndw ? b->base[i] : 0u;
+  if (i + 1u == b->ndw) v &= b->tailmask;
+  return v;
+}
+__device__ __forceinline__ void ub_refill(ubit *b)
+{
+  while (b->live <= 32u) {
+    const u32 v = (u32)__builtin_amdgcn_readlane((int)b->cur, (int)(b->dw & 63u));
+    b->dw++;
+    if ((b->dw & 63u) == 0u) { b->cur = b->nxt; b->nxt = ub_chunk(b, (b->dw >> 6) + 1u); }
+    b->buf |= (u64)__builtin_bswap32(v) << (32u - b->live);
+    b->live += 32u;
   }
 }
-__device__ __forceinline__ void br_init(bitrd *b, const u8 *in, u64 nbytes, u64 bitpos)
+__device__ __forceinline__ void ub_init(ubit *b, const u8 *in, u64 nbytes, u64 bitpos)
 {
-  b->in = in; b->nbytes = nbytes; b->pos = bitpos >> 3; b->buf = 0; b->live = 0;
-  br_fill(b);
-  const u32 skip = (u32)(bitpos & 7u);
+  const u32 mis = (u32)((uintptr_t)in & 3u);
+  b->base = reinterpret_cast<const u32 *>(in - mis);
+  b->ndw = (mis + nbytes + 3u) / 4u;
+  const u32 tb = (u32)((mis + nbytes) & 3u);
+  b->tailmask = tb ? (1u << (8u * tb)) - 1u : 0xFFFFFFFFu;
+  b->lead = mis * 8u;
+  const u64 off = bitpos + b->lead;
+  b->dw = off >> 5;
+  b->cur = ub_chunk(b, b->dw >> 6);
+  b->nxt = ub_chunk(b, (b->dw >> 6) + 1u);
+  b->buf = 0; b->live = 0;
+  ub_refill(b);
+  const u32 skip = (u32)(off & 31u);
   b->buf <<= skip; b->live -= skip;
 }
-__device__ __forceinline__ u32 br_get(bitrd *b, u32 n)      /* 1 <= n <= 32 */
+__device__ __forceinline__ u32 ub_get(ubit *b, u32 n)      /* 1 <= n <= 32 */
 {
-  if (b->live < n) br_fill(b);
+  if (b->live < n) ub_refill(b);
   const u32 v = (u32)(b->buf >> (64u - n));
   b->buf <<= n; b->live -= n;
   return v;
 }
-__device__ __forceinline__ u32 br_peek20(bitrd *b)
-{
-  if (b->live < 20u) br_fill(b);
-  return (u32)(b->buf >> 44);
-}
-__device__ __forceinline__ void br_skip(bitrd *b, u32 n) { b->buf <<= n; b->live -= n; }
-__device__ __forceinline__ u64 br_bitpos(const bitrd *b) { return b->pos * 8ull - b->live; }
+__device__ __forceinline__ u64 ub_bitpos(const ubit *b) { return b->dw * 32ull - b->live - b->lead; }
 
 /* ------------------------------------------------------------------ k_dscan */
 /* marks[]: bit position << 1 | kind (0 = block magic 0x314159265359, 1 = end-of-stream magic
@@ -93,10 +114,13 @@ k_dscan(const u8 *in, u64 nbytes, u64 *marks, u32 *nmarks, u32 cap)
 }
 
 /* ------------------------------------------------------------------ k_dhuff */
-/* One wave per block, lane 0 works: the whole stage is one dependent chain (bit cursor -> code ->
- * move-to-front list -> output position).                                                        */
+/* One wave per block.  The stage is one dependent chain (bit cursor -> code -> move-to-front list -> output
+ * position), so the whole wave walks it in lockstep with wave-uniform state and the lanes are used as storage
+ * and for the wide parts: the input window (ubit), the move-to-front list (256 entries in four vector
+ * registers: a front move is one wave_shr), the code tables (built 64 symbols at a time), zero-run fills.
+ * Codes of up to 10 bits -- nearly all -- resolve with one LDS lookup.                                     */
 __global__ void __launch_bounds__(64)
-k_dhuff(const u8 *in, u64 nbytes, lbz_dblock *blocks, u32 nblk, u8 *tt8_base, u32 *ftab_base, u8 *sel_base, u32 cap)
+k_dhuff(const u8 *in, u64 nbytes, lbz_dblock *blocks, u32 nblk, u8 *tt8_base, u32 cap)
 {
   __shared__ dec_lds S;
   const u32 lane = threadIdx.x;
@@ -104,125 +128,175 @@ k_dhuff(const u8 *in, u64 nbytes, lbz_dblock *blocks, u32 nblk, u8 *tt8_base, u3
   if (blk >= nblk) return;
   lbz_dblock *D = &blocks[blk];
   u8 *tt8 = tt8_base + (size_t)blk * cap;
-  u8 *sel = sel_base + (size_t)blk * DEC_MAX_SEL;
-  const u32 maxn = D->max_block < cap ? D->max_block : cap;
-  for (u32 i = lane; i < 256u; i += 64u) { S.unzftab[i] = 0; S.mtf[i] = (u8)i; }
-  __syncthreads();
-  if (lane == 0u) {
-    bitrd b;
-    br_init(&b, in, nbytes, D->bit_start);
-    u32 err = 0, n = 0;
-    D->stored_crc = br_get(&b, 32);
-    D->randomised = br_get(&b, 1);
-    D->orig_ptr = br_get(&b, 24);
-    /* used-byte map */
-    const u32 big = br_get(&b, 16);
-    u32 ninuse = 0;
-    for (u32 i = 0; i < 16u; i++)
-      if (big & (0x8000u >> i)) {
-        const u32 small = br_get(&b, 16);
-        for (u32 j = 0; j < 16u; j++) if (small & (0x8000u >> j)) S.seq2unseq[ninuse++] = (u8)(16u * i + j);
-      }
-    if (ninuse == 0u) err = 1;
-    const u32 alpha = ninuse + 2u, eob = alpha - 1u;
-    const u32 ngroups = br_get(&b, 3);
-    const u32 nsel = br_get(&b, 15);
-    if (!err && (ngroups < 2u || ngroups > LBZ_MAX_TREES || nsel < 1u)) err = 2;
-    /* selectors: unary move-to-front codes */
-    if (!err) {
-      u8 order[LBZ_MAX_TREES];
-      for (u32 i = 0; i < LBZ_MAX_TREES; i++) order[i] = (u8)i;
-      for (u32 i = 0; i < nsel && !err; i++) {
-        u32 j = 0;
-        while (br_get(&b, 1)) { j++; if (j >= ngroups) { err = 3; break; } }
-        if (err) break;
-        const u8 t = order[j];
-        for (u32 k = j; k > 0; k--) order[k] = order[k - 1u];
-        order[0] = t;
-        if (i < DEC_MAX_SEL) sel[i] = t;
+  const u32 maxn = rfl(D->max_block < cap ? D->max_block : cap);
+  ubit b;
+  ub_init(&b, in, nbytes, rfl64(D->bit_start));
+  u32 err = 0, n = 0;
+  const u32 stored_crc = ub_get(&b, 32);
+  const u32 randomised = ub_get(&b, 1);
+  const u32 orig_ptr = ub_get(&b, 24);
+  /* used-byte map */
+  const u32 big = ub_get(&b, 16);
+  u32 ninuse = 0;
+  for (u32 i = 0; i < 16u; i++)
+    if (big & (0x8000u >> i)) {
+      const u32 small = ub_get(&b, 16);
+      if (lane < 16u && (small & (0x8000u >> lane))) S.seq2unseq[ninuse + (u32)__popc(small >> (16u - lane))] = (u8)(16u * i + lane);
+      ninuse += (u32)__popc(small);
+    }
+  if (ninuse == 0u) err = 1;
+  const u32 alpha = ninuse + 2u, eob = alpha - 1u;
+  const u32 ngroups = ub_get(&b, 3);
+  const u32 nsel = ub_get(&b, 15);
+  if (!err && (ngroups < 2u || ngroups > LBZ_MAX_TREES || nsel < 1u)) err = 2;
+  /* selectors: unary move-to-front codes; the six-entry list is a word of nibbles */
+  if (!err) {
+    u32 order = 0x543210u, acc = 0;
+    for (u32 i = 0; i < nsel; i++) {
+      if (b.live < 6u) ub_refill(&b);
+      const u32 v6 = (u32)(b.buf >> 58);
+      const u32 j = (u32)__clz(~(v6 << 26));                       /* leading ones */
+      if (j >= ngroups) { err = 3; break; }
+      b.buf <<= j + 1u; b.live -= j + 1u;
+      const u32 t = (order >> (4u * j)) & 15u;
+      const u32 lowmask = (1u << (4u * j)) - 1u;
+      order = (order & ~((lowmask << 4) | 15u)) | ((order & lowmask) << 4) | t;
+      if (i < DEC_MAX_SEL) {
+        acc |= t << (4u * (i & 7u));
+        if ((i & 7u) == 7u || i + 1u == nsel || i + 1u == DEC_MAX_SEL) { if (lane == 0u) S.sel[i >> 3] = acc; acc = 0; }
       }
     }
-    /* code lengths: 5-bit start, then +1 / -1 steps (what encode.c:1231-1255 writes) */
-    for (u32 t = 0; t < ngroups && !err; t++) {
-      int cur = (int)br_get(&b, 5);
-      for (u32 v = 0; v < alpha && !err; v++) {
-        for (;;) {
-          if (cur < 1 || cur > 20) { err = 4; break; }
-          if (!br_get(&b, 1)) break;
-          cur += br_get(&b, 1) ? -1 : 1;
-        }
-        S.len[t][v] = (u8)cur;
-      }
-    }
-    /* canonical decoding tables (codes of one length are consecutive, lengths ascend; the format's own rule) */
-    for (u32 t = 0; t < ngroups && !err; t++) {
-      u32 mn = 32, mx = 0;
-      for (u32 v = 0; v < alpha; v++) { const u32 l = S.len[t][v]; mn = l < mn ? l : mn; mx = l > mx ? l : mx; }
-      S.minlen[t] = (u8)mn; S.maxlen[t] = (u8)mx;
-      u32 pp = 0, vec = 0;
-      for (u32 l = mn; l <= mx; l++) {
-        u32 cnt = 0;
-        const u32 before = pp;                                    /* symbols with a shorter code */
-        for (u32 v = 0; v < alpha; v++) if (S.len[t][v] == l) { S.perm[t][pp++] = (u16)v; cnt++; }
-        const u32 first = vec;                                    /* first code of this length */
-        vec += cnt;
-        S.limit[t][l] = (int)(vec << (20u - l)) - 1;              /* vec - 1 is the last code of length <= l; -1 if none */
-        S.base[t][l] = (int)first - (int)before;
-        vec <<= 1;
-      }
-    }
-    /* symbols */
-    if (!err) {
-      u32 groupno = 0, grouppos = 0, t = 0;
-      u32 es = 0, N = 1;
+  }
+  /* code lengths: 5-bit start, then +1 / -1 steps (what encode.c:1231-1255 writes) */
+  for (u32 t = 0; t < ngroups && !err; t++) {
+    int cur = (int)ub_get(&b, 5);
+    for (u32 v = 0; v < alpha && !err; v++) {
       for (;;) {
-        if (grouppos == 0u) {
-          if (groupno >= nsel) { err = 5; break; }
-          t = sel[groupno++]; grouppos = LBZ_GROUP;
-        }
-        grouppos--;
-        const u32 code = br_peek20(&b);
-        u32 l = S.minlen[t];
-        const u32 mx = S.maxlen[t];
-        while (l <= mx && (int)code > S.limit[t][l]) l++;
-        if (l > mx) { err = 6; break; }
-        br_skip(&b, l);
-        const int pi = (int)(code >> (20u - l)) - S.base[t][l];
-        if (pi < 0 || pi >= (int)alpha) { err = 6; break; }
-        const u32 sym = S.perm[t][pi];
-        if (sym <= 1u) {                                         /* RUNA / RUNB: bijective base-2 digits of a zero run */
-          es += (sym == 0u ? N : 2u * N);
-          N <<= 1;
-          if (N > (1u << 21)) { err = 7; break; }
-          continue;
-        }
-        if (es) {
-          const u8 uc = S.seq2unseq[S.mtf[0]];
-          if (n + es > maxn) { err = 8; break; }
-          for (u32 i = 0; i < es; i++) tt8[n + i] = uc;
-          S.unzftab[uc] += es;
-          n += es; es = 0; N = 1;
-        }
-        if (sym == eob) break;
-        const u32 nn = sym - 1u;
-        const u8 m = S.mtf[nn];
-        for (u32 k = nn; k > 0; k--) S.mtf[k] = S.mtf[k - 1u];
-        S.mtf[0] = m;
-        const u8 uc = S.seq2unseq[m];
-        if (n >= maxn) { err = 8; break; }
-        tt8[n++] = uc;
-        S.unzftab[uc]++;
+        if (cur < 1 || cur > 20) { err = 4; break; }
+        if (b.live < 2u) ub_refill(&b);
+        const u32 two = (u32)(b.buf >> 62);
+        if (!(two & 2u)) { b.buf <<= 1; b.live -= 1u; break; }
+        cur += (two & 1u) ? -1 : 1;
+        b.buf <<= 2; b.live -= 2u;
       }
+      if (lane == 0u) S.len[t][v] = (u8)cur;
     }
-    if (!err && D->randomised) err = 10;                         /* obsolete format variant, never written by lbzip2 */
-    if (!err && (n == 0u || D->orig_ptr >= n)) err = 9;
-    D->nblock = err ? 0u : n;
-    D->err = err;
-    D->bit_used = br_bitpos(&b);
   }
   __syncthreads();
-  u32 *ftab = ftab_base + (size_t)blk * 256u;
-  for (u32 i = lane; i < 256u; i += 64u) ftab[i] = S.unzftab[i];
+  /* canonical decoding tables (codes of one length are consecutive, lengths ascend; the format's own rule),
+     64 symbols at a time */
+  for (u32 i = lane; i < LBZ_MAX_TREES * (1u << DEC_LUT_BITS) / 2u; i += 64u) reinterpret_cast<u32 *>(&S.lut[0][0])[i] = 0;
+  __syncthreads();
+  for (u32 t = 0; t < ngroups && !err; t++) {
+    u32 ln[5];
+#pragma unroll
+    for (u32 k = 0; k < 5u; k++) { const u32 v = lane + 64u * k; ln[k] = v < alpha ? S.len[t][v] : 0u; }
+    u32 mn = 32, mx = 0;
+#pragma unroll
+    for (u32 k = 0; k < 5u; k++) if (ln[k]) { mn = ln[k] < mn ? ln[k] : mn; mx = ln[k] > mx ? ln[k] : mx; }
+    mn = rfl(wave_min(mn)); mx = rfl(wave_max(mx));
+    if (lane == 0u) { S.minlen[t] = (u8)mn; S.maxlen[t] = (u8)mx; }
+    u32 pp = 0, vec = 0;
+    for (u32 l = mn; l <= mx; l++) {
+      u32 below = 0;
+#pragma unroll
+      for (u32 k = 0; k < 5u; k++) {
+        const bool mine = ln[k] == l;
+        const u64 m = __ballot(mine);
+        if (mine) {
+          const u32 v = lane + 64u * k;
+          const u32 r = below + (u32)__popcll(m & lanes_below());
+          S.perm[t][pp + r] = (u16)v;
+          const u32 code = vec + r;
+          if (code >> l) err = 4;                                 /* more codes than the length admits */
+          else if (l <= DEC_LUT_BITS) {
+            const u32 e = v << 5 | l, first = code << (DEC_LUT_BITS - l);
+            for (u32 j = 0; j < (1u << (DEC_LUT_BITS - l)); j++) S.lut[t][first + j] = (u16)e;
+          }
+        }
+        below += (u32)__popcll(m);
+      }
+      const u32 first = vec;
+      vec += below;
+      if (lane == 0u) {
+        S.limit[t][l] = (int)(vec << (20u - l)) - 1;              /* vec - 1 is the last code of length <= l; -1 if none */
+        S.base[t][l] = (int)first - (int)pp;
+      }
+      pp += below;
+      vec <<= 1;
+    }
+    err = rfl(wave_max(err));
+  }
+  __syncthreads();
+  /* symbols */
+  if (!err) {
+    int L0 = (int)S.seq2unseq[lane], L1 = (int)S.seq2unseq[lane + 64u], L2 = (int)S.seq2unseq[lane + 128u], L3 = (int)S.seq2unseq[lane + 192u];
+    u32 groupno = 0, grouppos = 0, t = 0;
+    u32 es = 0, N = 0;
+    for (;;) {
+      if (grouppos == 0u) {
+        if (groupno >= nsel) { err = 5; break; }
+        t = groupno < DEC_MAX_SEL ? (rfl(S.sel[groupno >> 3]) >> (4u * (groupno & 7u))) & 15u : 0u;
+        groupno++; grouppos = LBZ_GROUP;
+      }
+      grouppos--;
+      if (b.live < 20u) ub_refill(&b);
+      const u32 e = rfl(S.lut[t][(u32)(b.buf >> (64u - DEC_LUT_BITS))]);
+      u32 l, sym;
+      if (e) { l = e & 31u; sym = e >> 5; }
+      else {
+        const u32 code = (u32)(b.buf >> 44);
+        l = rfl(S.minlen[t]);
+        const u32 mx = rfl(S.maxlen[t]);
+        while (l <= mx && (int)code > (int)rfl((u32)S.limit[t][l])) l++;
+        if (l > mx) { err = 6; break; }
+        const int pi = (int)(code >> (20u - l)) - (int)rfl((u32)S.base[t][l]);
+        if (pi < 0 || pi >= (int)alpha) { err = 6; break; }
+        sym = rfl(S.perm[t][pi]);
+      }
+      b.buf <<= l; b.live -= l;
+      if (sym <= 1u) {                                           /* RUNA / RUNB: bijective base-2 digits of a zero run */
+        es += (sym + 1u) << N;
+        N++;
+        if (N > 21u) { err = 7; break; }
+        continue;
+      }
+      if (es) {
+        if (n + es > maxn) { err = 8; break; }
+        const u32 uc = (u32)__builtin_amdgcn_readlane(L0, 0);
+        for (u32 i = lane; i < es; i += 64u) tt8[n + i] = (u8)uc;
+        n += es; es = 0; N = 0;
+      }
+      if (sym == eob) break;
+      const u32 nn = sym - 1u;
+      u32 m;
+      if (nn < 64u) {
+        m = (u32)__builtin_amdgcn_readlane(L0, (int)nn);
+        const int sh = wave_shr1(L0);
+        L0 = lane == 0u ? (int)m : (lane <= nn ? sh : L0);
+      } else {
+        const u32 q = nn >> 6, r = nn & 63u;
+        const int c0 = __builtin_amdgcn_readlane(L0, 63), c1 = __builtin_amdgcn_readlane(L1, 63), c2 = __builtin_amdgcn_readlane(L2, 63);
+        m = (u32)__builtin_amdgcn_readlane(q == 1u ? L1 : (q == 2u ? L2 : L3), (int)r);
+        const int s0 = wave_shr1(L0), s1 = wave_shr1(L1), s2 = wave_shr1(L2), s3 = wave_shr1(L3);
+        L0 = lane == 0u ? (int)m : s0;
+        L1 = lane == 0u ? c0 : ((q > 1u || lane <= r) ? s1 : L1);
+        if (q >= 2u) L2 = lane == 0u ? c1 : ((q > 2u || lane <= r) ? s2 : L2);
+        if (q >= 3u) L3 = lane == 0u ? c2 : (lane <= r ? s3 : L3);
+      }
+      if (n >= maxn) { err = 8; break; }
+      if (lane == 0u) tt8[n] = (u8)m;
+      n++;
+    }
+  }
+  if (!err && randomised) err = 10;                               /* obsolete format variant, never written by lbzip2 */
+  if (!err && (n == 0u || orig_ptr >= n)) err = 9;
+  if (lane == 0u) {
+    D->stored_crc = stored_crc; D->randomised = randomised; D->orig_ptr = orig_ptr;
+    D->nblock = err ? 0u : n;
+    D->err = err;
+    D->bit_used = ub_bitpos(&b);
+  }
 }
 
 /* ------------------------------------------------------------------ k_dsort */
@@ -230,7 +304,7 @@ k_dhuff(const u8 *in, u64 nbytes, lbz_dblock *blocks, u32 nblk, u8 *tt8_base, u3
  * Stable counting sort, 256 positions at a time: ranks inside a wave from match-any ballots, the four
  * waves of a tile in order through per-wave digit counts.                                          */
 __global__ void __launch_bounds__(256)
-k_dsort(const lbz_dblock *blocks, u32 nblk, const u8 *tt8_base, const u32 *ftab_base, u32 *tt_base, u32 cap)
+k_dsort(const lbz_dblock *blocks, u32 nblk, const u8 *tt8_base, u32 *tt_base, u32 cap)
 {
   __shared__ u32 cf[256];
   __shared__ u32 wcnt[4][256];
@@ -243,8 +317,25 @@ k_dsort(const lbz_dblock *blocks, u32 nblk, const u8 *tt8_base, const u32 *ftab_
   if (D->err || n == 0u) return;
   const u8 *tt8 = tt8_base + (size_t)blk * cap;
   u32 *tt = tt_base + (size_t)blk * cap;
+  for (u32 i = tid; i < 1024u; i += 256u) (&wcnt[0][0])[i] = 0;
+  __syncthreads();
+  for (u32 i0 = 0; i0 < n; i0 += 256u) {                        /* byte counts (a wave's equal bytes in one add) and tt = bytes */
+    const u32 i = i0 + tid;
+    const bool ok = i < n;
+    const u32 d = ok ? tt8[i] : 0u;
+    if (ok) tt[i] = d;
+    u64 mask = __ballot(ok);
+#pragma unroll
+    for (u32 bb = 0; bb < 8u; bb++) {
+      const bool bit = (d >> bb) & 1u;
+      const u64 bal = __ballot(bit);
+      mask &= bit ? bal : ~bal;
+    }
+    if (ok && (mask & lanes_below()) == 0ull) wcnt[w][d] += (u32)__popcll(mask);
+  }
+  __syncthreads();
   {
-    const u32 c = ftab_base[(size_t)blk * 256u + tid];
+    const u32 c = wcnt[0][tid] + wcnt[1][tid] + wcnt[2][tid] + wcnt[3][tid];
     u32 inc = c;
     for (u32 d = 1; d < 64u; d <<= 1) { const u32 o = (u32)__shfl_up((int)inc, d); if (lane >= d) inc += o; }
     if (lane == 63u) wsum[w] = inc;
@@ -253,7 +344,6 @@ k_dsort(const lbz_dblock *blocks, u32 nblk, const u8 *tt8_base, const u32 *ftab_
     for (u32 i = 0; i < w; i++) basev += wsum[i];
     cf[tid] = basev + inc - c;
   }
-  for (u32 i = tid; i < n; i += 256u) tt[i] = tt8[i];
   __syncthreads();
   for (u32 t0 = 0; t0 < n; t0 += 256u) {
     for (u32 i = tid; i < 1024u; i += 256u) (&wcnt[0][0])[i] = 0;

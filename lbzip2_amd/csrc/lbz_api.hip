@@ -527,8 +527,8 @@ struct lbzamd_dctx {
   uint32_t max_blocks = 0, cap = 0;          /* cap: elements per block in the per-block arrays */
   hipStream_t q = nullptr;
   hipEvent_t ev[7] = {};
-  u8 *tt8 = nullptr, *W = nullptr, *sel = nullptr;
-  u32 *tt = nullptr, *ftab = nullptr, *nmarks = nullptr, *pinfo = nullptr;
+  u8 *tt8 = nullptr, *W = nullptr;
+  u32 *tt = nullptr, *nmarks = nullptr, *pinfo = nullptr;
   u64 *marks = nullptr;
   lbz_dblock *blocks = nullptr;
   u8 *d_in = nullptr, *d_out = nullptr;
@@ -540,7 +540,7 @@ struct lbzamd_dctx {
 extern "C" void lbzamd_ddestroy(lbzamd_dctx *c)
 {
   if (!c) return;
-  (void)hipFree(c->tt8); (void)hipFree(c->W); (void)hipFree(c->sel); (void)hipFree(c->tt); (void)hipFree(c->ftab);
+  (void)hipFree(c->tt8); (void)hipFree(c->W); (void)hipFree(c->tt);
   (void)hipFree(c->pinfo); (void)hipFree(c->nmarks); (void)hipFree(c->marks); (void)hipFree(c->blocks); (void)hipFree(c->d_in); (void)hipFree(c->d_out);
   for (auto &e : c->ev) if (e) (void)hipEventDestroy(e);
   if (c->q) (void)hipStreamDestroy(c->q);
@@ -565,9 +565,7 @@ extern "C" int lbzamd_dcreate(lbzamd_dctx **out, int device, unsigned max_blocks
   DALLOC(c->tt8, (size_t)max_blocks * c->cap);
   DALLOC(c->W, (size_t)max_blocks * c->cap);
   DALLOC(c->tt, (size_t)max_blocks * c->cap * sizeof(u32));
-  DALLOC(c->sel, (size_t)max_blocks * 18002u);
   DALLOC(c->pinfo, (size_t)max_blocks * (c->cap / 16u) * sizeof(u32));
-  DALLOC(c->ftab, (size_t)max_blocks * 256u * sizeof(u32));
   DALLOC(c->blocks, (size_t)max_blocks * sizeof(lbz_dblock));
   DALLOC(c->marks, (size_t)c->marks_cap * sizeof(u64));
   DALLOC(c->nmarks, sizeof(u32));
@@ -659,9 +657,9 @@ extern "C" int lbzamd_decompress_device(lbzamd_dctx *c, const void *d_in_v, size
     const u32 nb = (u32)std::min<size_t>(c->max_blocks, hb.size() - b0);
     HIPCHK(hipMemcpyAsync(c->blocks, hb.data() + b0, nb * sizeof(lbz_dblock), hipMemcpyHostToDevice, q));
     HIPCHK(hipEventRecord(c->ev[1], q));
-    hipLaunchKernelGGL(k_dhuff, dim3(nb), dim3(64), 0, q, d_in, (u64)len, c->blocks, nb, c->tt8, c->ftab, c->sel, c->cap);
+    hipLaunchKernelGGL(k_dhuff, dim3(nb), dim3(64), 0, q, d_in, (u64)len, c->blocks, nb, c->tt8, c->cap);
     HIPCHK(hipEventRecord(c->ev[2], q));
-    hipLaunchKernelGGL(k_dsort, dim3(nb), dim3(256), 0, q, (const lbz_dblock *)c->blocks, nb, (const u8 *)c->tt8, (const u32 *)c->ftab, c->tt, c->cap);
+    hipLaunchKernelGGL(k_dsort, dim3(nb), dim3(256), 0, q, (const lbz_dblock *)c->blocks, nb, (const u8 *)c->tt8, c->tt, c->cap);
     HIPCHK(hipEventRecord(c->ev[3], q));
     hipLaunchKernelGGL(k_dwalk, dim3(nb), dim3(256), 0, q, c->blocks, nb, (const u32 *)c->tt, c->W, c->pinfo, c->cap);
     HIPCHK(hipEventRecord(c->ev[4], q));

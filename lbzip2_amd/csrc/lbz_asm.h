@@ -12,6 +12,12 @@ __device__ __forceinline__ int lane_write(int old, int val, int lane)
   return old;
 }
 
+/* wave_shr:1 -- lane l of the result is lane l - 1 of v (lane 0: v's own lane 0) */
+__device__ __forceinline__ int wave_shr1(int v)
+{
+  return __builtin_amdgcn_update_dpp(v, v, 0x138, 0xf, 0xf, false);
+}
+
 /* One claim per wave from an LDS ticket counter (all 64 lanes active): returns 0, 1, 2, ... in
  * claim order, wave-uniform.  Every lane adds one -- the compiler folds that into a single
  * ds_add_rtn of 64 by one lane -- because a claim written as `if (lane == 0) atomicAdd` inside a

@@ -3,6 +3,7 @@
 #ifndef LBZ_ASM_H
 #define LBZ_ASM_H
 static inline int lane_write(int old, int val, int lane) { return (int)(threadIdx.x & 63) == lane ? val : old; }
+static inline int wave_shr1(int v) { const int o = __shfl_up(v, 1u); return (threadIdx.x & 63) == 0 ? v : o; }
 /* lanes are fibers here and their atomics interleave with other waves': lane 0 takes the whole
  * wave's 64 tickets at once */
 static inline unsigned wave_claim(unsigned *tickets)
