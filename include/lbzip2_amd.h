@@ -149,7 +149,10 @@ typedef struct lbzamd_dctx lbzamd_dctx;
 typedef struct lbzamd_dstats {
   uint64_t n_in, n_out;
   uint32_t nblocks, nstreams;
-  float ms_scan, ms_huff, ms_sort, ms_walk, ms_emit, ms_total;
+  /* ms_scan, ms_blocks, ms_emit: HIP events around the three launches (ms_total = their sum).  A block's
+     codes, sort and walk run back to back in the ms_blocks kernel: ms_huff / ms_sort / ms_walk are the
+     SLOWEST block's stage times (device clock), so they need not add up to ms_blocks. */
+  float ms_scan, ms_huff, ms_sort, ms_walk, ms_emit, ms_total, ms_blocks;
 } lbzamd_dstats;
 int  lbzamd_dcreate(lbzamd_dctx **ctx, int device, unsigned max_blocks);
 void lbzamd_ddestroy(lbzamd_dctx *ctx);

@@ -57,7 +57,7 @@ def fold_parts(cc, parts):
 class DStats(C.Structure):
     _fields_ = [("n_in", C.c_uint64), ("n_out", C.c_uint64), ("nblocks", C.c_uint32), ("nstreams", C.c_uint32),
                 ("ms_scan", C.c_float), ("ms_huff", C.c_float), ("ms_sort", C.c_float), ("ms_walk", C.c_float),
-                ("ms_emit", C.c_float), ("ms_total", C.c_float)]
+                ("ms_emit", C.c_float), ("ms_total", C.c_float), ("ms_blocks", C.c_float)]
 
 
 class BlockInfo(C.Structure):

@@ -49,20 +49,23 @@ struct ubit {
 };
 __device__ __forceinline__ u32 rfl(u32 v) { return (u32)__builtin_amdgcn_readfirstlane((int)v); }
 __device__ __forceinline__ u64 rfl64(u64 v) { return (u64)rfl((u32)v) | (u64)rfl((u32)(v >> 32)) << 32; }
-__device__ __forceinline__ u32 ub_chunk(const ubit *b, u64 chunk)
+__device__ __forceinline__ u32 ub_chunk(const ubit *b, u64 chunk)          /* the raw dwords: nothing here waits for the load */
 {
   const u64 i = chunk * 64u + lane_id();
-  u32 v = i < b->ndw ? b->base[i] : 0u;
-  if (i + 1u == b->ndw) v &= b->tailmask;
-  return v;
+  return i < b->ndw ? b->base[i] : 0u;
+}
+__device__ __forceinline__ u32 ub_cook(const ubit *b, u32 v, u64 chunk)    /* MSB first, once per dword instead of once per use */
+{
+  if (chunk * 64u + lane_id() + 1u == b->ndw) v &= b->tailmask;
+  return __builtin_bswap32(v);
 }
 __device__ __forceinline__ void ub_refill(ubit *b)
 {
   while (b->live <= 32u) {
     const u32 v = (u32)__builtin_amdgcn_readlane((int)b->cur, (int)(b->dw & 63u));
     b->dw++;
-    if ((b->dw & 63u) == 0u) { b->cur = b->nxt; b->nxt = ub_chunk(b, (b->dw >> 6) + 1u); }
-    b->buf |= (u64)__builtin_bswap32(v) << (32u - b->live);
+    if ((b->dw & 63u) == 0u) { b->cur = ub_cook(b, b->nxt, b->dw >> 6); b->nxt = ub_chunk(b, (b->dw >> 6) + 1u); }
+    b->buf |= (u64)v << (32u - b->live);
     b->live += 32u;
   }
 }
@@ -76,7 +79,7 @@ __device__ __forceinline__ void ub_init(ubit *b, const u8 *in, u64 nbytes, u64 b
   b->lead = mis * 8u;
   const u64 off = bitpos + b->lead;
   b->dw = off >> 5;
-  b->cur = ub_chunk(b, b->dw >> 6);
+  b->cur = ub_cook(b, ub_chunk(b, b->dw >> 6), b->dw >> 6);
   b->nxt = ub_chunk(b, (b->dw >> 6) + 1u);
   b->buf = 0; b->live = 0;
   ub_refill(b);
@@ -119,15 +122,9 @@ k_dscan(const u8 *in, u64 nbytes, u64 *marks, u32 *nmarks, u32 cap)
  * and for the wide parts: the input window (ubit), the move-to-front list (256 entries in four vector
  * registers: a front move is one wave_shr), the code tables (built 64 symbols at a time), zero-run fills.
  * Codes of up to 10 bits -- nearly all -- resolve with one LDS lookup.                                     */
-__global__ void __launch_bounds__(64)
-k_dhuff(const u8 *in, u64 nbytes, lbz_dblock *blocks, u32 nblk, u8 *tt8_base, u32 cap)
+__device__ __forceinline__ void dhuff_block(const u8 *in, u64 nbytes, lbz_dblock *D, u8 *tt8, u32 cap, dec_lds &S)
 {
-  __shared__ dec_lds S;
-  const u32 lane = threadIdx.x;
-  const u32 blk = blockIdx.x;
-  if (blk >= nblk) return;
-  lbz_dblock *D = &blocks[blk];
-  u8 *tt8 = tt8_base + (size_t)blk * cap;
+  const u32 lane = threadIdx.x;                  /* wave 0 of the workgroup */
   const u32 maxn = rfl(D->max_block < cap ? D->max_block : cap);
   ubit b;
   ub_init(&b, in, nbytes, rfl64(D->bit_start));
@@ -182,11 +179,11 @@ k_dhuff(const u8 *in, u64 nbytes, lbz_dblock *blocks, u32 nblk, u8 *tt8_base, u3
       if (lane == 0u) S.len[t][v] = (u8)cur;
     }
   }
-  __syncthreads();
+  wave_sync();
   /* canonical decoding tables (codes of one length are consecutive, lengths ascend; the format's own rule),
      64 symbols at a time */
   for (u32 i = lane; i < LBZ_MAX_TREES * (1u << DEC_LUT_BITS) / 2u; i += 64u) reinterpret_cast<u32 *>(&S.lut[0][0])[i] = 0;
-  __syncthreads();
+  wave_sync();
   for (u32 t = 0; t < ngroups && !err; t++) {
     u32 ln[5];
 #pragma unroll
@@ -209,7 +206,7 @@ k_dhuff(const u8 *in, u64 nbytes, lbz_dblock *blocks, u32 nblk, u8 *tt8_base, u3
           S.perm[t][pp + r] = (u16)v;
           const u32 code = vec + r;
           if (code >> l) err = 4;                                 /* more codes than the length admits */
-          else if (l <= DEC_LUT_BITS) {
+          else if (l <= DEC_LUT_BITS && v != eob) {               /* the end-of-block symbol takes the general step */
             const u32 e = v << 5 | l, first = code << (DEC_LUT_BITS - l);
             for (u32 j = 0; j < (1u << (DEC_LUT_BITS - l)); j++) S.lut[t][first + j] = (u16)e;
           }
@@ -227,24 +224,38 @@ k_dhuff(const u8 *in, u64 nbytes, lbz_dblock *blocks, u32 nblk, u8 *tt8_base, u3
     }
     err = rfl(wave_max(err));
   }
-  __syncthreads();
+  wave_sync();
   /* symbols */
   if (!err) {
     int L0 = (int)S.seq2unseq[lane], L1 = (int)S.seq2unseq[lane + 64u], L2 = (int)S.seq2unseq[lane + 128u], L3 = (int)S.seq2unseq[lane + 192u];
-    u32 groupno = 0, grouppos = 0, t = 0;
+    u32 groupno = 0, k = LBZ_GROUP, t = 0;
     u32 es = 0, N = 0;
     for (;;) {
-      if (grouppos == 0u) {
+      /* The common cases run in huff_fast() (lbz_asm.h): a dependent instruction costs a lone wave ~2.5 ns
+         whatever its kind and the table lookup ~37 ns (tests/micro/chain.hip), so that loop is written by
+         hand; it returns for anything else and one general step follows.                               */
+      if (k < LBZ_GROUP) {
+        u32 dwl = (u32)b.dw;
+        const u32 dwl0 = dwl;
+#ifdef LBZ_EMULATED
+        huff_fast(b.buf, b.live, dwl, b.cur, k, n, es, N, L0, L1, L2, L3, S.lut[t], tt8, maxn, lane);
+#else
+        huff_fast(b.buf, b.live, dwl, b.cur, k, n, es, N, L0, L1, L2, L3,
+                  (u32)(size_t)(const __attribute__((address_space(3))) void *)S.lut[t], tt8, maxn, lane);
+#endif
+        b.dw += dwl - dwl0;
+      }
+      if (k == LBZ_GROUP) {                                      /* a group: LBZ_GROUP symbols of one tree */
         if (groupno >= nsel) { err = 5; break; }
         t = groupno < DEC_MAX_SEL ? (rfl(S.sel[groupno >> 3]) >> (4u * (groupno & 7u))) & 15u : 0u;
-        groupno++; grouppos = LBZ_GROUP;
+        groupno++;
+        if (n > maxn) { err = 8; break; }                        /* the array has room for a group beyond maxn */
+        k = 0;
       }
-      grouppos--;
       if (b.live < 20u) ub_refill(&b);
       const u32 e = rfl(S.lut[t][(u32)(b.buf >> (64u - DEC_LUT_BITS))]);
-      u32 l, sym;
-      if (e) { l = e & 31u; sym = e >> 5; }
-      else {
+      u32 l = e & 31u, sym = e >> 5;
+      if (e == 0u) {                                             /* a long code or the end of the block */
         const u32 code = (u32)(b.buf >> 44);
         l = rfl(S.minlen[t]);
         const u32 mx = rfl(S.maxlen[t]);
@@ -255,6 +266,7 @@ k_dhuff(const u8 *in, u64 nbytes, lbz_dblock *blocks, u32 nblk, u8 *tt8_base, u3
         sym = rfl(S.perm[t][pi]);
       }
       b.buf <<= l; b.live -= l;
+      k++;
       if (sym <= 1u) {                                           /* RUNA / RUNB: bijective base-2 digits of a zero run */
         es += (sym + 1u) << N;
         N++;
@@ -264,6 +276,7 @@ k_dhuff(const u8 *in, u64 nbytes, lbz_dblock *blocks, u32 nblk, u8 *tt8_base, u3
       if (es) {
         if (n + es > maxn) { err = 8; break; }
         const u32 uc = (u32)__builtin_amdgcn_readlane(L0, 0);
+#pragma clang loop vectorize(disable) unroll(disable)
         for (u32 i = lane; i < es; i += 64u) tt8[n + i] = (u8)uc;
         n += es; es = 0; N = 0;
       }
@@ -284,10 +297,10 @@ k_dhuff(const u8 *in, u64 nbytes, lbz_dblock *blocks, u32 nblk, u8 *tt8_base, u3
         if (q >= 2u) L2 = lane == 0u ? c1 : ((q > 2u || lane <= r) ? s2 : L2);
         if (q >= 3u) L3 = lane == 0u ? c2 : (lane <= r ? s3 : L3);
       }
-      if (n >= maxn) { err = 8; break; }
       if (lane == 0u) tt8[n] = (u8)m;
       n++;
     }
+    if (!err && n > maxn) err = 8;
   }
   if (!err && randomised) err = 10;                               /* obsolete format variant, never written by lbzip2 */
   if (!err && (n == 0u || orig_ptr >= n)) err = 9;
@@ -303,20 +316,18 @@ k_dhuff(const u8 *in, u64 nbytes, lbz_dblock *blocks, u32 nblk, u8 *tt8_base, u3
 /* tt[k] = (position of the k-th byte in sorted order) << 8 | byte at position k  (decode.c:852-942).
  * Stable counting sort, 256 positions at a time: ranks inside a wave from match-any ballots, the four
  * waves of a tile in order through per-wave digit counts.                                          */
-__global__ void __launch_bounds__(256)
-k_dsort(const lbz_dblock *blocks, u32 nblk, const u8 *tt8_base, u32 *tt_base, u32 cap)
+struct sort_lds {
+  u32 cf[256];
+  u32 wcnt[4][256];
+  u32 wsum[4];
+};
+__device__ __forceinline__ void dsort_block(const lbz_dblock *D, const u8 *tt8, u32 *tt, sort_lds &S)
 {
-  __shared__ u32 cf[256];
-  __shared__ u32 wcnt[4][256];
-  __shared__ u32 wsum[4];
+  u32 (&cf)[256] = S.cf;
+  u32 (&wcnt)[4][256] = S.wcnt;
+  u32 (&wsum)[4] = S.wsum;
   const u32 tid = threadIdx.x, lane = tid & 63u, w = tid >> 6;
-  const u32 blk = blockIdx.x;
-  if (blk >= nblk) return;
-  const lbz_dblock *D = &blocks[blk];
   const u32 n = D->nblock;
-  if (D->err || n == 0u) return;
-  const u8 *tt8 = tt8_base + (size_t)blk * cap;
-  u32 *tt = tt_base + (size_t)blk * cap;
   for (u32 i = tid; i < 1024u; i += 256u) (&wcnt[0][0])[i] = 0;
   __syncthreads();
   for (u32 i0 = 0; i0 < n; i0 += 256u) {                        /* byte counts (a wave's equal bytes in one add) and tt = bytes */
@@ -424,20 +435,10 @@ __device__ __forceinline__ u32 crc_shift(const u32 *pow8, u32 v, u32 nbytes)    
 }
 __device__ __forceinline__ u32 rle_step(u32 c, bool eq) { return eq ? (c == 4u ? 0u : c + 1u) : (c == 4u ? 0u : 1u); }
 
-__global__ void __launch_bounds__(DW_T)
-k_dwalk(lbz_dblock *blocks, u32 nblk, const u32 *tt_base, u8 *W_base, u32 *pinfo_base, u32 cap)
+__device__ __forceinline__ void dwalk_block(lbz_dblock *D, const u32 *tt, u8 *W, u32 *pinfo, walk_lds &S)
 {
-  __shared__ walk_lds S;
   const u32 tid = threadIdx.x;
-  const u32 blk = blockIdx.x;
-  if (blk >= nblk) return;
-  lbz_dblock *D = &blocks[blk];
   const u32 n = D->nblock;
-  if (D->err || n == 0u) { if (tid == 0u) D->out_len = 0; return; }
-  const u32 *tt = tt_base + (size_t)blk * cap;
-  u8 *W = W_base + (size_t)blk * cap;
-  u32 *pinfo = pinfo_base + (size_t)blk * (cap / 16u);
-
   {
     u32 c = tid << 24;
     for (u32 k = 0; k < 8u; k++) c = (c & 0x80000000u) ? (c << 1) ^ CRC_POLY : c << 1;
@@ -588,6 +589,42 @@ k_dwalk(lbz_dblock *blocks, u32 nblk, const u32 *tt_base, u8 *W_base, u32 *pinfo
     D->out_len = total;
     if (cc != D->stored_crc) D->err = 11;
   }
+}
+
+/* ------------------------------------------------------------------ k_dblock */
+/* The three stages of one block in one workgroup: a block whose codes are done goes on to its sort and its
+ * walk while others still decode, so a pass takes the slowest block's chain, not the sum of the slowest of
+ * every stage.  Wave 0 decodes (the other three wait at the barrier); sort and walk use all four.       */
+union dblock_lds {
+  dec_lds h;
+  sort_lds s;
+  walk_lds w;
+};
+__global__ void __launch_bounds__(DW_T)
+k_dblock(const u8 *in, u64 nbytes, lbz_dblock *blocks, u32 nblk, u8 *tt8_base, u32 *tt_base, u8 *W_base, u32 *pinfo_base, u32 cap)
+{
+  __shared__ dblock_lds U;
+  const u32 tid = threadIdx.x;
+  const u32 blk = blockIdx.x;
+  if (blk >= nblk) return;
+  lbz_dblock *D = &blocks[blk];
+  u8 *tt8 = tt8_base + (size_t)blk * cap;
+  u32 *tt = tt_base + (size_t)blk * cap;
+  const u64 k0 = wall_clock64();
+  if (tid < 64u) dhuff_block(in, nbytes, D, tt8, cap, U.h);
+  __threadfence_block();
+  __syncthreads();
+  const u64 k1 = wall_clock64();
+  if (D->err || D->nblock == 0u) {
+    if (tid == 0u) { D->out_len = 0; D->tk[0] = (u32)(k1 - k0); D->tk[1] = D->tk[2] = 0; }
+    return;
+  }
+  dsort_block(D, tt8, tt, U.s);
+  __threadfence_block();
+  __syncthreads();
+  const u64 k2 = wall_clock64();
+  dwalk_block(D, tt, W_base + (size_t)blk * cap, pinfo_base + (size_t)blk * (cap / 16u), U.w);
+  if (tid == 0u) { D->tk[0] = (u32)(k1 - k0); D->tk[1] = (u32)(k2 - k1); D->tk[2] = (u32)(wall_clock64() - k2); }
 }
 
 /* ------------------------------------------------------------------ k_demit */

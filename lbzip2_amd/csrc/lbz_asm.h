@@ -18,6 +18,143 @@ __device__ __forceinline__ int wave_shr1(int v)
   return __builtin_amdgcn_update_dpp(v, v, 0x138, 0xf, 0xf, false);
 }
 
+/* The common cases of the decoder's symbol loop (k_decode.hip, dhuff_block), hand-scheduled: a lone wave
+ * issues one dependent instruction every ~2.5 ns whatever its kind, so the loop is as short as it can be made
+ * and stays in scalar registers.  All arguments are wave-uniform except L0..L3 (the move-to-front list, entry i in
+ * lane i & 63 of register i >> 6), cur (the input window, dword i of the current 256-byte chunk in lane i, MSB first) and lane.
+ *
+ * Per step: take 32 more bits when fewer than 20 are live; look the next 10 bits up (entry = symbol << 5 |
+ * length); RUNA/RUNB add to the pending zero run; any other symbol first stores a pending run of <= 64 bytes, then
+ * moves list entry symbol - 1 to the front and stores it (entries 64..255 live in L1..L3).  The loop RETURNS, with nothing of the current
+ * symbol consumed, when the group's 50 symbols are done, the table has no entry (long code, end of block),
+ * the run is longer than 64 or would overflow, or the next dword is the
+ * last of its chunk -- the caller takes one general step and comes back.                               */
+__device__ __forceinline__ void huff_fast(unsigned long long &buf, unsigned &live, unsigned &dwl, unsigned cur, unsigned &k,
+                                          unsigned &n, unsigned &es, unsigned &N, int &L0, int &L1, int &L2, int &L3,
+                                          unsigned lutaddr, unsigned char *tt8, unsigned maxn, unsigned lane)
+{
+  unsigned t0, t1, t2, e, l, sym, va, vb, vsh, ve;
+  asm volatile(
+    "s_mov_b64 s[40:41], %[buf]\n"
+    "HF_LOOP_%=:\n\t"
+    "s_cmp_ge_u32 %[k], 50\n\t"
+    "s_cbranch_scc1 HF_DONE_%=\n\t"
+    "s_cmp_ge_u32 %[live], 20\n\t"
+    "s_cbranch_scc1 HF_LOOK_%=\n\t"
+    "s_and_b32 %[t0], %[dwl], 63\n\t"
+    "s_cmp_eq_u32 %[t0], 63\n\t"
+    "s_cbranch_scc1 HF_DONE_%=\n\t"
+    "v_readlane_b32 s42, %[cur], %[t0]\n\t"
+    "s_mov_b32 s43, 0\n\t"
+    "s_sub_u32 %[t0], 32, %[live]\n\t"
+    "s_lshl_b64 s[42:43], s[42:43], %[t0]\n\t"
+    "s_or_b64 s[40:41], s[40:41], s[42:43]\n\t"
+    "s_add_u32 %[live], %[live], 32\n\t"
+    "s_add_u32 %[dwl], %[dwl], 1\n"
+    "HF_LOOK_%=:\n\t"
+    "s_lshr_b32 %[t0], s41, 21\n\t"
+    "s_and_b32 %[t0], %[t0], 0x7fe\n\t"
+    "s_add_u32 %[t0], %[t0], %[lut]\n\t"
+    "v_mov_b32 %[va], %[t0]\n\t"
+    "ds_read_u16 %[ve], %[va]\n\t"
+    "s_waitcnt lgkmcnt(0)\n\t"
+    "v_readfirstlane_b32 %[e], %[ve]\n\t"
+    "s_cmp_eq_u32 %[e], 0\n\t"
+    "s_cbranch_scc1 HF_DONE_%=\n\t"
+    "s_and_b32 %[l], %[e], 31\n\t"
+    "s_lshr_b32 %[sym], %[e], 5\n\t"
+    "s_cmp_le_u32 %[sym], 1\n\t"
+    "s_cbranch_scc1 HF_RUN_%=\n\t"
+    "s_sub_u32 %[sym], %[sym], 1\n\t"
+    "s_cmp_eq_u32 %[es], 0\n\t"
+    "s_cbranch_scc1 HF_LIT_%=\n\t"
+    "s_cmp_gt_u32 %[es], 64\n\t"
+    "s_cbranch_scc1 HF_DONE_%=\n\t"
+    "s_add_u32 %[t0], %[n], %[es]\n\t"
+    "s_cmp_gt_u32 %[t0], %[maxn]\n\t"
+    "s_cbranch_scc1 HF_DONE_%=\n\t"
+    "v_readlane_b32 %[t1], %[L0], 0\n\t"
+    "v_mov_b32 %[vb], %[t1]\n\t"
+    "v_add_u32 %[va], %[n], %[lane]\n\t"
+    "v_cmp_gt_u32 vcc, %[es], %[lane]\n\t"
+    "s_and_saveexec_b64 s[44:45], vcc\n\t"
+    "global_store_byte %[va], %[vb], %[tt8]\n\t"
+    "s_mov_b64 exec, s[44:45]\n\t"
+    "s_mov_b32 %[n], %[t0]\n\t"
+    "s_mov_b32 %[es], 0\n\t"
+    "s_mov_b32 %[N], 0\n"
+    "HF_LIT_%=:\n\t"
+    "s_lshl_b64 s[40:41], s[40:41], %[l]\n\t"
+    "s_sub_u32 %[live], %[live], %[l]\n\t"
+    "s_add_u32 %[k], %[k], 1\n\t"
+    "s_cmp_ge_u32 %[sym], 64\n\t"
+    "s_cbranch_scc1 HF_FAR_%=\n\t"
+    "v_readlane_b32 %[t1], %[L0], %[sym]\n\t"
+    "v_mov_b32_dpp %[vsh], %[L0] wave_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+    "v_cmp_ge_u32 vcc, %[sym], %[lane]\n\t"
+    "v_cndmask_b32 %[L0], %[L0], %[vsh], vcc\n\t"
+    "v_writelane_b32 %[L0], %[t1], 0\n\t"
+    "HF_OUT_%=:\n\t"
+    "v_mov_b32 %[vb], %[t1]\n\t"
+    "v_mov_b32 %[va], %[n]\n\t"
+    "global_store_byte %[va], %[vb], %[tt8]\n\t"
+    "s_add_u32 %[n], %[n], 1\n\t"
+    "s_branch HF_LOOP_%=\n"
+    /* a front move from entry 64..255: registers below the entry's shift whole, their last lanes carry over */
+    "HF_FAR_%=:\n\t"
+    "s_and_b32 %[t0], %[sym], 63\n\t"
+    "v_readlane_b32 %[t2], %[L0], 63\n\t"
+    "v_cmp_ge_u32 vcc, %[t0], %[lane]\n\t"
+    "s_cmp_ge_u32 %[sym], 128\n\t"
+    "s_cbranch_scc1 HF_FAR2_%=\n\t"
+    "v_readlane_b32 %[t1], %[L1], %[t0]\n\t"
+    "v_mov_b32_dpp %[vsh], %[L1] wave_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+    "v_cndmask_b32 %[L1], %[L1], %[vsh], vcc\n\t"
+    "v_writelane_b32 %[L1], %[t2], 0\n\t"
+    "s_branch HF_FAR0_%=\n"
+    "HF_FAR2_%=:\n\t"
+    "v_readlane_b32 s42, %[L1], 63\n\t"
+    "v_mov_b32_dpp %[L1], %[L1] wave_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+    "v_writelane_b32 %[L1], %[t2], 0\n\t"
+    "s_cmp_ge_u32 %[sym], 192\n\t"
+    "s_cbranch_scc1 HF_FAR3_%=\n\t"
+    "v_readlane_b32 %[t1], %[L2], %[t0]\n\t"
+    "v_mov_b32_dpp %[vsh], %[L2] wave_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+    "v_cndmask_b32 %[L2], %[L2], %[vsh], vcc\n\t"
+    "v_writelane_b32 %[L2], s42, 0\n\t"
+    "s_branch HF_FAR0_%=\n"
+    "HF_FAR3_%=:\n\t"
+    "v_readlane_b32 s43, %[L2], 63\n\t"
+    "v_mov_b32_dpp %[L2], %[L2] wave_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+    "v_writelane_b32 %[L2], s42, 0\n\t"
+    "v_readlane_b32 %[t1], %[L3], %[t0]\n\t"
+    "v_mov_b32_dpp %[vsh], %[L3] wave_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+    "v_cndmask_b32 %[L3], %[L3], %[vsh], vcc\n\t"
+    "v_writelane_b32 %[L3], s43, 0\n"
+    "HF_FAR0_%=:\n\t"
+    "v_mov_b32_dpp %[L0], %[L0] wave_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+    "v_writelane_b32 %[L0], %[t1], 0\n\t"
+    "s_branch HF_OUT_%=\n"
+    "HF_RUN_%=:\n\t"
+    "s_cmp_ge_u32 %[N], 21\n\t"
+    "s_cbranch_scc1 HF_DONE_%=\n\t"
+    "s_add_u32 %[t0], %[sym], 1\n\t"
+    "s_lshl_b32 %[t0], %[t0], %[N]\n\t"
+    "s_add_u32 %[es], %[es], %[t0]\n\t"
+    "s_add_u32 %[N], %[N], 1\n\t"
+    "s_lshl_b64 s[40:41], s[40:41], %[l]\n\t"
+    "s_sub_u32 %[live], %[live], %[l]\n\t"
+    "s_add_u32 %[k], %[k], 1\n\t"
+    "s_branch HF_LOOP_%=\n"
+    "HF_DONE_%=:\n\t"
+    "s_mov_b64 %[buf], s[40:41]"
+    : [buf] "+s"(buf), [live] "+s"(live), [dwl] "+s"(dwl), [k] "+s"(k), [n] "+s"(n), [es] "+s"(es), [N] "+s"(N), [L0] "+v"(L0),
+      [L1] "+v"(L1), [L2] "+v"(L2), [L3] "+v"(L3), [t0] "=&s"(t0), [t1] "=&s"(t1), [t2] "=&s"(t2), [e] "=&s"(e), [l] "=&s"(l), [sym] "=&s"(sym),
+      [va] "=&v"(va), [vb] "=&v"(vb), [vsh] "=&v"(vsh), [ve] "=&v"(ve)
+    : [cur] "v"(cur), [lane] "v"(lane), [lut] "s"(lutaddr), [tt8] "s"(tt8), [maxn] "s"(maxn)
+    : "s40", "s41", "s42", "s43", "s44", "s45", "vcc", "scc", "memory");
+}
+
 /* One claim per wave from an LDS ticket counter (all 64 lanes active): returns 0, 1, 2, ... in
  * claim order, wave-uniform.  Every lane adds one -- the compiler folds that into a single
  * ds_add_rtn of 64 by one lane -- because a claim written as `if (lane == 0) atomicAdd` inside a
