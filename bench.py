@@ -31,6 +31,7 @@ Extra objects in the JSON line:
                 encode 18 N_mtf+N_out.  peak 8000 GB/s (MI355X HBM3E).  roofline.isolated: the same
                 table from one extra untimed single-stream pass (no overlap between rounds).
   value_host    host buffer in -> .bz2 bytes in host memory (pinned, PCIe-inclusive), same input.
+  decode        the inverse path on the stream just written (untimed by the driver): decoded MB/s, round trip checked.
   cpu_baseline  reference lbzip2's block codec (oracle/_ref: "reference") or the restatement
                 (oracle/: "port") on the box's host cores through the pthreads driver of
                 oracle/cpu_mt.h, over a bounded sample of the same workload.
@@ -145,6 +146,7 @@ def main():
     ap.add_argument("--no-verify", action="store_true", help="skip the untimed md5 check against the reference fixture")
     ap.add_argument("--no-host", action="store_true", help="skip the host-to-host leg (value_host)")
     ap.add_argument("--no-isolated", action="store_true", help="skip the extra single-stream pass (profiling runs)")
+    ap.add_argument("--no-decode", action="store_true", help="skip the inverse-path leg (decode)")
     args = ap.parse_args()
 
     import torch
@@ -275,6 +277,28 @@ def main():
         value_host = {"value": round(n / best / 1e6, 1), "unit": "MB/s", "ms": round(best * 1e3, 2), "same_stream": bool(ok),
                       "what": "pinned host buffer in -> .bz2 bytes in pinned host memory: per-round H2D and D2H overlapped with the kernels of the other stream's round"}
 
+    decode = None
+    if rank == 0 and not args.no_decode and world == 1:
+        # the inverse path on the stream just written: every block decoded at once, compared with the input
+        back = torch.empty(n + 64, dtype=torch.uint8, device="cuda")
+        with lib.decoder(max(8, min(4096, 2 * nslabs + 8))) as dec:
+            best = None
+            for _ in range(3):
+                torch.cuda.synchronize()
+                td = time.perf_counter()
+                k = dec.decompress_device(dst.data_ptr(), out_len, back.data_ptr(), back.numel())
+                torch.cuda.synchronize()
+                dt = time.perf_counter() - td
+                best = dt if best is None or dt < best else best
+            ds = dec.stats()
+        decode = {"value": round(n / best / 1e6, 1), "unit": "MB/s", "ms": round(best * 1e3, 2),
+                  "round_trip": bool(k == n and torch.equal(back[:n], src)), "blocks": ds.nblocks,
+                  "ms": {"k_dscan": round(ds.ms_scan, 2), "k_dblock": round(ds.ms_blocks, 2), "k_demit": round(ds.ms_emit, 2)},
+                  "slowest_block_ms": {"codes": round(ds.ms_huff, 2), "sort": round(ds.ms_sort, 2), "walk": round(ds.ms_walk, 2)},
+                  "what": "decoded bytes per second, .bz2 stream and output both resident in HBM: magic scan, then one workgroup "
+                          "per block (prefix codes + inverse MTF, counting sort, list ranking walk, CRC), then inverse RLE1 into place"}
+        del back
+
     if rank == 0:
         nchunks = (nslabs + slabs - 1) // slabs
         nslots = ctx.nslots
@@ -346,6 +370,8 @@ def main():
         }
         if value_host:
             res["value_host"] = value_host
+        if decode:
+            res["decode"] = decode
         if not args.no_cpu:
             res["cpu_baseline"] = cpu_baseline(full, args.level)
         print(json.dumps(res), flush=True)

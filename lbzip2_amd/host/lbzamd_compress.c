@@ -256,7 +256,7 @@ static int stream_files(const char *in_path, const char *out_path, unsigned leve
 
 int main(int argc, char **argv)
 {
-  unsigned level = 9, nworkers = 0, timing = 0, repeat = 1, chunk_slabs = 256, npipes = 2;
+  unsigned level = 9, nworkers = 0, timing = 0, repeat = 1, chunk_slabs = 256, npipes = 2, decompress = 0;
   const char *in_path = NULL, *out_path = NULL;
   for (int i = 1; i < argc; i++) {
     if (!strcmp(argv[i], "-f") && i + 1 < argc) { in_path = argv[++i]; continue; }
@@ -264,10 +264,42 @@ int main(int argc, char **argv)
     if (!strcmp(argv[i], "-c") && i + 1 < argc) { chunk_slabs = (unsigned)atoi(argv[++i]); continue; }
     if (!strcmp(argv[i], "-p") && i + 1 < argc) { npipes = (unsigned)atoi(argv[++i]); continue; }
     if (!strcmp(argv[i], "-t")) { timing = 1; continue; }            /* phase times on stderr */
+    if (!strcmp(argv[i], "-d")) { decompress = 1; continue; }        /* the inverse path: .bz2 -> bytes */
     if (!strcmp(argv[i], "-r") && i + 1 < argc) { repeat = (unsigned)atoi(argv[++i]); continue; }   /* run the codec phase N times */
     if (argv[i][0] == '-' && argv[i][1] >= '1' && argv[i][1] <= '9' && !argv[i][2]) level = argv[i][1] - '0';
     else if (!strcmp(argv[i], "-w") && i + 1 < argc) nworkers = (unsigned)atoi(argv[++i]);
-    else { fprintf(stderr, "usage: %s [-1..-9] [-w N] [-t] [-r N] < in > out.bz2\n", argv[0]); return 2; }
+    else { fprintf(stderr, "usage: %s [-1..-9] [-w N] [-t] [-r N] < in > out.bz2 | -f IN -o OUT [-c slabs] [-p pipelines] | -d [-f IN] [-o OUT]\n", argv[0]); return 2; }
+  }
+  if (decompress) {
+    /* whole file in, every block decoded at once (lbzamd_decompress_host), whole file out */
+    FILE *fi = in_path && strcmp(in_path, "-") ? fopen(in_path, "rb") : stdin;
+    FILE *fo = out_path && strcmp(out_path, "-") ? fopen(out_path, "wb") : stdout;
+    if (!fi || !fo) { perror("lbzamd_compress -d"); return 1; }
+    size_t zlen;
+    unsigned char *z = read_all(fi, &zlen);
+    lbzamd_dctx *d;
+    const double t0 = now_s();
+    unsigned maxb = (unsigned)(zlen / 20000 + 8);
+    if (lbzamd_dcreate(&d, -1, maxb > 2400 ? 2400 : maxb)) { fprintf(stderr, "lbzamd: %s\n", lbzamd_last_error()); return 1; }
+    size_t need = 0;
+    int rc = lbzamd_decompress_host(d, z, zlen, NULL, 0, &need);         /* size pass: everything but the output copy */
+    if (rc != 0 && rc != -2) { fprintf(stderr, "lbzamd: %s\n", lbzamd_last_error()); return 1; }
+    unsigned char *out = malloc(need ? need : 1);
+    size_t n = 0;
+    const double t1 = now_s();
+    if (lbzamd_decompress_host(d, z, zlen, out, need, &n)) { fprintf(stderr, "lbzamd: %s\n", lbzamd_last_error()); return 1; }
+    const double t2 = now_s();
+    if (timing) {
+      lbzamd_dstats ds;
+      lbzamd_dget_stats(d, &ds);
+      fprintf(stderr, "decode: %zu B -> %zu B, %u blocks in %u stream(s); context + size pass %.3f s, decode %.3f s = %.0f MB/s (device: scan %.1f blocks %.1f emit %.1f ms)\n",
+              zlen, n, ds.nblocks, ds.nstreams, t1 - t0, t2 - t1, (double)n / (t2 - t1) / 1e6, ds.ms_scan, ds.ms_blocks, ds.ms_emit);
+    }
+    fwrite(out, 1, n, fo);
+    if (fo != stdout) fclose(fo);
+    lbzamd_ddestroy(d);
+    free(out); free(z);
+    return 0;
   }
   if (in_path || out_path) {
     if (chunk_slabs < 1) chunk_slabs = 1;

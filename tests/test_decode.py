@@ -55,6 +55,32 @@ def test_damaged_streams_are_refused(emu):
             emu.decompress(bytes(bad))
 
 
+def test_cli_decompress(emu):
+    """lbzip2_amd/host/lbzamd_compress.c -d: file in, every block at once, file out"""
+    d = bytes(gen("wiki", 200000, 5))
+    z = bz2.compress(d, 1) + L.orc_compress(b"x" * 1000, 9)
+    exe = os.path.join(EMU_DIR, "_build", "lbzamd_compress_emu")
+    r = subprocess.run([exe, "-d"], input=z, capture_output=True, timeout=600)
+    assert r.returncode == 0 and r.stdout == d + b"x" * 1000, r.stderr[-500:]
+    r = subprocess.run([exe, "-d"], input=z[:-3], capture_output=True, timeout=600)
+    assert r.returncode != 0 and b"lbzamd" in r.stderr
+
+
+@pytest.mark.gpu
+def test_cli_decompress_on_the_gpu(tmp_path):
+    """the host driver's two directions back to back: file -> .bz2 -> file"""
+    import hashlib
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "lbzip2_amd", "host", "lbzamd_compress")
+    subprocess.check_call(["make", "-s", "-C", os.path.join(root, "lbzip2_amd", "csrc")])
+    data = L.gen_kind("wiki", 300_000_000, 6)
+    src, z, back = tmp_path / "in.bin", tmp_path / "in.bz2", tmp_path / "back.bin"
+    src.write_bytes(data)
+    subprocess.check_call([exe, "-9", "-f", str(src), "-o", str(z)], timeout=600)
+    subprocess.check_call([exe, "-d", "-f", str(z), "-o", str(back)], timeout=600)
+    assert hashlib.md5(back.read_bytes()).digest() == hashlib.md5(data).digest()
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("kind,n,seed,level", [("wiki", 100_000_000, 1, 9), ("rand", 30_000_000, 4, 9), ("mixed", 120_000_000, 3, 1),
                                                ("tar", 175_000_000, 5, 9), ("text", 50_000_000, 2, 5)])
