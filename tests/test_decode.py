@@ -43,6 +43,16 @@ def test_reference_and_python_streams(emu):
     assert emu.decompress(bz2.compress(d2, 9) + b"\0" * 7) == d2            # trailing garbage is ignored
 
 
+def test_more_blocks_than_the_context_holds(emu):
+    """max_blocks = 2: seven blocks are taken in four passes, offsets carry over"""
+    d = bytes(gen("wiki", 650000, 8))
+    z = L.orc_compress(d, 1)
+    with emu.decoder(2) as dec:
+        assert dec.decompress(z) == d
+        st = dec.stats()
+    assert st.nblocks == 7 and st.nstreams == 1 and st.n_out == len(d)
+
+
 def test_damaged_streams_are_refused(emu):
     z = bytearray(L.orc_compress(bytes(gen("text", 120000, 6)), 1))
     for mutate in (lambda b: b.__setitem__(len(b) // 2, b[len(b) // 2] ^ 0x10),       # payload bit: block CRC or code error
