@@ -78,6 +78,29 @@ template <class T> __device__ __forceinline__ T wave_max(T v)
   return v;
 }
 
+#ifndef LBZ_EMULATED
+/* 32-bit unsigned scans and reductions on the DPP network instead of ds_bpermute: the kernels that scan the
+ * most are the ones bound by LDS, and a __shfl_* is an LDS-crossbar operation.  row_shr 1/2/4/8 inside the rows
+ * of 16, then row_bcast:15 into rows 1 and 3, row_bcast:31 into rows 2 and 3; lanes without a source take the
+ * identity.  Every one of these is a single v_<op>_dpp.                                                      */
+#define LBZ_DPP(ident, v, ctrl, rows) ((u32)__builtin_amdgcn_update_dpp((int)(ident), (int)(v), (ctrl), (rows), 0xf, false))
+#define LBZ_DPP_SCAN(OP, ident)                                          \
+  v = OP(v, LBZ_DPP(ident, v, 0x111, 0xf));                              \
+  v = OP(v, LBZ_DPP(ident, v, 0x112, 0xf));                              \
+  v = OP(v, LBZ_DPP(ident, v, 0x114, 0xf));                              \
+  v = OP(v, LBZ_DPP(ident, v, 0x118, 0xf));                              \
+  v = OP(v, LBZ_DPP(ident, v, 0x142, 0xa));                              \
+  v = OP(v, LBZ_DPP(ident, v, 0x143, 0xc));
+__device__ __forceinline__ u32 dpp_add(u32 a, u32 b) { return a + b; }
+__device__ __forceinline__ u32 dpp_max(u32 a, u32 b) { return a > b ? a : b; }
+__device__ __forceinline__ u32 dpp_min(u32 a, u32 b) { return a < b ? a : b; }
+template <> __device__ __forceinline__ u32 wave_incl_add<u32>(u32 v) { LBZ_DPP_SCAN(dpp_add, 0u) return v; }
+template <> __device__ __forceinline__ u32 wave_incl_max<u32>(u32 v) { LBZ_DPP_SCAN(dpp_max, 0u) return v; }
+template <> __device__ __forceinline__ u32 wave_sum<u32>(u32 v) { LBZ_DPP_SCAN(dpp_add, 0u) return (u32)__builtin_amdgcn_readlane((int)v, 63); }
+template <> __device__ __forceinline__ u32 wave_max<u32>(u32 v) { LBZ_DPP_SCAN(dpp_max, 0u) return (u32)__builtin_amdgcn_readlane((int)v, 63); }
+template <> __device__ __forceinline__ u32 wave_min<u32>(u32 v) { LBZ_DPP_SCAN(dpp_min, 0xFFFFFFFFu) return (u32)__builtin_amdgcn_readlane((int)v, 63); }
+#endif
+
 /* LDS scratch for the workgroup scans/reductions: one object, reused everywhere. */
 struct wg_scratch {
   u32 a[LBZ_NW + 1];
