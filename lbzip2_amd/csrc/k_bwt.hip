@@ -638,8 +638,7 @@ __device__ u32 wave_radix_range(batch_lds *B, u32 cs, u32 ce)
   const u32 lane = lane_id(), w = wave_id();
   u64 vo = 0, va = ~0ull;
   for (u32 j = cs + lane; j < ce; j += 64u) { const u64 k = B->kA[j]; vo |= k; va &= k; }
-#pragma unroll
-  for (u32 d = 32; d >= 1; d >>= 1) { vo |= __shfl_xor(vo, (int)d); va &= __shfl_xor(va, (int)d); }
+  wave_or_and64(&vo, &va);
   const u64 varying = vo ^ va;
   if (TOP_ONLY && varying == 0ull) return 64u;
   const u32 ptop = TOP_ONLY ? (63u - (u32)__clzll((long long)varying)) / 8u : 0u;   /* most significant varying byte */
@@ -810,7 +809,7 @@ __device__ u32 wave_runs(batch_lds *B, u32 cs, u32 ce, u32 sh = 0u)
       if (hn) B->gend[h] = (u16)(j + 1u);
     }
     ntied += (u32)__popcll(__ballot(ok && !(hd && hn)));
-    carry = (u32)__shfl((int)h, 63);
+    carry = (u32)__builtin_amdgcn_readlane((int)h, 63);
   }
   wave_sync();
   return ntied;

@@ -143,7 +143,7 @@ __device__ void collect_pass(const u8 *x, u32 base, u32 end, u32 cap, u8 *out, c
     if (vec_ok && p0 + COL_TILE + COL_IPT <= end)        /* the next tile's bytes, requested a tile ahead */
       nxt = *reinterpret_cast<const uint4 *>(x + p0 + COL_TILE);
     /* the byte before this thread's first: the neighbour lane's last, or one load per wave */
-    u8 prevb = (u8)__shfl_up((int)b[COL_IPT - 1u], 1u);
+    u8 prevb = (u8)lane_from_below((u32)b[COL_IPT - 1u]);
     if (lane_id() == 0u) prevb = (p0 > base && p0 <= end) ? x[p0 - 1] : (u8)0;
 
     /* run heads and the start of the run each position belongs to */

@@ -73,7 +73,7 @@ __device__ __forceinline__ void mtf_ranks(const u8 *bwt, u8 *rk, u32 lo, u32 hi,
       const u32 b0 = c0 + 64u * t, p = b0 + lane;
       const bool ok = p < hi;
       const int c = ok ? (int)S->cmap[inb[64u * t + lane]] : 0;
-      int cprev = __shfl_up(c, 1u);
+      int cprev = wave_shr1(c);
       if (lane == 0u) cprev = carry;
       carry = __builtin_amdgcn_readlane(c, 63);
       u64 heads = __ballot(ok && c != cprev);
@@ -171,8 +171,8 @@ k_mtf(const u8 *Bbase, u8 *Rbase, u16 *Vbase, u32 *freq_out, lbz_block_meta *met
 #pragma unroll
     for (u32 k = 0; k < 4u; k++) {
       const u32 p = b0 + 64u * k + lane;
-      const u32 before = (u32)__shfl_up((int)by[k], 1u);
-      const u32 after = (u32)__shfl_down((int)by[k], 1u);
+      const u32 before = lane_from_below(by[k]);
+      const u32 after = lane_from_above(by[k]);
       if (p < hi) {
         /* only the ends of runs touch LDS: far fewer atomics, and fewer of them on one address */
         const u32 code = S.cmap[by[k]];

@@ -155,6 +155,12 @@ __device__ __forceinline__ void huff_fast(unsigned long long &buf, unsigned &liv
     : "s40", "s41", "s42", "s43", "s44", "s45", "vcc", "scc", "memory");
 }
 
+/* wave_shl:1 -- lane l of the result is lane l + 1 of v (lane 63: v's own) */
+__device__ __forceinline__ int wave_shl1(int v)
+{
+  return __builtin_amdgcn_update_dpp(v, v, 0x130, 0xf, 0xf, false);
+}
+
 /* One claim per wave from an LDS ticket counter (all 64 lanes active): returns 0, 1, 2, ... in
  * claim order, wave-uniform.  Every lane adds one -- the compiler folds that into a single
  * ds_add_rtn of 64 by one lane -- because a claim written as `if (lane == 0) atomicAdd` inside a

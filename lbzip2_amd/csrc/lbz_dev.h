@@ -99,7 +99,23 @@ template <> __device__ __forceinline__ u32 wave_incl_max<u32>(u32 v) { LBZ_DPP_S
 template <> __device__ __forceinline__ u32 wave_sum<u32>(u32 v) { LBZ_DPP_SCAN(dpp_add, 0u) return (u32)__builtin_amdgcn_readlane((int)v, 63); }
 template <> __device__ __forceinline__ u32 wave_max<u32>(u32 v) { LBZ_DPP_SCAN(dpp_max, 0u) return (u32)__builtin_amdgcn_readlane((int)v, 63); }
 template <> __device__ __forceinline__ u32 wave_min<u32>(u32 v) { LBZ_DPP_SCAN(dpp_min, 0xFFFFFFFFu) return (u32)__builtin_amdgcn_readlane((int)v, 63); }
+__device__ __forceinline__ u32 dpp_or(u32 a, u32 b) { return a | b; }
+__device__ __forceinline__ u32 dpp_and(u32 a, u32 b) { return a & b; }
+__device__ __forceinline__ u32 wave_or(u32 v) { LBZ_DPP_SCAN(dpp_or, 0u) return (u32)__builtin_amdgcn_readlane((int)v, 63); }
+__device__ __forceinline__ u32 wave_and(u32 v) { LBZ_DPP_SCAN(dpp_and, 0xFFFFFFFFu) return (u32)__builtin_amdgcn_readlane((int)v, 63); }
+#else
+__device__ __forceinline__ u32 wave_or(u32 v) { for (u32 d = 32; d >= 1; d >>= 1) v |= __shfl_xor(v, (int)d); return v; }
+__device__ __forceinline__ u32 wave_and(u32 v) { for (u32 d = 32; d >= 1; d >>= 1) v &= __shfl_xor(v, (int)d); return v; }
 #endif
+/* OR and AND of a 64-bit value over the wave, in every lane */
+__device__ __forceinline__ void wave_or_and64(u64 *vo, u64 *va)
+{
+  *vo = (u64)wave_or((u32)*vo) | (u64)wave_or((u32)(*vo >> 32)) << 32;
+  *va = (u64)wave_and((u32)*va) | (u64)wave_and((u32)(*va >> 32)) << 32;
+}
+/* lane l takes lane l - 1's / l + 1's value (the end lane keeps its own): one DPP move, no LDS */
+__device__ __forceinline__ u32 lane_from_below(u32 v) { return (u32)wave_shr1((int)v); }
+__device__ __forceinline__ u32 lane_from_above(u32 v) { return (u32)wave_shl1((int)v); }
 
 /* LDS scratch for the workgroup scans/reductions: one object, reused everywhere. */
 struct wg_scratch {
@@ -142,13 +158,13 @@ __device__ __forceinline__ void wg_excl_max_add(u32 vmax, u32 vadd, u32 *emax, u
     u32 pa = l < LBZ_NW ? sc->b[l] : 0u;
     u32 qm = wave_incl_max(pm);
     u32 qa = wave_incl_add(pa);
-    u32 qm_ex = __shfl_up(qm, 1u);
+    u32 qm_ex = lane_from_below(qm);
     if (l == 0) qm_ex = 0u;
     if (l < LBZ_NW) { sc->a[l] = qm_ex; sc->b[l] = qa - pa; }
     if (l == LBZ_NW - 1) { sc->a[LBZ_NW] = qm; sc->b[LBZ_NW] = qa; }
   }
   __syncthreads();
-  u32 pm_ex = __shfl_up(im, 1u);
+  u32 pm_ex = lane_from_below(im);
   if (l == 0) pm_ex = 0u;
   u32 bm = sc->a[w];
   *emax = bm > pm_ex ? bm : pm_ex;
@@ -188,11 +204,7 @@ __device__ __forceinline__ u32 wg_max(u32 v, wg_scratch *sc)
 __device__ __forceinline__ void wg_or_and64(u64 v_or, u64 v_and, u64 *r_or, u64 *r_and, wg_scratch *sc)
 {
   const u32 l = lane_id(), w = wave_id();
-#pragma unroll
-  for (u32 d = 32; d >= 1; d >>= 1) {
-    v_or |= __shfl_xor(v_or, (int)d);
-    v_and &= __shfl_xor(v_and, (int)d);
-  }
+  wave_or_and64(&v_or, &v_and);
   if (l == 0) { sc->a[w] = (u32)v_or; sc->b[w] = (u32)(v_or >> 32); }
   __syncthreads();
   u64 o = 0;

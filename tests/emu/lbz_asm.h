@@ -4,6 +4,7 @@
 #define LBZ_ASM_H
 static inline int lane_write(int old, int val, int lane) { return (int)(threadIdx.x & 63) == lane ? val : old; }
 static inline int wave_shr1(int v) { const int o = __shfl_up(v, 1u); return (threadIdx.x & 63) == 0 ? v : o; }
+static inline int wave_shl1(int v) { const int o = __shfl_down(v, 1u); return (threadIdx.x & 63) == 63 ? v : o; }
 /* C statement of lbz_asm.h's huff_fast (same contract; lut is the table itself here, not its LDS address) */
 static inline void huff_fast(unsigned long long &buf, unsigned &live, unsigned &dwl, unsigned cur, unsigned &k,
                              unsigned &n, unsigned &es, unsigned &N, int &L0, int &L1, int &L2, int &L3, const unsigned short *lut,
