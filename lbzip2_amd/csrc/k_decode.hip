@@ -18,6 +18,7 @@
  *   k_demit   inverse RLE1 of W[] into the output at the block's offset
  */
 #include "lbz_kernels.h"
+#include "lbz_rand.h"
 
 #define DEC_MAX_SEL 18002u
 #define DEC_LUT_BITS 10u
@@ -302,7 +303,6 @@ __device__ __forceinline__ void dhuff_block(const u8 *in, u64 nbytes, lbz_dblock
     }
     if (!err && n > maxn) err = 8;
   }
-  if (!err && randomised) err = 10;                               /* obsolete format variant, never written by lbzip2 */
   if (!err && (n == 0u || orig_ptr >= n)) err = 9;
   if (lane == 0u) {
     D->stored_crc = stored_crc; D->randomised = randomised; D->orig_ptr = orig_ptr;
@@ -509,6 +509,23 @@ __device__ __forceinline__ void dwalk_block(lbz_dblock *D, const u32 *tt, u8 *W,
   const u32 period = S.period;
   if (period < n) {
     for (u32 j = period + tid; j < n; j += DW_T) W[j] = W[j % period];
+    __syncthreads();
+  }
+
+  if (D->randomised) {
+    /* the format's obsolete "randomised" variant (bzip2 0.9.0 wrote it for blocks it found hard to sort; no current
+       compressor does, the reference's decoder still takes it, tests/README "rand"): byte k is flipped iff k + 2 is a
+       partial sum of the step table taken cyclically */
+    for (u32 i = tid; i < 512u; i += DW_T) S.nxt[i] = LBZ_RNUMS[i];
+    __syncthreads();
+    if (tid == 0u) { u32 acc = 0; for (u32 i = 0; i < 512u; i++) { acc += S.nxt[i]; S.nxt[i] = acc; } }
+    __syncthreads();
+    const u32 cyc = S.nxt[511];
+    for (u32 m = tid;; m += DW_T) {
+      const u32 pos = (m >> 9) * cyc + S.nxt[m & 511u] - 2u;
+      if (pos >= n) break;
+      W[pos] ^= 1u;
+    }
     __syncthreads();
   }
 

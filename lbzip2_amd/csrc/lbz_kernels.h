@@ -25,7 +25,7 @@ struct lbz_dblock {
   u32 randomised, orig_ptr;
   u32 nblock;         /* length before inverse RLE1 */
   u32 out_len;        /* decoded bytes */
-  u32 err;            /* 0 ok; 1..10 malformed block; 11 CRC mismatch */
+  u32 err;            /* 0 ok; 1..9 malformed block; 11 CRC mismatch */
   u32 tk[3];          /* 100 MHz ticks of the block's three stages (codes, sort, walk) */
 };
 __global__ void k_dscan(const u8 *in, u64 nbytes, u64 *marks, u32 *nmarks, u32 cap);

@@ -43,6 +43,45 @@ def test_reference_and_python_streams(emu):
     assert emu.decompress(bz2.compress(d2, 9) + b"\0" * 7) == d2            # trailing garbage is ignored
 
 
+def expand_cases():
+    import json
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "expand_cases.json")
+    return json.load(open(path))["cases"]
+
+
+def check_expand_case(lib, c):
+    """one case of the reference's decompressor suite (its tests/README: 32767 selectors, 20-bit codes, a zip bomb,
+    randomised and cyclic blocks, the largest origin pointer, concatenated streams, gaps and trailing garbage, block
+    overruns, the CVE-2010-0405 stream, block and stream CRC errors, truncated and empty files): accepted or refused
+    as the compiled reference does, same bytes out"""
+    import hashlib
+    z = bytes.fromhex(c["bz2_hex"])
+    if c["ok"]:
+        out = lib.decompress(z)
+        assert len(out) == c["out_len"] and hashlib.md5(out).hexdigest() == c["out_md5"], c["name"]
+    else:
+        with pytest.raises(LbzError):
+            lib.decompress(z)
+
+
+@pytest.mark.parametrize("c", [c for c in expand_cases() if c["out_len"] < 10**6], ids=lambda c: c["name"])
+def test_reference_expand_suite(emu, c):
+    check_expand_case(emu, c)
+
+
+def test_randomisation_table_is_libbz2s():
+    import ctypes
+    import ctypes.util
+    import re
+    name = ctypes.util.find_library("bz2")
+    if not name:
+        pytest.skip("no libbz2 here")
+    tab = list((ctypes.c_int * 512).in_dll(ctypes.CDLL(name), "BZ2_rNums"))
+    src = open(os.path.join(os.path.dirname(EMU_DIR), "..", "lbzip2_amd", "csrc", "lbz_rand.h")).read()
+    mine = [int(x) for x in re.findall(r"\d+", src[src.index("LBZ_RNUMS[512] = {") + 18:])][:512]
+    assert mine == tab
+
+
 def test_more_blocks_than_the_context_holds(emu):
     """max_blocks = 2: seven blocks are taken in four passes, offsets carry over"""
     d = bytes(gen("wiki", 650000, 8))
@@ -111,6 +150,13 @@ def test_round_trip_full_size(kind, n, seed, level):
         st = d.stats()
     assert k == n and bool(torch.equal(out[:n], src))
     assert st.nblocks >= (n + M - 1) // M and st.nstreams == 1
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("c", expand_cases(), ids=lambda c: c["name"])
+def test_reference_expand_suite_on_the_gpu(c):
+    import lbzip2_amd
+    check_expand_case(lbzip2_amd.library(), c)
 
 
 @pytest.mark.gpu
