@@ -69,6 +69,23 @@ def test_reference_expand_suite(emu, c):
     check_expand_case(emu, c)
 
 
+def suite_streams(step):
+    import tarfile
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "suite_inputs.tar")
+    with tarfile.open(path) as t:
+        members = [m for m in t.getmembers() if m.isfile()]
+        for m in members[::step]:
+            yield m.name, t.extractfile(m).read()
+
+
+def test_reference_compress_suite_streams_decode(emu):
+    """the .bz2 files of the reference's compressor suites (fuzz-divbwt, fuzz-collect, manual-compress) are streams
+    too: every 12th of the 1093 here (all of them on the GPU), decoded and compared with Python's bz2"""
+    with emu.decoder(64) as d:
+        for name, z in suite_streams(12):
+            assert d.decompress(z) == bz2.decompress(z), name
+
+
 def test_randomisation_table_is_libbz2s():
     import ctypes
     import ctypes.util
@@ -157,6 +174,14 @@ def test_round_trip_full_size(kind, n, seed, level):
 def test_reference_expand_suite_on_the_gpu(c):
     import lbzip2_amd
     check_expand_case(lbzip2_amd.library(), c)
+
+
+@pytest.mark.gpu
+def test_reference_compress_suite_streams_decode_on_the_gpu():
+    import lbzip2_amd
+    with lbzip2_amd.library().decoder(64) as d:
+        for name, z in suite_streams(1):
+            assert d.decompress(z) == bz2.decompress(z), name
 
 
 @pytest.mark.gpu
