@@ -105,6 +105,12 @@ const char *lbzamd_last_error(void);
 
 /* d_in/d_out are device pointers.  Writes a complete .bz2 stream; *out_len = its size.
  * Work is enqueued on the context's stream and waited for.  0 on success.              */
+/* The reference's -u / --sequential (main.c; compress.c:129-198 do_collect_seq): with on != 0 the context's
+ * following calls cut blocks where they are FULL (a continuous RLE1 over the input, bzip2's own blocking) instead
+ * of at every bs100k * 100000 input bytes; the stream is byte-identical to `lbzip2 -u`.  A block's start is known
+ * only when its predecessor has been cut, so the blocks' first pass runs as a chain on the device; the body-only
+ * calls (a slab range of a bigger stream) are refused in this mode.  max_slabs then counts blocks per chunk. */
+int  lbzamd_set_sequential(lbzamd_ctx *ctx, int on);
 int  lbzamd_compress_device(lbzamd_ctx *ctx, const void *d_in, size_t len,
                             void *d_out, size_t out_cap, size_t *out_len);
 /* Multi-GPU shards: the blocks of a slab-aligned range only (no "BZh9", no trailer), plus the

@@ -19,7 +19,7 @@ EXPORTS = [
     "lbzamd_encoder_alloc_size", "lbzamd_encoder_init", "lbzamd_collect", "lbzamd_encode",
     "lbzamd_transmit", "lbzamd_encoder_abandon",
     "lbzamd_create", "lbzamd_destroy", "lbzamd_last_error", "lbzamd_compress_device",
-    "lbzamd_compress_host", "lbzamd_bound", "lbzamd_get_stats", "lbzamd_stream", "lbzamd_slots",
+    "lbzamd_compress_host", "lbzamd_bound", "lbzamd_get_stats", "lbzamd_stream", "lbzamd_slots", "lbzamd_set_sequential",
     "lbzamd_block_slots", "lbzamd_block_info_get", "lbzamd_read_stage", "lbzamd_run_stages",
     "lbzamd_compress_device_body", "lbzamd_compress_host_body", "lbzamd_fold_parts",
     "lbzamd_pinned_alloc", "lbzamd_pinned_free",
@@ -129,6 +129,8 @@ class Library:
         lib.lbzamd_get_stats.restype = C.c_int
         lib.lbzamd_stream.argtypes = [vp]
         lib.lbzamd_stream.restype = vp
+        lib.lbzamd_set_sequential.argtypes = [vp, C.c_int]
+        lib.lbzamd_set_sequential.restype = C.c_int
         lib.lbzamd_slots.argtypes = [vp]
         lib.lbzamd_slots.restype = C.c_uint32
         lib.lbzamd_block_slots.argtypes = [vp]
@@ -161,12 +163,14 @@ class Library:
             return d.decompress(data)
 
     # ---- whole-stream helpers -------------------------------------------------
-    def compress(self, data, level=9, max_slabs=None):
-        """bytes -> .bz2 bytes through the batch interface."""
+    def compress(self, data, level=9, max_slabs=None, sequential=False):
+        """bytes -> .bz2 bytes through the batch interface (sequential: the reference's -u blocking)."""
         M = level * 100000
         if max_slabs is None:
             max_slabs = max(1, min(1200, (len(data) + M - 1) // M))
         with self.context(level, max_slabs) as ctx:
+            if sequential:
+                ctx.set_sequential(True)
             return ctx.compress(data)
 
     def compress_workunits(self, data, level=9):
@@ -265,6 +269,11 @@ class Context:
         if self.L.lib.lbzamd_compress_host(self.h, C.c_void_p(h_in), length, C.c_void_p(h_out), out_cap, C.byref(n)):
             raise LbzError("lbzamd_compress_host: " + self.L.error())
         return n.value
+
+    def set_sequential(self, on=True):
+        """the reference's -u / --sequential: blocks are cut where they are full (compress.c:129-198)"""
+        if self.L.lib.lbzamd_set_sequential(self.h, 1 if on else 0):
+            raise LbzError("lbzamd_set_sequential: " + self.L.error())
 
     def compress_device(self, d_in, length, d_out, out_cap):
         """d_in/d_out: integer device addresses (e.g. torch tensor .data_ptr())."""

@@ -286,3 +286,75 @@ k_collect(const u8 *in, u64 in_len, lbz_layout L, u8 *Tbase, lbz_block_meta *met
     __syncthreads();
   }
 }
+
+
+/* ---- -u / --sequential (compress.c:129-198, do_collect_seq): a block takes input until it is full, whatever
+ * the slab boundaries, so where block b starts is known only when block b - 1 has been cut.  One launch, one
+ * workgroup per block slot; workgroups take their block number from a ticket counter (so every predecessor is
+ * resident or done) and wait for the predecessor to publish its cut: the tokenising pass of the blocks runs as
+ * a chain, the CRC of a block -- the longer part -- runs beside its successors' passes.
+ * starts[b] = (input position of block b) + 1, 0 = not known yet; starts[0] comes from the host.            */
+__global__ void __launch_bounds__(LBZ_WG, 4)
+k_collect_seq(const u8 *in, u64 in_len, lbz_layout L, u8 *Tbase, lbz_block_meta *meta, u32 nblk,
+              unsigned long long *starts, u32 *ticket, lbz_seq_out *so)
+{
+  __shared__ collect_lds S;
+  __shared__ unsigned long long s_start;
+  const u32 tid = threadIdx.x;
+  if (tid == 0) S.bc[3] = atomicAdd(ticket, 1u);
+  if (tid < 256) {
+    u32 c = tid << 24;
+    for (int k = 0; k < 8; k++) c = (c & 0x80000000u) ? (c << 1) ^ CRC_POLY : (c << 1);
+    S.crc_tab[tid] = c;
+    S.inuse[tid] = 0;
+  }
+  __syncthreads();
+  const u32 b = S.bc[3];
+  if (b >= nblk) return;
+  if (tid == 0) {
+    unsigned long long v = 0;
+    for (u32 spins = 0; spins < (1u << 26); spins++) {          /* bounded: a lost predecessor must not hang the device */
+      v = __atomic_load_n(&starts[b], __ATOMIC_ACQUIRE);
+      if (v) break;
+      __builtin_amdgcn_s_sleep(4);
+    }
+    s_start = v;
+  }
+  __syncthreads();
+  lbz_block_meta *m = &meta[2u * b], *m2 = &meta[2u * b + 1u];
+  if (tid == 0) { m2->n = 0; m2->consumed = 0; m2->out_len = 0; m2->err = 0; m2->nmtf = 0; }
+  if (s_start == 0ull) {                                         /* the chain broke */
+    if (tid == 0) { so->err = 1u; m->n = 0; m->consumed = 0; m->out_len = 0; m->err = 1u; m->nmtf = 0; __atomic_store_n(&starts[b + 1u], 0ull, __ATOMIC_RELEASE); }
+    return;
+  }
+  const u64 p = s_start - 1ull;
+  if (p >= in_len) {                                             /* input used up by the blocks before */
+    if (tid == 0) {
+      m->n = 0; m->consumed = 0; m->out_len = 0; m->err = 0; m->nmtf = 0;
+      __atomic_store_n(&starts[b + 1u], p + 1ull, __ATOMIC_RELEASE);
+      if (b + 1u == nblk) so->next = p;
+    }
+    return;
+  }
+  /* an aligned view of the input: x16 + base = in + p.  A block takes at most M / 5 runs of 259 bytes. */
+  const u32 mis = (u32)(((uintptr_t)in + p) & 15u);
+  const u8 *x = in + p - mis;
+  const u64 left = in_len - p;
+  const u64 maxraw = (u64)L.M * 52u + 1024u;
+  const u32 end = mis + (u32)(left < maxraw ? left : maxraw);
+  collect_pass(x, mis, end, L.M, Tbase + lbz_elem_off(L, 2u * b), &S);
+  const u32 nblock = S.bc[0], stop = S.bc[1];
+  if (tid == 0) {
+    const u64 nx = p + (u64)(stop - mis);
+    __atomic_store_n(&starts[b + 1u], nx + 1ull, __ATOMIC_RELEASE);
+    if (b + 1u == nblk || nx >= in_len) so->next = nx;
+    atomicAdd(&so->nblocks, 1u);
+  }
+  __syncthreads();
+  const u32 crc = wg_crc32(x, mis, stop, end, &S);
+  if (tid < 256) m->inuse[tid] = (u8)S.inuse[tid];
+  if (tid == 0) {
+    m->n = nblock; m->crc = crc; m->consumed = stop - mis;
+    m->err = 0; m->out_len = 0; m->nmtf = 0; m->periodic = 0; m->bwt_idx = 0;
+  }
+}

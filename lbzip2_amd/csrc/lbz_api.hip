@@ -60,6 +60,10 @@ struct lbzamd_ctx {
   lbz_stream_state *st = nullptr;
   u8 *d_in = nullptr, *d_out = nullptr;      /* staging for the host-buffer path */
   const u8 *h2d_host = nullptr;              /* host-buffer call in progress: rounds copy their own slabs in */
+  bool sequential = false;                   /* -u: blocks span slab boundaries (k_collect_seq) */
+  unsigned long long *seq_starts = nullptr;  /* max_slabs + 1 chain entries, ticket, lbz_seq_out */
+  u32 *seq_ticket = nullptr;
+  lbz_seq_out *seq_out = nullptr;
   size_t d_in_cap = 0, d_out_cap = 0;
   /* host */
   std::vector<lbz_block_meta> h_meta;
@@ -74,6 +78,7 @@ static int ctx_free(lbzamd_ctx *c)
   (void)hipFree(c->T); (void)hipFree(c->B); (void)hipFree(c->R); (void)hipFree(c->O); (void)hipFree(c->ws); (void)hipFree(c->V);
   (void)hipFree(c->freq); (void)hipFree(c->offs); (void)hipFree(c->meta); (void)hipFree(c->st);
   (void)hipFree(c->d_in); (void)hipFree(c->d_out);
+  (void)hipFree(c->seq_starts); (void)hipFree(c->seq_ticket); (void)hipFree(c->seq_out);
   for (auto &e : c->ev) if (e) (void)hipEventDestroy(e);
   for (auto &e : c->bev) if (e) (void)hipEventDestroy(e);
   for (auto &e : c->jev) if (e) (void)hipEventDestroy(e);
@@ -220,7 +225,7 @@ static int timed_end(lbzamd_ctx *c, size_t *nbev, hipStream_t s)
   return 0;
 }
 
-static int run_chunk(lbzamd_ctx *c, const u8 *d_in, size_t len, uint32_t nsl, int upto)
+static int run_chunk(lbzamd_ctx *c, const u8 *d_in, size_t len, uint32_t nsl, int upto, bool collected = false)
 {
   hipStream_t s = c->stream;
   HIPCHK(hipEventRecord(c->ev[0], s));
@@ -245,16 +250,18 @@ static int run_chunk(lbzamd_ctx *c, const u8 *d_in, size_t len, uint32_t nsl, in
       hipStream_t q = lane ? c->side[lane - 1u] : s;
       u8 *ws = c->ws + (size_t)lane * c->nslots * (c->slot_bytes + c->spill_bytes);
       u8 *wsp = ws + (size_t)c->nslots * c->slot_bytes;
-      if (c->h2d_host) {
+      if (c->h2d_host && !collected) {
         /* host-buffer path: the round's slabs come in on the round's stream, so the copy of one
            round overlaps the kernels of the other stream's round */
         const size_t o = (size_t)first * c->L.M;
         const size_t nb = (size_t)count * c->L.M < len - o ? (size_t)count * c->L.M : len - o;
         HIPCHK(hipMemcpyAsync(const_cast<u8 *>(d_in) + o, c->h2d_host + (d_in - c->d_in) + o, nb, hipMemcpyHostToDevice, q));
       }
-      if (timed_begin(c, &nbev, 5, q)) return -1;
-      hipLaunchKernelGGL(k_collect, dim3(count), dim3(LBZ_COLLECT_WG), 0, q, d_in, (u64)len, c->L, c->T, c->meta, first, nullptr, nullptr);
-      if (timed_end(c, &nbev, q)) return -1;
+      if (!collected) {
+        if (timed_begin(c, &nbev, 5, q)) return -1;
+        hipLaunchKernelGGL(k_collect, dim3(count), dim3(LBZ_COLLECT_WG), 0, q, d_in, (u64)len, c->L, c->T, c->meta, first, nullptr, nullptr);
+        if (timed_end(c, &nbev, q)) return -1;
+      }
       if (timed_begin(c, &nbev, 0, q)) return -1;
       if (LBZ_BWT_WG >= 1024 && count > c->ncus)      /* 512-thread workgroups share a CU two by two at 128 VGPRs already */
         hipLaunchKernelGGL(k_bwt_part2, dim3(grid), dim3(LBZ_BWT_WG), 0, q, (const u8 *)c->T, c->meta, c->L,
@@ -317,6 +324,16 @@ static int add_times(lbzamd_ctx *c, float *acc)
 static int compress_device(lbzamd_ctx *c, const void *d_in_v, size_t len, void *d_out_v, size_t out_cap,
                            size_t *out_len, bool body, lbzamd_part *part);
 
+/* -u / --sequential of the reference (main.c, compress.c:129-198): blocks take input until they are full instead
+ * of being cut at every bs100k * 100000 input bytes -- the blocking of bzip2 itself, a slightly better ratio, and
+ * a serial dependency between the blocks' starts. */
+extern "C" int lbzamd_set_sequential(lbzamd_ctx *c, int on)
+{
+  if (!c) { g_err = "lbzamd_set_sequential: bad argument"; return -1; }
+  c->sequential = on != 0;
+  return 0;
+}
+
 extern "C" int lbzamd_compress_device(lbzamd_ctx *c, const void *d_in_v, size_t len,
                                       void *d_out_v, size_t out_cap, size_t *out_len)
 {
@@ -347,9 +364,69 @@ static int compress_device(lbzamd_ctx *c, const void *d_in_v, size_t len, void *
   hipStream_t s = c->stream;
   for (float &k : c->kms) k = 0;
 
+  if (c->sequential) {
+    /* -u / --sequential (compress.c:129-198): chunks of up to max_slabs BLOCKS; where a block starts is known
+       when its predecessor has been cut, so the tokenising pass of a chunk's blocks runs as a chain inside one
+       launch (k_collect_seq) before the rounds take the blocks through the other stages */
+    if (body) { g_err = "lbzamd_compress: a slab range of a sequential stream cannot be cut ahead of time (body-only call in sequential mode)"; return -1; }
+    if (!c->seq_starts) {
+      HIPCHK(hipMalloc((void **)&c->seq_starts, ((size_t)c->max_slabs + 2u) * sizeof(unsigned long long)));
+      HIPCHK(hipMalloc((void **)&c->seq_ticket, sizeof(u32)));
+      HIPCHK(hipMalloc((void **)&c->seq_out, sizeof(lbz_seq_out)));
+    }
+    if (c->h2d_host) {                           /* host-buffer call: the cuts are not known slab by slab, copy up front */
+      HIPCHK(hipMemcpyAsync(const_cast<u8 *>(d_in), c->h2d_host, len, hipMemcpyHostToDevice, s));
+    }
+    uint64_t pos = 0;
+    bool first = true;
+    do {
+      const unsigned long long start0 = pos + 1ull;
+      HIPCHK(hipMemsetAsync(c->seq_starts, 0, ((size_t)c->max_slabs + 2u) * sizeof(unsigned long long), s));
+      HIPCHK(hipMemsetAsync(c->seq_ticket, 0, sizeof(u32), s));
+      HIPCHK(hipMemsetAsync(c->seq_out, 0, sizeof(lbz_seq_out), s));
+      HIPCHK(hipMemcpyAsync(c->seq_starts, &start0, sizeof start0, hipMemcpyHostToDevice, s));
+      HIPCHK(hipEventRecord(c->ev[4], s));
+      if (len) hipLaunchKernelGGL(k_collect_seq, dim3(c->max_slabs), dim3(LBZ_COLLECT_WG), 0, s, d_in, (u64)len, c->L, c->T, c->meta,
+                                  (u32)c->max_slabs, c->seq_starts, c->seq_ticket, c->seq_out);
+      HIPCHK(hipEventRecord(c->ev[5], s));
+      lbz_seq_out so{};
+      if (len) {
+        HIPCHK(hipMemcpyAsync(&so, c->seq_out, sizeof so, hipMemcpyDeviceToHost, s));
+        HIPCHK(hipStreamSynchronize(s));
+        HIPCHK(hipGetLastError());
+        if (so.err) { g_err = "lbzamd_compress: the block chain of the sequential mode broke (device error)"; return -1; }
+        float t = 0;
+        HIPCHK(hipEventElapsedTime(&t, c->ev[4], c->ev[5]));
+        acc[3] += t;
+      }
+      const uint32_t nb = so.nblocks;
+      const bool last = !len || so.next >= len;
+      if (nb) {
+        if (run_chunk(c, d_in, len, nb, 3, true)) return -1;
+      } else {
+        c->nbev_used = 0;
+        for (int i = 0; i <= 2; i++) HIPCHK(hipEventRecord(c->ev[i], s));
+      }
+      hipLaunchKernelGGL(k_offsets, dim3(1), dim3(LBZ_WG), 0, s, (const lbz_block_meta *)c->meta, (u32)(2u * nb),
+                         (u32)c->bs100k, (u32)first, (u32)last, 0u, c->offs, c->st, d_out, (u64)out_cap);
+      if (nb)
+        hipLaunchKernelGGL(k_gather, dim3((u32)(2u * nb)), dim3(LBZ_WG), 0, s, (const u8 *)c->O,
+                           (const lbz_block_meta *)c->meta, c->L, (const u64 *)c->offs,
+                           (const lbz_stream_state *)c->st, d_out, (u32)nb);
+      HIPCHK(hipEventRecord(c->ev[3], s));
+      HIPCHK(hipGetLastError());
+      HIPCHK(hipStreamSynchronize(s));
+      if (add_times(c, acc)) return -1;
+      if (!last && nb == 0) { g_err = "lbzamd_compress: sequential mode made no progress"; return -1; }
+      pos = so.next;
+      first = false;
+      if (last) break;
+    } while (true);
+    c->kms[5] += acc[3];
+  }
   size_t done = 0;
   bool first = true;
-  do {
+  if (!c->sequential) do {
     const size_t nsl = nslabs - done < c->max_slabs ? nslabs - done : c->max_slabs;
     const bool last = done + nsl == nslabs;
     const size_t off = done * (size_t)M;
@@ -384,7 +461,7 @@ static int compress_device(lbzamd_ctx *c, const void *d_in_v, size_t len, void *
   c->stats.ms_bwt_part = c->kms[0]; c->stats.ms_bwt_batch = c->kms[1]; c->stats.ms_bwt_fix = c->kms[2];
   c->stats.ms_bwt = c->kms[0] + c->kms[1] + c->kms[2];
   c->stats.ms_mtf = c->kms[3]; c->stats.ms_encode = c->kms[4]; c->stats.ms_finish = acc[2];
-  c->stats.ms_total = acc[0] + acc[1] + acc[2];
+  c->stats.ms_total = acc[0] + acc[1] + acc[2] + acc[3];
   if (st.err) {
     char buf[96];
     snprintf(buf, sizeof buf, "device pipeline error code %u%s", st.err, st.err == 100u ? " (output buffer too small)" : "");

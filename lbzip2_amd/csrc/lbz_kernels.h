@@ -40,6 +40,13 @@ __global__ void k_collect(const u8 *in, u64 in_len, lbz_layout L, u8 *Tbase, lbz
  * spill block -- lbz_round_block().  Primaries come first so that the heavy blocks spread over
  * all XCDs (their block ids are all even).  The BWT kernels give workgroup i the workspace slot
  * i of `ws` (count full-size slots, then count spill-size slots at ws_spill).               */
+struct lbz_seq_out {
+  u64 next;          /* input position behind the last block of this launch */
+  u32 nblocks;       /* blocks that took input */
+  u32 err;
+};
+__global__ void k_collect_seq(const u8 *in, u64 in_len, lbz_layout L, u8 *Tbase, lbz_block_meta *meta, u32 nblk,
+                              unsigned long long *starts, u32 *ticket, lbz_seq_out *so);
 __global__ void k_bwt_part(const u8 *Tbase, lbz_block_meta *meta, lbz_layout L, u32 first, u32 count,
                            u8 *ws, u64 slot_bytes, u8 *ws_spill, u64 spill_bytes, const u32 *slabs);
 __global__ void k_bwt_part2(const u8 *Tbase, lbz_block_meta *meta, lbz_layout L, u32 first, u32 count,

@@ -256,7 +256,7 @@ static int stream_files(const char *in_path, const char *out_path, unsigned leve
 
 int main(int argc, char **argv)
 {
-  unsigned level = 9, nworkers = 0, timing = 0, repeat = 1, chunk_slabs = 256, npipes = 2, decompress = 0;
+  unsigned level = 9, nworkers = 0, timing = 0, repeat = 1, chunk_slabs = 256, npipes = 2, decompress = 0, sequential = 0;
   const char *in_path = NULL, *out_path = NULL;
   for (int i = 1; i < argc; i++) {
     if (!strcmp(argv[i], "-f") && i + 1 < argc) { in_path = argv[++i]; continue; }
@@ -265,6 +265,7 @@ int main(int argc, char **argv)
     if (!strcmp(argv[i], "-p") && i + 1 < argc) { npipes = (unsigned)atoi(argv[++i]); continue; }
     if (!strcmp(argv[i], "-t")) { timing = 1; continue; }            /* phase times on stderr */
     if (!strcmp(argv[i], "-d")) { decompress = 1; continue; }        /* the inverse path: .bz2 -> bytes */
+    if (!strcmp(argv[i], "-u")) { sequential = 1; continue; }        /* the reference's -u: blocks cut where they are full (batch mode) */
     if (!strcmp(argv[i], "-r") && i + 1 < argc) { repeat = (unsigned)atoi(argv[++i]); continue; }   /* run the codec phase N times */
     if (argv[i][0] == '-' && argv[i][1] >= '1' && argv[i][1] <= '9' && !argv[i][2]) level = argv[i][1] - '0';
     else if (!strcmp(argv[i], "-w") && i + 1 < argc) nworkers = (unsigned)atoi(argv[++i]);
@@ -319,6 +320,7 @@ int main(int argc, char **argv)
       fprintf(stderr, "lbzamd: %s\n", lbzamd_last_error());
       return 1;
     }
+    if (sequential && lbzamd_set_sequential(ctx, 1)) { fprintf(stderr, "lbzamd: %s\n", lbzamd_last_error()); return 1; }
     double t1 = now_s();
     for (unsigned r = 0; r < repeat; r++) {
       if (lbzamd_compress_host(ctx, in, len, out, cap, &n)) { fprintf(stderr, "lbzamd: %s\n", lbzamd_last_error()); return 1; }

@@ -615,6 +615,39 @@ done:
   return o;
 }
 
+/* -u / --sequential (compress.c:129-198): a block takes input until it is full, whatever the slab boundaries */
+size_t
+orc_compress_seq(const uint8_t *in, size_t len, unsigned bs100k,
+                 uint8_t *out, size_t cap, uint32_t *nblocks)
+{
+  uint32_t M = bs100k * 100000u, combined = 0, nb = 0;
+  uint8_t *block = malloc(M);
+  uint16_t *mtfv = malloc(((size_t)M + 1 + ORC_GROUP) * sizeof *mtfv);
+  orc_block_t *b = malloc(sizeof *b);
+  size_t o = 0, pos = 0;
+
+  if (cap < 14) { o = 0; goto done; }
+  out[o++] = 'B'; out[o++] = 'Z'; out[o++] = 'h'; out[o++] = (uint8_t)('0' + bs100k);
+  while (pos < len) {
+    orc_collect_t c;
+    orc_collect(in + pos, len - pos, M, block, &c);
+    pos += c.consumed;
+    orc_encode_block(block, &c, 8, mtfv, b);
+    if (o + b->out_len + 10 > cap) { o = 0; goto done; }
+    orc_transmit(b, mtfv, out + o);
+    o += b->out_len;
+    combined = ((combined << 1) | (combined >> 31)) ^ ~c.crc;
+    nb++;
+  }
+  out[o++] = 0x17; out[o++] = 0x72; out[o++] = 0x45; out[o++] = 0x38; out[o++] = 0x50; out[o++] = 0x90;
+  out[o++] = (uint8_t)(combined >> 24); out[o++] = (uint8_t)(combined >> 16);
+  out[o++] = (uint8_t)(combined >> 8);  out[o++] = (uint8_t)combined;
+done:
+  if (nblocks) *nblocks = nb;
+  free(block); free(mtfv); free(b);
+  return o;
+}
+
 /* ------------------------------------------------------------------------- */
 /* Seeded inputs                                          */
 /* ------------------------------------------------------------------------- */

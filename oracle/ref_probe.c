@@ -57,6 +57,47 @@ ref_compress_stream(const uint8_t *in, size_t len, unsigned bs100k,
   return o;
 }
 
+/* ---- the same for -u / --sequential (compress.c:129-198 do_collect_seq): ONE encoder keeps collecting over
+ * slab boundaries until its block is full, so the blocking is that of a continuous RLE1 over the input ---- */
+size_t
+ref_compress_seq(const uint8_t *in, size_t len, unsigned bs100k,
+                 uint8_t *out, size_t outcap)
+{
+  size_t mbs = (size_t)bs100k * 100000u;
+  size_t o = 0, pos = 0;
+  uint32_t combined = 0;
+  if (outcap < 14) return 0;
+  out[o++] = 'B'; out[o++] = 'Z'; out[o++] = 'h'; out[o++] = (uint8_t)('0' + bs100k);
+  while (pos < len) {
+    struct encoder_state *e = malloc(encoder_alloc_size(mbs));
+    uint32_t crc;
+    size_t size;
+    int full = 0;
+    encoder_init(e, mbs, CLUSTER_FACTOR);
+    while (!full && pos < len) {                        /* slab by slab, as the scheduler feeds it */
+      size_t left = len - pos < mbs ? len - pos : mbs, before = left;
+      full = collect(e, in + pos, &left);
+      pos += before - left;
+    }
+    size = encode(e, &crc);
+    if (o + (size + 3) / 4 * 4 + 10 > outcap) { free(e); return 0; }
+    {
+      uint32_t *buf = malloc(((size + 3) / 4) * 4);
+      transmit(e, buf);
+      memcpy(out + o, buf, size);
+      free(buf);
+    }
+    o += size;
+    combined = combine_crc(combined, crc);
+    free(e);
+  }
+  out[o++] = 0x17; out[o++] = 0x72; out[o++] = 0x45;
+  out[o++] = 0x38; out[o++] = 0x50; out[o++] = 0x90;
+  out[o++] = combined >> 24; out[o++] = combined >> 16;
+  out[o++] = combined >> 8;  out[o++] = combined;
+  return o;
+}
+
 /* ---- per-stage accessors ---- */
 uint32_t ref_nblock(struct encoder_state *e) { return e->nblock; }
 uint32_t ref_block_crc(struct encoder_state *e) { return e->block_crc; }

@@ -20,6 +20,7 @@
 #include <cstring>
 #include <functional>
 #include <type_traits>
+#include <unistd.h>
 
 #define LBZ_EMULATED 1
 
@@ -67,7 +68,7 @@ static inline void __builtin_amdgcn_s_barrier() { emu::sync_block(); }
 static inline void __builtin_amdgcn_s_waitcnt(int) {}
 static inline void __threadfence() { std::atomic_thread_fence(std::memory_order_seq_cst); }
 static inline void __threadfence_block() {}
-static inline void __builtin_amdgcn_s_sleep(int) {}
+static inline void __builtin_amdgcn_s_sleep(int) { usleep(50); }   /* a spinning workgroup waits for one that runs on another host thread */
 static inline unsigned long long wall_clock64() { return 0; }
 
 static inline unsigned long long __ballot(int pred) { return emu::wave_ballot(pred); }

@@ -127,6 +127,29 @@ def orc_compress(data: bytes, level: int = 9) -> bytes:
     return out.raw[:n]
 
 
+def ref_compress_seq(data: bytes, level: int = 9) -> bytes:
+    """-u / --sequential blocking through the compiled reference (oracle/ref_probe.c: ref_compress_seq)"""
+    R = ref()
+    R.ref_compress_seq.argtypes = [C.c_char_p, C.c_size_t, C.c_uint, C.c_void_p, C.c_size_t]
+    R.ref_compress_seq.restype = C.c_size_t
+    cap = _cap(len(data))
+    out = C.create_string_buffer(cap)
+    n = R.ref_compress_seq(bytes(data), len(data), level, out, cap)
+    assert n > 0
+    return out.raw[:n]
+
+
+def orc_compress_seq(data: bytes, level: int = 9) -> bytes:
+    O = oracle()
+    O.orc_compress_seq.argtypes = [C.c_char_p, C.c_size_t, C.c_uint, C.c_void_p, C.c_size_t, C.c_void_p]
+    O.orc_compress_seq.restype = C.c_size_t
+    cap = _cap(len(data))
+    out = C.create_string_buffer(cap)
+    n = O.orc_compress_seq(bytes(data), len(data), level, out, cap, None)
+    assert n > 0
+    return out.raw[:n]
+
+
 def ref_compress(data: bytes, level: int = 9) -> bytes:
     R = ref()
     cap = _cap(len(data))
