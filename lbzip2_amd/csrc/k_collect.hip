@@ -117,7 +117,9 @@ __device__ u32 wg_crc32(const u8 *x, u32 a, u32 b, u32 xlen, collect_lds *S)
 }
 
 /* Tokenise x[base..end) into out[] (capacity cap).  Returns via S->bc: [0] = bytes written,
- * [1] = first unconsumed position (== end if everything fitted).                        */
+ * [1] = first unconsumed position (== end if everything fitted).  EMIT = false: the same decisions without
+ * the output (count bytes, staging, stores, used-byte map) -- where the block ends, nothing else.          */
+template <bool EMIT = true>
 __device__ void collect_pass(const u8 *x, u32 base, u32 end, u32 cap, u8 *out, collect_lds *S)
 {
   const u32 tid = threadIdx.x;
@@ -171,7 +173,7 @@ __device__ void collect_pass(const u8 *x, u32 base, u32 end, u32 cap, u8 *out, c
       if (act) {
         const u32 kk = (p - (rs - 1u)) % LBZ_RUN_CAP;
         u32 e = kk < 3u ? 1u : (kk == 3u ? 2u : 0u);
-        if (kk == 3u) {
+        if (EMIT && kk == 3u) {
           u32 c = 0;
           while (c < 255u && p + 1u + c < end && x[p + 1u + c] == b[i]) c++;
           cnt[i] = (u8)c;
@@ -201,6 +203,7 @@ __device__ void collect_pass(const u8 *x, u32 base, u32 end, u32 cap, u8 *out, c
     /* the tile's bytes go to LDS first and leave as whole 16-byte vectors of the block array */
     const u32 gbase = o_base & ~15u;
     u32 oo = o;
+    if (EMIT) {
 #pragma unroll
     for (u32 i = 0; i < COL_IPT; i++) {
       const u32 e = (emit2 >> (2u * i)) & 3u;
@@ -211,8 +214,9 @@ __device__ void collect_pass(const u8 *x, u32 base, u32 end, u32 cap, u8 *out, c
       }
       oo += e;
     }
+    }
     __syncthreads();
-    {
+    if (EMIT) {
       const u32 o_end = (cut != end) ? S->bc[0] : o_base + ttot;        /* bytes of this block so far */
       const bool out_ok = ((uintptr_t)out & 15u) == 0u;
       for (u32 v = gbase + 16u * tid; v < o_end; v += 16u * LBZ_WG) {
@@ -342,14 +346,17 @@ k_collect_seq(const u8 *in, u64 in_len, lbz_layout L, u8 *Tbase, lbz_block_meta 
   const u64 left = in_len - p;
   const u64 maxraw = (u64)L.M * 52u + 1024u;
   const u32 end = mis + (u32)(left < maxraw ? left : maxraw);
-  collect_pass(x, mis, end, L.M, Tbase + lbz_elem_off(L, 2u * b), &S);
-  const u32 nblock = S.bc[0], stop = S.bc[1];
+  collect_pass<false>(x, mis, end, L.M, nullptr, &S);        /* where this block ends: the successor can start */
+  const u32 stop = S.bc[1];
   if (tid == 0) {
     const u64 nx = p + (u64)(stop - mis);
     __atomic_store_n(&starts[b + 1u], nx + 1ull, __ATOMIC_RELEASE);
     if (b + 1u == nblk || nx >= in_len) so->next = nx;
     atomicAdd(&so->nblocks, 1u);
   }
+  __syncthreads();
+  collect_pass<true>(x, mis, stop, L.M, Tbase + lbz_elem_off(L, 2u * b), &S);      /* off the chain: bytes, used-byte map, CRC */
+  const u32 nblock = S.bc[0];
   __syncthreads();
   const u32 crc = wg_crc32(x, mis, stop, end, &S);
   if (tid < 256) m->inuse[tid] = (u8)S.inuse[tid];
