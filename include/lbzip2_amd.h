@@ -51,7 +51,8 @@ void   encoder_init(struct encoder_state *e, unsigned long mbs, unsigned cf);
 /* Consumes a prefix of buf[0..*buf_sz) into the block (RLE1 + CRC); *buf_sz = bytes left
  * unconsumed.  Returns 1 if the block filled up before the input ran out.
  * RESTRICTIONS of this implementation (the call pattern of compress.c's default mode, :73-118, is
- * what it serves; lbzip2's -u/--sequential mode, compress.c:129-198, is not supported):
+ * what it serves; lbzip2's -u/--sequential mode, compress.c:129-198, re-enters collect() and is served by the
+ * batch interface only -- lbzamd_set_sequential() below):
  *   - ONE collect() per encoder state, on at most max_block_size bytes (more is left unconsumed:
  *     the caller re-queues it as the slab's next work unit, compress.c:98-104);
  *   - a second collect() on the same state, or encode() on a state that never collected a byte,
