@@ -120,15 +120,16 @@ __device__ u32 wg_crc32(const u8 *x, u32 a, u32 b, u32 xlen, collect_lds *S)
  * [1] = first unconsumed position (== end if everything fitted).  EMIT = false: the same decisions without
  * the output (count bytes, staging, stores, used-byte map) -- where the block ends, nothing else.          */
 template <bool EMIT = true>
-__device__ void collect_pass(const u8 *x, u32 base, u32 end, u32 cap, u8 *out, collect_lds *S)
+__device__ void collect_pass(const u8 *x, u32 base, u32 end, u32 cap, u8 *out, collect_lds *S,
+                             u32 t_resume = 0xFFFFFFFFu, u32 o_resume = 0, u32 rs_resume = 0)
 {
   const u32 tid = threadIdx.x;
   const bool vec_ok = ((uintptr_t)x & 15u) == 0u;
-  u32 carry_rs = 0;        /* (run start of the last byte seen) + 1; 0 = none yet */
-  u32 o_base = 0;
+  u32 carry_rs = rs_resume;   /* (run start of the last byte seen) + 1; 0 = none yet */
+  u32 o_base = o_resume;
   u32 cut = end;
 
-  const u32 tfirst = base & ~(COL_TILE - 1u);
+  const u32 tfirst = t_resume != 0xFFFFFFFFu ? t_resume : base & ~(COL_TILE - 1u);   /* resume: the state seq_skip() left */
   uint4 nxt = { 0u, 0u, 0u, 0u };
   if (vec_ok && tfirst + tid * COL_IPT + COL_IPT <= end) nxt = *reinterpret_cast<const uint4 *>(x + tfirst + tid * COL_IPT);
   for (u32 t0 = tfirst; t0 < end; t0 += COL_TILE) {
@@ -292,6 +293,71 @@ k_collect(const u8 *in, u64 in_len, lbz_layout L, u8 *Tbase, lbz_block_meta *met
 }
 
 
+/* The part of a block that cannot contain its end, in 64 KB steps with one scan and one sum each: the same run
+ * starts and emitted-byte counts as collect_pass, totals only.  Leaves the state collect_pass resumes from (tile,
+ * bytes so far, run start carried) at the first step the block might fill in.                              */
+#define SKIP_IPT 64u
+#define SKIP_TILE (LBZ_WG * SKIP_IPT)
+__device__ void seq_skip(const u8 *x, u32 base, u32 end, u32 cap, collect_lds *S, u32 *t_out, u32 *o_out, u32 *rs_out)
+{
+  const u32 tid = threadIdx.x;
+  const bool vec_ok = ((uintptr_t)x & 15u) == 0u;
+  u32 carry_rs = 0, o_base = 0;
+  u32 t0 = base & ~(COL_TILE - 1u);
+  for (; t0 < end; t0 += SKIP_TILE) {
+    const u32 p0 = t0 + tid * SKIP_IPT;
+    u32 w[SKIP_IPT / 4u];
+    if (vec_ok && p0 + SKIP_IPT <= end) {
+#pragma unroll
+      for (u32 q = 0; q < SKIP_IPT / 16u; q++) {
+        const uint4 v = *reinterpret_cast<const uint4 *>(x + p0 + 16u * q);
+        w[4u * q] = v.x; w[4u * q + 1u] = v.y; w[4u * q + 2u] = v.z; w[4u * q + 3u] = v.w;
+      }
+    } else {
+#pragma unroll
+      for (u32 q = 0; q < SKIP_IPT / 4u; q++) {
+        w[q] = 0;
+        for (u32 j = 0; j < 4u; j++) if (p0 + 4u * q + j < end) w[q] |= (u32)x[p0 + 4u * q + j] << (8u * j);
+      }
+    }
+    u32 prevb = lane_from_below(w[SKIP_IPT / 4u - 1u] >> 24);
+    if (lane_id() == 0u) prevb = (p0 > base && p0 <= end) ? x[p0 - 1] : 0u;
+    /* the last run head of my bytes */
+    u32 lh = 0, pb = prevb;
+#pragma unroll
+    for (u32 i = 0; i < SKIP_IPT; i++) {
+      const u32 p = p0 + i, bi = (w[i >> 2] >> (8u * (i & 3u))) & 255u;
+      const bool act = p >= base && p < end;
+      if (act && (p == base || bi != pb)) lh = p + 1u;
+      pb = bi;
+    }
+    u32 emax, e_unused, tmax, t_unused;
+    wg_excl_max_add(lh, 0u, &emax, &e_unused, &tmax, &t_unused, &S->sc);
+    u32 rs = emax > carry_rs ? emax : carry_rs;
+    /* bytes my positions emit: k = position inside the run's 259-byte chunk, kept incrementally */
+    u32 nout = 0, k = 0;
+    bool have = false;
+    pb = prevb;
+#pragma unroll
+    for (u32 i = 0; i < SKIP_IPT; i++) {
+      const u32 p = p0 + i, bi = (w[i >> 2] >> (8u * (i & 3u))) & 255u;
+      const bool act = p >= base && p < end;
+      if (act) {
+        if (p == base || bi != pb) { k = 0; have = true; }
+        else if (!have) { k = (p - (rs - 1u)) % LBZ_RUN_CAP; have = true; }
+        else { k++; if (k == LBZ_RUN_CAP) k = 0; }
+        nout += k < 3u ? 1u : (k == 3u ? 2u : 0u);
+      }
+      pb = bi;
+    }
+    const u32 total = wg_sum(nout, &S->sc);
+    if (o_base + total > cap) break;                 /* the block may end in this step: collect_pass takes over here */
+    o_base += total;
+    carry_rs = tmax > carry_rs ? tmax : carry_rs;
+  }
+  *t_out = t0; *o_out = o_base; *rs_out = carry_rs;
+}
+
 /* ---- -u / --sequential (compress.c:129-198, do_collect_seq): a block takes input until it is full, whatever
  * the slab boundaries, so where block b starts is known only when block b - 1 has been cut.  One launch, one
  * workgroup per block slot; workgroups take their block number from a ticket counter (so every predecessor is
@@ -346,7 +412,9 @@ k_collect_seq(const u8 *in, u64 in_len, lbz_layout L, u8 *Tbase, lbz_block_meta 
   const u64 left = in_len - p;
   const u64 maxraw = (u64)L.M * 52u + 1024u;
   const u32 end = mis + (u32)(left < maxraw ? left : maxraw);
-  collect_pass<false>(x, mis, end, L.M, nullptr, &S);        /* where this block ends: the successor can start */
+  u32 t_res, o_res, rs_res;
+  seq_skip(x, mis, end, L.M, &S, &t_res, &o_res, &rs_res);    /* 64 KB steps up to where the block might end ... */
+  collect_pass<false>(x, mis, end, L.M, nullptr, &S, t_res, o_res, rs_res);   /* ... and the cut itself: the successor can start */
   const u32 stop = S.bc[1];
   if (tid == 0) {
     const u64 nx = p + (u64)(stop - mis);
