@@ -23,8 +23,9 @@ __device__ __forceinline__ int wave_shr1(int v)
  * and stays in scalar registers.  All arguments are wave-uniform except L0..L3 (the move-to-front list, entry i in
  * lane i & 63 of register i >> 6), cur (the input window, dword i of the current 256-byte chunk in lane i, MSB first) and lane.
  *
- * Per step: take 32 more bits when fewer than 20 are live; look the next 10 bits up (entry = symbol << 5 |
- * length); RUNA/RUNB add to the pending zero run; any other symbol first stores a pending run of <= 64 bytes, then
+ * A strip at a time: with more than 32 bits in the buffer, lane j looks up the 10 bits that start at bit j (ONE LDS
+ * read, entry = symbol << 5 | length); the symbols of the strip are then taken with v_readlane at the running bit
+ * offset, so the LDS latency (~37 ns) is paid once per ~10 symbols and not per symbol.  Per symbol: RUNA/RUNB add to the pending zero run; any other symbol first stores a pending run of <= 64 bytes, then
  * moves list entry symbol - 1 to the front and stores it (entries 64..255 live in L1..L3).  The loop RETURNS, with nothing of the current
  * symbol consumed, when the group's 50 symbols are done, the table has no entry (long code, end of block),
  * the run is longer than 64 or would overflow, or the next dword is the
@@ -33,14 +34,18 @@ __device__ __forceinline__ void huff_fast(unsigned long long &buf, unsigned &liv
                                           unsigned &n, unsigned &es, unsigned &N, int &L0, int &L1, int &L2, int &L3,
                                           unsigned lutaddr, unsigned char *tt8, unsigned maxn, unsigned lane)
 {
-  unsigned t0, t1, t2, e, l, sym, va, vb, vsh, ve;
+  unsigned t0, t1, t2, e, l, sym, off, lim, va, vb, vsh, ve;
+  const unsigned vneg = (32u - lane) & 31u;
   asm volatile(
-    "s_mov_b64 s[40:41], %[buf]\n"
-    "HF_LOOP_%=:\n\t"
-    "s_cmp_ge_u32 %[k], 50\n\t"
-    "s_cbranch_scc1 HF_DONE_%=\n\t"
-    "s_cmp_ge_u32 %[live], 20\n\t"
-    "s_cbranch_scc1 HF_LOOK_%=\n\t"
+    "s_mov_b64 s[40:41], %[buf]\n\t"
+    "s_mov_b32 s46, 1\n\t"                      /* lane 0 */
+    "s_mov_b32 s47, 0\n\t"
+    "s_mov_b32 s48, 0\n\t"                      /* lanes 32..63 */
+    "s_mov_b32 s49, -1\n"
+    /* a strip: every lane looks up the 10 bits that start at ITS bit offset of the buffer, one LDS read for all */
+    "HF_REFRESH_%=:\n\t"
+    "s_cmp_gt_u32 %[live], 32\n\t"
+    "s_cbranch_scc1 HF_STRIP_%=\n\t"
     "s_and_b32 %[t0], %[dwl], 63\n\t"
     "s_cmp_eq_u32 %[t0], 63\n\t"
     "s_cbranch_scc1 HF_DONE_%=\n\t"
@@ -51,16 +56,29 @@ __device__ __forceinline__ void huff_fast(unsigned long long &buf, unsigned &liv
     "s_or_b64 s[40:41], s[40:41], s[42:43]\n\t"
     "s_add_u32 %[live], %[live], 32\n\t"
     "s_add_u32 %[dwl], %[dwl], 1\n"
-    "HF_LOOK_%=:\n\t"
-    "s_lshr_b32 %[t0], s41, 21\n\t"
-    "s_and_b32 %[t0], %[t0], 0x7fe\n\t"
-    "s_add_u32 %[t0], %[t0], %[lut]\n\t"
-    "v_mov_b32 %[va], %[t0]\n\t"
+    "HF_STRIP_%=:\n\t"
+    "v_mov_b32 %[vb], s40\n\t"
+    "v_mov_b32 %[vsh], s41\n\t"
+    "v_alignbit_b32 %[va], s41, %[vb], %[vneg]\n\t"          /* lanes 1..31: (hi << j) | (lo >> (32 - j)) */
+    "v_cndmask_b32_e64 %[va], %[va], %[vsh], s[46:47]\n\t"   /* lane 0: hi */
+    "v_lshlrev_b32 %[vb], %[lane], %[vb]\n\t"                /* lanes 32..63: lo << (j - 32) */
+    "v_cndmask_b32_e64 %[va], %[va], %[vb], s[48:49]\n\t"
+    "v_lshrrev_b32 %[va], 21, %[va]\n\t"
+    "v_and_b32 %[va], 0x7fe, %[va]\n\t"
+    "v_add_u32 %[va], %[lut], %[va]\n\t"
     "ds_read_u16 %[ve], %[va]\n\t"
-    "s_waitcnt lgkmcnt(0)\n\t"
-    "v_readfirstlane_b32 %[e], %[ve]\n\t"
+    "s_mov_b32 %[off], 0\n\t"
+    "s_sub_u32 %[lim], %[live], 10\n\t"
+    "s_min_u32 %[lim], %[lim], 53\n\t"        /* a strip ends before bit 64: the 64-bit shift that drops it takes 0..63 */
+    "s_waitcnt lgkmcnt(0)\n"
+    "HF_LOOP_%=:\n\t"
+    "s_cmp_ge_u32 %[k], 50\n\t"
+    "s_cbranch_scc1 HF_EXIT_%=\n\t"
+    "s_cmp_gt_u32 %[off], %[lim]\n\t"
+    "s_cbranch_scc1 HF_CONSUME_%=\n\t"
+    "v_readlane_b32 %[e], %[ve], %[off]\n\t"
     "s_cmp_eq_u32 %[e], 0\n\t"
-    "s_cbranch_scc1 HF_DONE_%=\n\t"
+    "s_cbranch_scc1 HF_EXIT_%=\n\t"
     "s_and_b32 %[l], %[e], 31\n\t"
     "s_lshr_b32 %[sym], %[e], 5\n\t"
     "s_cmp_le_u32 %[sym], 1\n\t"
@@ -69,10 +87,10 @@ __device__ __forceinline__ void huff_fast(unsigned long long &buf, unsigned &liv
     "s_cmp_eq_u32 %[es], 0\n\t"
     "s_cbranch_scc1 HF_LIT_%=\n\t"
     "s_cmp_gt_u32 %[es], 64\n\t"
-    "s_cbranch_scc1 HF_DONE_%=\n\t"
+    "s_cbranch_scc1 HF_EXIT_%=\n\t"
     "s_add_u32 %[t0], %[n], %[es]\n\t"
     "s_cmp_gt_u32 %[t0], %[maxn]\n\t"
-    "s_cbranch_scc1 HF_DONE_%=\n\t"
+    "s_cbranch_scc1 HF_EXIT_%=\n\t"
     "v_readlane_b32 %[t1], %[L0], 0\n\t"
     "v_mov_b32 %[vb], %[t1]\n\t"
     "v_add_u32 %[va], %[n], %[lane]\n\t"
@@ -84,8 +102,7 @@ __device__ __forceinline__ void huff_fast(unsigned long long &buf, unsigned &liv
     "s_mov_b32 %[es], 0\n\t"
     "s_mov_b32 %[N], 0\n"
     "HF_LIT_%=:\n\t"
-    "s_lshl_b64 s[40:41], s[40:41], %[l]\n\t"
-    "s_sub_u32 %[live], %[live], %[l]\n\t"
+    "s_add_u32 %[off], %[off], %[l]\n\t"
     "s_add_u32 %[k], %[k], 1\n\t"
     "s_cmp_ge_u32 %[sym], 64\n\t"
     "s_cbranch_scc1 HF_FAR_%=\n\t"
@@ -137,22 +154,29 @@ __device__ __forceinline__ void huff_fast(unsigned long long &buf, unsigned &liv
     "s_branch HF_OUT_%=\n"
     "HF_RUN_%=:\n\t"
     "s_cmp_ge_u32 %[N], 21\n\t"
-    "s_cbranch_scc1 HF_DONE_%=\n\t"
+    "s_cbranch_scc1 HF_EXIT_%=\n\t"
     "s_add_u32 %[t0], %[sym], 1\n\t"
     "s_lshl_b32 %[t0], %[t0], %[N]\n\t"
     "s_add_u32 %[es], %[es], %[t0]\n\t"
     "s_add_u32 %[N], %[N], 1\n\t"
-    "s_lshl_b64 s[40:41], s[40:41], %[l]\n\t"
-    "s_sub_u32 %[live], %[live], %[l]\n\t"
+    "s_add_u32 %[off], %[off], %[l]\n\t"
     "s_add_u32 %[k], %[k], 1\n\t"
     "s_branch HF_LOOP_%=\n"
+    /* the strip is used up: drop its bits, look the next ones up */
+    "HF_CONSUME_%=:\n\t"
+    "s_lshl_b64 s[40:41], s[40:41], %[off]\n\t"
+    "s_sub_u32 %[live], %[live], %[off]\n\t"
+    "s_branch HF_REFRESH_%=\n"
+    "HF_EXIT_%=:\n\t"
+    "s_lshl_b64 s[40:41], s[40:41], %[off]\n\t"
+    "s_sub_u32 %[live], %[live], %[off]\n"
     "HF_DONE_%=:\n\t"
     "s_mov_b64 %[buf], s[40:41]"
     : [buf] "+s"(buf), [live] "+s"(live), [dwl] "+s"(dwl), [k] "+s"(k), [n] "+s"(n), [es] "+s"(es), [N] "+s"(N), [L0] "+v"(L0),
       [L1] "+v"(L1), [L2] "+v"(L2), [L3] "+v"(L3), [t0] "=&s"(t0), [t1] "=&s"(t1), [t2] "=&s"(t2), [e] "=&s"(e), [l] "=&s"(l), [sym] "=&s"(sym),
-      [va] "=&v"(va), [vb] "=&v"(vb), [vsh] "=&v"(vsh), [ve] "=&v"(ve)
-    : [cur] "v"(cur), [lane] "v"(lane), [lut] "s"(lutaddr), [tt8] "s"(tt8), [maxn] "s"(maxn)
-    : "s40", "s41", "s42", "s43", "s44", "s45", "vcc", "scc", "memory");
+      [off] "=&s"(off), [lim] "=&s"(lim), [va] "=&v"(va), [vb] "=&v"(vb), [vsh] "=&v"(vsh), [ve] "=&v"(ve)
+    : [cur] "v"(cur), [lane] "v"(lane), [vneg] "v"(vneg), [lut] "s"(lutaddr), [tt8] "s"(tt8), [maxn] "s"(maxn)
+    : "s40", "s41", "s42", "s43", "s44", "s45", "s46", "s47", "s48", "s49", "vcc", "scc", "memory");
 }
 
 /* wave_shl:1 -- lane l of the result is lane l + 1 of v (lane 63: v's own) */

@@ -11,47 +11,55 @@ static inline void huff_fast(unsigned long long &buf, unsigned &live, unsigned &
                              unsigned char *tt8, unsigned maxn, unsigned lane)
 {
   for (;;) {
-    if (k >= 50u) return;
-    if (live < 20u) {
+    /* a strip: lane j looks up the 10 bits that start at bit j of the buffer */
+    if (live <= 32u) {
       const unsigned i = dwl & 63u;
       if (i == 63u) return;
       const unsigned v = (unsigned)__builtin_amdgcn_readlane((int)cur, (int)i);
       buf |= (unsigned long long)v << (32u - live);
       live += 32u; dwl++;
     }
-    const unsigned e = (unsigned)__builtin_amdgcn_readfirstlane((int)lut[(unsigned)(buf >> 54)]);
-    if (e == 0u) return;
-    const unsigned l = e & 31u, sym = e >> 5;
-    if (sym <= 1u) {
-      if (N >= 21u) return;
-      es += (sym + 1u) << N; N++;
-    } else {
-      const unsigned nn = sym - 1u;
-      if (es) {
-        if (es > 64u || n + es > maxn) return;
-        const unsigned uc = (unsigned)__builtin_amdgcn_readlane(L0, 0);
-        if (lane < es) tt8[n + lane] = (unsigned char)uc;
-        n += es; es = 0; N = 0;
-      }
-      unsigned m;
-      if (nn < 64u) {
-        m = (unsigned)__builtin_amdgcn_readlane(L0, (int)nn);
-        const int sh = wave_shr1(L0);
-        L0 = lane == 0u ? (int)m : (lane <= nn ? sh : L0);
+    const int ve = (int)lut[(unsigned)((buf << lane) >> 54)];
+    unsigned off = 0;
+    const unsigned lim = live - 10u < 53u ? live - 10u : 53u;      /* a strip ends before bit 64 (shift counts 0..63) */
+    for (;;) {
+      if (k >= 50u) { buf <<= off; live -= off; return; }
+      if (off > lim) break;
+      const unsigned e = (unsigned)__builtin_amdgcn_readlane(ve, (int)off);
+      if (e == 0u) { buf <<= off; live -= off; return; }
+      const unsigned l = e & 31u, sym = e >> 5;
+      if (sym <= 1u) {
+        if (N >= 21u) { buf <<= off; live -= off; return; }
+        es += (sym + 1u) << N; N++;
       } else {
-        const unsigned q = nn >> 6, r = nn & 63u;
-        const int c0 = __builtin_amdgcn_readlane(L0, 63), c1 = __builtin_amdgcn_readlane(L1, 63), c2 = __builtin_amdgcn_readlane(L2, 63);
-        m = (unsigned)__builtin_amdgcn_readlane(q == 1u ? L1 : (q == 2u ? L2 : L3), (int)r);
-        const int s0 = wave_shr1(L0), s1 = wave_shr1(L1), s2 = wave_shr1(L2), s3 = wave_shr1(L3);
-        L0 = lane == 0u ? (int)m : s0;
-        L1 = lane == 0u ? c0 : ((q > 1u || lane <= r) ? s1 : L1);
-        if (q >= 2u) L2 = lane == 0u ? c1 : ((q > 2u || lane <= r) ? s2 : L2);
-        if (q >= 3u) L3 = lane == 0u ? c2 : (lane <= r ? s3 : L3);
+        const unsigned nn = sym - 1u;
+        if (es) {
+          if (es > 64u || n + es > maxn) { buf <<= off; live -= off; return; }
+          const unsigned uc = (unsigned)__builtin_amdgcn_readlane(L0, 0);
+          if (lane < es) tt8[n + lane] = (unsigned char)uc;
+          n += es; es = 0; N = 0;
+        }
+        unsigned m;
+        if (nn < 64u) {
+          m = (unsigned)__builtin_amdgcn_readlane(L0, (int)nn);
+          const int sh = wave_shr1(L0);
+          L0 = lane == 0u ? (int)m : (lane <= nn ? sh : L0);
+        } else {
+          const unsigned q = nn >> 6, r = nn & 63u;
+          const int c0 = __builtin_amdgcn_readlane(L0, 63), c1 = __builtin_amdgcn_readlane(L1, 63), c2 = __builtin_amdgcn_readlane(L2, 63);
+          m = (unsigned)__builtin_amdgcn_readlane(q == 1u ? L1 : (q == 2u ? L2 : L3), (int)r);
+          const int s0 = wave_shr1(L0), s1 = wave_shr1(L1), s2 = wave_shr1(L2), s3 = wave_shr1(L3);
+          L0 = lane == 0u ? (int)m : s0;
+          L1 = lane == 0u ? c0 : ((q > 1u || lane <= r) ? s1 : L1);
+          if (q >= 2u) L2 = lane == 0u ? c1 : ((q > 2u || lane <= r) ? s2 : L2);
+          if (q >= 3u) L3 = lane == 0u ? c2 : (lane <= r ? s3 : L3);
+        }
+        if (lane == 0u) tt8[n] = (unsigned char)m;
+        n++;
       }
-      if (lane == 0u) tt8[n] = (unsigned char)m;
-      n++;
+      off += l; k++;
     }
-    buf <<= l; live -= l; k++;
+    buf <<= off; live -= off;
   }
 }
 /* lanes are fibers here and their atomics interleave with other waves': lane 0 takes the whole
