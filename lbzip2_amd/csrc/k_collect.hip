@@ -322,33 +322,66 @@ __device__ void seq_skip(const u8 *x, u32 base, u32 end, u32 cap, collect_lds *S
     }
     u32 prevb = lane_from_below(w[SKIP_IPT / 4u - 1u] >> 24);
     if (lane_id() == 0u) prevb = (p0 > base && p0 <= end) ? x[p0 - 1] : 0u;
-    /* the last run head of my bytes */
-    u32 lh = 0, pb = prevb;
+    /* bit i of eq: byte i equals the byte before it -- four bytes per step (zero bytes of w ^ (w shifted in by one)) */
+    u64 eq = 0;
+    {
+      u32 pbyte = prevb;
 #pragma unroll
-    for (u32 i = 0; i < SKIP_IPT; i++) {
-      const u32 p = p0 + i, bi = (w[i >> 2] >> (8u * (i & 3u))) & 255u;
-      const bool act = p >= base && p < end;
-      if (act && (p == base || bi != pb)) lh = p + 1u;
-      pb = bi;
+      for (u32 q = 0; q < SKIP_IPT / 4u; q++) {
+        const u32 xw = w[q] ^ ((w[q] << 8) | pbyte);
+        const u32 nz = (((xw & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | xw) & 0x80808080u;     /* 0x80 in every non-zero byte */
+        const u32 y = (~nz & 0x80808080u) >> 7;
+        eq |= (u64)((y | (y >> 7) | (y >> 14) | (y >> 21)) & 15u) << (4u * q);
+        pbyte = w[q] >> 24;
+      }
     }
+    /* my positions inside [base, end), run heads among them (the block's first byte always is one) */
+    const u32 nlo = base > p0 ? (base - p0 < SKIP_IPT ? base - p0 : SKIP_IPT) : 0u;
+    const u32 nhi = end > p0 ? (end - p0 < SKIP_IPT ? end - p0 : SKIP_IPT) : 0u;
+    const u64 mlo = nlo >= 64u ? ~0ull : (1ull << nlo) - 1ull, mhi = nhi >= 64u ? ~0ull : (1ull << nhi) - 1ull;
+    const u64 act = mhi & ~mlo;
+    u64 heads = act & ~eq;
+    if (base >= p0 && base < p0 + SKIP_IPT) heads |= 1ull << (base - p0);
+    heads &= act;
+    const u64 cont = act & ~heads;                      /* positions that continue the run of the byte before */
+    const u32 lh = heads ? p0 + 64u - (u32)__clzll((long long)heads) : 0u;      /* (last head) + 1 */
     u32 emax, e_unused, tmax, t_unused;
     wg_excl_max_add(lh, 0u, &emax, &e_unused, &tmax, &t_unused, &S->sc);
     u32 rs = emax > carry_rs ? emax : carry_rs;
-    /* bytes my positions emit: k = position inside the run's 259-byte chunk, kept incrementally */
-    u32 nout = 0, k = 0;
-    bool have = false;
-    pb = prevb;
+    /* Bytes my positions emit: one each, one more where a run reaches its fourth byte (the count byte), none for
+       the run's bytes after that -- counted on the bit masks.  A run that comes in from the left has `lead` bytes
+       before me and t of mine; inside my range three continuing positions in a row mark the fourth byte of a run
+       that began here.  Only a run that could pass its 259-byte chunk inside my range is walked byte by byte. */
+    u32 nout;
+    const u32 first = act ? (u32)__ffsll((long long)act) - 1u : 0u;
+    const bool leftrun = act && ((cont >> first) & 1ull);
+    const u64 cf = cont >> first;
+    const u32 t = leftrun ? (~cf ? (u32)__ffsll((long long)~cf) - 1u : 64u) : 0u;
+    const u32 lead = leftrun ? p0 + first - (rs - 1u) : 0u;
+    if (!leftrun || lead + t < LBZ_RUN_CAP) {
+      const u64 tm = t >= 64u ? ~0ull : ((1ull << t) - 1ull) << first;
+      const u64 inner = cont & ~tm;
+      const u64 c3 = inner & (inner << 1) & (inner << 2);
+      const u32 n3 = (u32)__popcll(c3 & ~(c3 << 1)), n4 = (u32)__popcll(c3) - n3;
+      const u32 n3l = (leftrun && lead <= 3u && lead + t > 3u) ? 1u : 0u;
+      const u32 n4l = (leftrun && lead + t > 4u) ? lead + t - (lead > 4u ? lead : 4u) : 0u;
+      nout = (u32)__popcll(act) + n3 + n3l - n4 - n4l;
+    } else {
+      u32 k = 0, pb = prevb;
+      bool have = false;
+      nout = 0;
 #pragma unroll
-    for (u32 i = 0; i < SKIP_IPT; i++) {
-      const u32 p = p0 + i, bi = (w[i >> 2] >> (8u * (i & 3u))) & 255u;
-      const bool act = p >= base && p < end;
-      if (act) {
-        if (p == base || bi != pb) { k = 0; have = true; }
-        else if (!have) { k = (p - (rs - 1u)) % LBZ_RUN_CAP; have = true; }
-        else { k++; if (k == LBZ_RUN_CAP) k = 0; }
-        nout += k < 3u ? 1u : (k == 3u ? 2u : 0u);
+      for (u32 i = 0; i < SKIP_IPT; i++) {
+        const u32 p = p0 + i, bi = (w[i >> 2] >> (8u * (i & 3u))) & 255u;
+        if ((act >> i) & 1ull) {
+          if ((heads >> i) & 1ull) { k = 0; have = true; }
+          else if (!have) { k = (p - (rs - 1u)) % LBZ_RUN_CAP; have = true; }
+          else { k++; if (k == LBZ_RUN_CAP) k = 0; }
+          nout += k < 3u ? 1u : (k == 3u ? 2u : 0u);
+        }
+        pb = bi;
       }
-      pb = bi;
+      (void)pb;
     }
     const u32 total = wg_sum(nout, &S->sc);
     if (o_base + total > cap) break;                 /* the block may end in this step: collect_pass takes over here */
@@ -413,6 +446,7 @@ k_collect_seq(const u8 *in, u64 in_len, lbz_layout L, u8 *Tbase, lbz_block_meta 
   const u64 maxraw = (u64)L.M * 52u + 1024u;
   const u32 end = mis + (u32)(left < maxraw ? left : maxraw);
   u32 t_res, o_res, rs_res;
+  __builtin_amdgcn_s_setprio(3);            /* the chain's link goes first on its SIMDs; its neighbours are off the chain */
   seq_skip(x, mis, end, L.M, &S, &t_res, &o_res, &rs_res);    /* 64 KB steps up to where the block might end ... */
   collect_pass<false>(x, mis, end, L.M, nullptr, &S, t_res, o_res, rs_res);   /* ... and the cut itself: the successor can start */
   const u32 stop = S.bc[1];
@@ -422,6 +456,7 @@ k_collect_seq(const u8 *in, u64 in_len, lbz_layout L, u8 *Tbase, lbz_block_meta 
     if (b + 1u == nblk || nx >= in_len) so->next = nx;
     atomicAdd(&so->nblocks, 1u);
   }
+  __builtin_amdgcn_s_setprio(0);
   __syncthreads();
   collect_pass<true>(x, mis, stop, L.M, Tbase + lbz_elem_off(L, 2u * b), &S);      /* off the chain: bytes, used-byte map, CRC */
   const u32 nblock = S.bc[0];

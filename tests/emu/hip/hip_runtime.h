@@ -68,6 +68,7 @@ static inline void __builtin_amdgcn_s_barrier() { emu::sync_block(); }
 static inline void __builtin_amdgcn_s_waitcnt(int) {}
 static inline void __threadfence() { std::atomic_thread_fence(std::memory_order_seq_cst); }
 static inline void __threadfence_block() {}
+static inline void __builtin_amdgcn_s_setprio(int) {}
 static inline void __builtin_amdgcn_s_sleep(int) { usleep(50); }   /* a spinning workgroup waits for one that runs on another host thread */
 static inline unsigned long long wall_clock64() { return 0; }
 
