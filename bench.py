@@ -147,6 +147,7 @@ def main():
     ap.add_argument("--no-host", action="store_true", help="skip the host-to-host leg (value_host)")
     ap.add_argument("--no-isolated", action="store_true", help="skip the extra single-stream pass (profiling runs)")
     ap.add_argument("--no-decode", action="store_true", help="skip the inverse-path leg (decode)")
+    ap.add_argument("--no-seq", action="store_true", help="skip the -u / --sequential leg")
     args = ap.parse_args()
 
     import torch
@@ -299,6 +300,33 @@ def main():
                           "per block (prefix codes + inverse MTF, counting sort, list ranking walk, CRC), then inverse RLE1 into place"}
         del back
 
+    sequential = None
+    if rank == 0 and not args.no_seq and world == 1 and not strong:
+        # the reference's -u blocking of the same input, checked against its own fixture
+        with lib.context(args.level, slabs, 0, local) as cs:
+            cs.set_sequential(True)
+            best = None
+            for _ in range(2):
+                torch.cuda.synchronize()
+                tq = time.perf_counter()
+                mq = cs.compress_device(src.data_ptr(), n, dst.data_ptr(), dst.numel())
+                torch.cuda.synchronize()
+                dt = time.perf_counter() - tq
+                best = dt if best is None or dt < best else best
+            sq = cs.stats()
+        okq = None
+        try:
+            recs = json.load(open(os.path.join(ROOT, "tests", "golden", "seq_fixtures.json")))["records"]
+            rec = [r for r in recs if (r["kind"], r["n"], r["seed"], r["level"]) == (args.kind, args.bytes, seed, args.level)]
+            if rec and not args.no_verify:
+                zq = dst[:mq].cpu().numpy().tobytes()
+                okq = mq == rec[0]["out_len"] and hashlib.md5(zq).hexdigest() == rec[0]["ref_md5"]
+        except (OSError, ValueError, KeyError):
+            okq = None
+        sequential = {"value": round(n / best / 1e6, 1), "unit": "MB/s", "ms_total": round(best * 1e3, 2), "out_bytes": mq,
+                      "blocks": sq.nblocks, "verified": okq, "ms_block_chain": round(sq.ms_collect, 2),
+                      "what": "lbzip2 -u blocking (blocks cut where they are full): the blocks' first pass is a chain on the device"}
+
     if rank == 0:
         nchunks = (nslabs + slabs - 1) // slabs
         nslots = ctx.nslots
@@ -372,6 +400,8 @@ def main():
             res["value_host"] = value_host
         if decode:
             res["decode"] = decode
+        if sequential:
+            res["sequential"] = sequential
         if not args.no_cpu:
             res["cpu_baseline"] = cpu_baseline(full, args.level)
         print(json.dumps(res), flush=True)

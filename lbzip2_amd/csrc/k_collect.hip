@@ -293,7 +293,7 @@ k_collect(const u8 *in, u64 in_len, lbz_layout L, u8 *Tbase, lbz_block_meta *met
 }
 
 
-/* The part of a block that cannot contain its end, in 64 KB steps with one scan and one sum each: the same run
+/* The part of a block that cannot contain its end, in steps of 64 bytes per thread with one scan and one sum each: the same run
  * starts and emitted-byte counts as collect_pass, totals only.  Leaves the state collect_pass resumes from (tile,
  * bytes so far, run start carried) at the first step the block might fill in.                              */
 #define SKIP_IPT 64u

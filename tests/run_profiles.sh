@@ -9,7 +9,7 @@ OUT=$PWD/gpurun_out
 mkdir -p $OUT/prof_$TAG
 export TMPDIR=/tmp
 KIND=wiki; for a in $ARGS; do case $a in text|rand|mixed|tar|wiki) KIND=$a;; esac; done
-B="python $PWD/bench.py --steps 2 --warmup 1 --no-cpu --no-isolated --no-host --no-verify --no-decode $ARGS"
+B="python $PWD/bench.py --steps 2 --warmup 1 --no-cpu --no-isolated --no-host --no-verify --no-decode --no-seq $ARGS"
 ( cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_$TAG/stats -- $B > $OUT/${TAG}_rocprof_bench.json.log 2>&1 )
 ( cd /tmp && timeout 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/prof_$TAG/pmc_fetch -- $B > /dev/null 2>&1 )
 ( cd /tmp && timeout 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/prof_$TAG/pmc_write -- $B > /dev/null 2>&1 )
