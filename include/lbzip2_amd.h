@@ -50,15 +50,16 @@ size_t encoder_alloc_size(unsigned long mbs);
 void   encoder_init(struct encoder_state *e, unsigned long mbs, unsigned cf);
 /* Consumes a prefix of buf[0..*buf_sz) into the block (RLE1 + CRC); *buf_sz = bytes left
  * unconsumed.  Returns 1 if the block filled up before the input ran out.
- * RESTRICTIONS of this implementation (the call pattern of compress.c's default mode, :73-118, is
- * what it serves; lbzip2's -u/--sequential mode, compress.c:129-198, re-enters collect() and is served by the
- * batch interface only -- lbzamd_set_sequential() below):
- *   - ONE collect() per encoder state, on at most max_block_size bytes (more is left unconsumed:
- *     the caller re-queues it as the slab's next work unit, compress.c:98-104);
- *   - a second collect() on the same state, or encode() on a state that never collected a byte,
- *     is a fatal error (message on stderr + abort(), the reference's convention for fatal errors);
- *   - the return value is `consumed < offered`, which equals the reference's "block full"
- *     (encode.c:335) whenever input is left over -- the only case compress.c acts on.         */
+ * How this implementation serves the two call patterns of compress.c:
+ *   - default mode (:73-118): ONE collect() per state on at most max_block_size bytes; the calls of all worker
+ *     threads are batched into rounds on the device.  What does not fit is left unconsumed and the return value is
+ *     1 ("block full", encode.c:335): the caller re-queues it as the slab's next work unit (compress.c:98-104);
+ *   - -u / --sequential (:129-198): collect() called AGAIN on a state that already holds bytes appends to its
+ *     block: the block's raw bytes move to a device buffer of their own and the block is tokenised again from its
+ *     start with the new input behind it; the return value is 1 once input is left over.  One such call at a time
+ *     (the reference holds a token around it); a call on a full block takes nothing and returns 1;
+ *   - encode() on a state that never collected a byte is a fatal error (message on stderr + abort(), the
+ *     reference's convention for fatal errors).                                                          */
 int    collect(struct encoder_state *e, const uint8_t *buf, size_t *buf_sz);
 /* Runs BWT, MTF/ZRLE and prefix-code selection; returns the exact compressed size in bytes
  * and the block's un-inverted CRC through *crc.                                          */

@@ -394,6 +394,29 @@ class Decoder:
         return s
 
 
+def compress_workunits_seq(library, data, level=9):
+    """bytes -> .bz2 bytes through the drop-in symbols, called as the reference's -u mode calls them
+    (compress.c:129-198 do_collect_seq): ONE encoder keeps collecting slab after slab until its block is full."""
+    M = level * 100000
+    out = bytearray(b"BZh" + bytes([0x30 + level]))
+    combined = 0
+    slabs = [data[off:off + M] for off in range(0, len(data), M)]
+    k, pos = 0, 0                       # current slab, position inside it
+    while k < len(slabs):
+        enc = library.encoder(M)
+        full = False
+        while not full and k < len(slabs):
+            took, full = enc.collect_full(slabs[k][pos:])
+            pos += took
+            if pos == len(slabs[k]):
+                k, pos = k + 1, 0
+        size, crc = enc.encode()
+        out += enc.transmit()[:size]
+        combined = combine_crc(combined, crc)
+    out += bytes([0x17, 0x72, 0x45, 0x38, 0x50, 0x90]) + combined.to_bytes(4, "big")
+    return bytes(out)
+
+
 class Encoder:
     """The reference's work unit (encode.h:27-33): caller-allocated opaque state."""
 
@@ -406,10 +429,15 @@ class Encoder:
 
     def collect(self, buf):
         """Returns the number of bytes consumed from buf."""
+        return self.collect_full(buf)[0]
+
+    def collect_full(self, buf):
+        """(bytes consumed, the reference's return value: block full).  May be called again on the same state
+        with further input until the block is full (compress.c:160-170, the -u mode)."""
         left = C.c_size_t(len(buf))
-        b = (C.c_char * len(buf)).from_buffer_copy(buf)
-        self.L.lib.collect(self.state, b, C.byref(left))
-        return len(buf) - left.value
+        b = (C.c_char * max(1, len(buf))).from_buffer_copy(bytes(buf) or b"\0")
+        full = self.L.lib.collect(self.state, b, C.byref(left))
+        return len(buf) - left.value, bool(full)
 
     def encode(self):
         crc = C.c_uint32()

@@ -399,7 +399,7 @@ __device__ void seq_skip(const u8 *x, u32 base, u32 end, u32 cap, collect_lds *S
  * starts[b] = (input position of block b) + 1, 0 = not known yet; starts[0] comes from the host.            */
 __global__ void __launch_bounds__(LBZ_WG, 4)
 k_collect_seq(const u8 *in, u64 in_len, lbz_layout L, u8 *Tbase, lbz_block_meta *meta, u32 nblk,
-              unsigned long long *starts, u32 *ticket, lbz_seq_out *so)
+              unsigned long long *starts, u32 *ticket, lbz_seq_out *so, u32 slot0)
 {
   __shared__ collect_lds S;
   __shared__ unsigned long long s_start;
@@ -424,7 +424,8 @@ k_collect_seq(const u8 *in, u64 in_len, lbz_layout L, u8 *Tbase, lbz_block_meta 
     s_start = v;
   }
   __syncthreads();
-  lbz_block_meta *m = &meta[2u * b], *m2 = &meta[2u * b + 1u];
+  const u32 slot = slot0 + b;                                     /* block b of the chain lives in slab slot slot0 + b */
+  lbz_block_meta *m = &meta[2u * slot], *m2 = &meta[2u * slot + 1u];
   if (tid == 0) { m2->n = 0; m2->consumed = 0; m2->out_len = 0; m2->err = 0; m2->nmtf = 0; }
   if (s_start == 0ull) {                                         /* the chain broke */
     if (tid == 0) { so->err = 1u; m->n = 0; m->consumed = 0; m->out_len = 0; m->err = 1u; m->nmtf = 0; __atomic_store_n(&starts[b + 1u], 0ull, __ATOMIC_RELEASE); }
@@ -458,7 +459,7 @@ k_collect_seq(const u8 *in, u64 in_len, lbz_layout L, u8 *Tbase, lbz_block_meta 
   }
   __builtin_amdgcn_s_setprio(0);
   __syncthreads();
-  collect_pass<true>(x, mis, stop, L.M, Tbase + lbz_elem_off(L, 2u * b), &S);      /* off the chain: bytes, used-byte map, CRC */
+  collect_pass<true>(x, mis, stop, L.M, Tbase + lbz_elem_off(L, 2u * slot), &S);      /* off the chain: bytes, used-byte map, CRC */
   const u32 nblock = S.bc[0];
   __syncthreads();
   const u32 crc = wg_crc32(x, mis, stop, end, &S);

@@ -387,7 +387,7 @@ static int compress_device(lbzamd_ctx *c, const void *d_in_v, size_t len, void *
       HIPCHK(hipMemcpyAsync(c->seq_starts, &start0, sizeof start0, hipMemcpyHostToDevice, s));
       HIPCHK(hipEventRecord(c->ev[4], s));
       if (len) hipLaunchKernelGGL(k_collect_seq, dim3(c->max_slabs), dim3(LBZ_COLLECT_WG), 0, s, d_in, (u64)len, c->L, c->T, c->meta,
-                                  (u32)c->max_slabs, c->seq_starts, c->seq_ticket, c->seq_out);
+                                  (u32)c->max_slabs, c->seq_starts, c->seq_ticket, c->seq_out, 0u);
       HIPCHK(hipEventRecord(c->ev[5], s));
       lbz_seq_out so{};
       if (len) {
@@ -845,7 +845,10 @@ struct encoder_state {
   uint32_t collected;
   wu_pool *pool;              /* set while the state holds a slab */
   uint32_t slab;
-  uint32_t pad_[7];
+  uint32_t seq_cap;           /* re-entered collect() (the reference's -u mode): the block's raw bytes so far live in */
+  u8 *seq_dev;                /* a device buffer of their own, seq_cap bytes                                         */
+  uint32_t seq_full;          /* the block is full: further collect() calls take nothing */
+  uint32_t pad_[3];
 };
 #define ENC_MAGIC 0x6c627a41u
 
@@ -880,6 +883,13 @@ struct wu_pool {
   std::mutex mu;
   std::condition_variable cv;
   std::vector<uint32_t> free_slabs;
+  /* re-entered collect(): one at a time (the reference holds a token, compress.c:62,143), own stream and scratch */
+  std::mutex seq_mu;
+  hipStream_t seq_q = nullptr;
+  unsigned long long *seq_starts = nullptr;
+  u32 *seq_ticket = nullptr;
+  lbz_seq_out *seq_out = nullptr;
+  std::vector<std::pair<u8 *, uint32_t>> seq_free;     /* buffers of finished blocks, kept for the next ones */
 };
 
 static std::mutex g_pools_mu;
@@ -907,6 +917,10 @@ static wu_pool *pool_for(unsigned bs100k)
   HIPDIE(hipHostMalloc((void **)&p->h_in, (size_t)p->P * c->L.M, hipHostMallocDefault), "pool");
   HIPDIE(hipHostMalloc((void **)&p->h_out, (size_t)p->P * c->L.out_a, hipHostMallocDefault), "pool");
   for (uint32_t i = p->P; i-- > 0;) p->free_slabs.push_back(i);
+  HIPDIE(hipStreamCreateWithFlags(&p->seq_q, hipStreamNonBlocking), "pool");
+  HIPDIE(hipMalloc((void **)&p->seq_starts, 4u * sizeof(unsigned long long)), "pool");
+  HIPDIE(hipMalloc((void **)&p->seq_ticket, sizeof(u32)), "pool");
+  HIPDIE(hipMalloc((void **)&p->seq_out, sizeof(lbz_seq_out)), "pool");
   g_pools[bs100k] = p;
   return p;
 }
@@ -1013,10 +1027,62 @@ extern "C" void lbzamd_encoder_init(encoder_state *e, unsigned long mbs, unsigne
   e->magic = ENC_MAGIC; e->mbs = (uint32_t)mbs; e->cf = cf;
 }
 
+/* collect() called again on a state that holds bytes already (compress.c:160-170, the -u mode: one encoder keeps
+ * collecting slab after slab until its block is full).  The block's raw bytes so far move to a device buffer of
+ * their own, the new ones are appended, and the block is tokenised again from its start (k_collect_seq with a chain
+ * of one): how much of the new input fits is the cut position minus what was there before.  The reference allows
+ * one such caller at a time (its collect token); so does this. */
+static int collect_again(encoder_state *e, const uint8_t *buf, size_t *buf_sz)
+{
+  wu_pool *p = e->pool;
+  lbzamd_ctx *c = p->c;
+  if (e->seq_full || *buf_sz == 0) return e->seq_full ? 1 : 0;
+  std::lock_guard<std::mutex> lk(p->seq_mu);
+  HIPDIE(hipSetDevice(c->device), "collect");
+  const uint32_t have = e->collected;
+  const size_t room = (size_t)e->mbs * 52u + 4096u;              /* a block never takes more raw bytes than this */
+  const size_t len = *buf_sz < room ? *buf_sz : room;
+  const size_t need = (size_t)have + len + 64u;
+  if (!e->seq_dev || e->seq_cap < need) {
+    u8 *nb = nullptr;
+    uint32_t ncap = 0;
+    for (size_t i = 0; i < p->seq_free.size(); i++)
+      if (p->seq_free[i].second >= need) { nb = p->seq_free[i].first; ncap = p->seq_free[i].second; p->seq_free.erase(p->seq_free.begin() + (long)i); break; }
+    if (!nb) {
+      size_t want = (size_t)e->mbs * 5u / 2u + 4096u;
+      while (want < need) want *= 2u;
+      HIPDIE(hipMalloc((void **)&nb, want), "collect");
+      ncap = (uint32_t)want;
+    }
+    const u8 *old = e->seq_dev ? e->seq_dev : c->d_in + (size_t)e->slab * c->L.M;
+    if (have) HIPDIE(hipMemcpyAsync(nb, old, have, hipMemcpyDeviceToDevice, p->seq_q), "collect");
+    if (e->seq_dev) { HIPDIE(hipStreamSynchronize(p->seq_q), "collect"); p->seq_free.push_back({ e->seq_dev, e->seq_cap }); }
+    e->seq_dev = nb; e->seq_cap = ncap;
+  }
+  HIPDIE(hipMemcpyAsync(e->seq_dev + have, buf, len, hipMemcpyHostToDevice, p->seq_q), "collect");
+  const unsigned long long start0 = 1ull;
+  HIPDIE(hipMemsetAsync(p->seq_starts, 0, 4u * sizeof(unsigned long long), p->seq_q), "collect");
+  HIPDIE(hipMemsetAsync(p->seq_ticket, 0, sizeof(u32), p->seq_q), "collect");
+  HIPDIE(hipMemsetAsync(p->seq_out, 0, sizeof(lbz_seq_out), p->seq_q), "collect");
+  HIPDIE(hipMemcpyAsync(p->seq_starts, &start0, sizeof start0, hipMemcpyHostToDevice, p->seq_q), "collect");
+  hipLaunchKernelGGL(k_collect_seq, dim3(1), dim3(LBZ_COLLECT_WG), 0, p->seq_q, (const u8 *)e->seq_dev, (u64)(have + len), c->L, c->T, c->meta,
+                     1u, p->seq_starts, p->seq_ticket, p->seq_out, e->slab);
+  lbz_seq_out so{};
+  HIPDIE(hipMemcpyAsync(&so, p->seq_out, sizeof so, hipMemcpyDeviceToHost, p->seq_q), "collect");
+  HIPDIE(hipStreamSynchronize(p->seq_q), "collect");
+  HIPDIE(hipGetLastError(), "collect");
+  if (so.err || so.next < have) { g_err = "device error while re-entering collect()"; die("collect"); }
+  const size_t took = (size_t)so.next - have;
+  e->collected = (uint32_t)so.next;
+  *buf_sz -= took;
+  if (took < len) e->seq_full = 1;                              /* input left over: the block is full (encode.c:335) */
+  return e->seq_full ? 1 : 0;
+}
+
 extern "C" int lbzamd_collect(encoder_state *e, const uint8_t *buf, size_t *buf_sz)
 {
   if (!e || e->magic != ENC_MAGIC || !buf || !buf_sz) { g_err = "bad encoder state"; die("collect"); }
-  if (e->pool) { g_err = "collect() called twice on one state (only the default, non -u mode is supported)"; die("collect"); }
+  if (e->pool) return collect_again(e, buf, buf_sz);
   const size_t avail = *buf_sz < e->mbs ? *buf_sz : e->mbs;
   if (avail == 0) return 0;
   wu_pool *p = pool_for(e->mbs / 100000u);
@@ -1032,6 +1098,7 @@ extern "C" int lbzamd_collect(encoder_state *e, const uint8_t *buf, size_t *buf_
   pool_submit(p, &r);
   e->collected = r.consumed;
   *buf_sz -= r.consumed;
+  if (r.consumed < avail) e->seq_full = 1;                      /* input left over: the block is full */
   return r.consumed < avail;
 }
 
@@ -1051,6 +1118,12 @@ extern "C" size_t lbzamd_encode(encoder_state *e, uint32_t *crc)
 static void pool_release(encoder_state *e)
 {
   wu_pool *p = e->pool;
+  if (e->seq_dev) {
+    std::lock_guard<std::mutex> lk(p->seq_mu);
+    if (p->seq_free.size() < 64u) p->seq_free.push_back({ e->seq_dev, e->seq_cap });
+    else (void)hipFree(e->seq_dev);
+    e->seq_dev = nullptr; e->seq_cap = 0;
+  }
   {
     std::lock_guard<std::mutex> lk(p->mu);
     p->free_slabs.push_back(e->slab);

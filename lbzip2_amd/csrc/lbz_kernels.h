@@ -46,7 +46,7 @@ struct lbz_seq_out {
   u32 err;
 };
 __global__ void k_collect_seq(const u8 *in, u64 in_len, lbz_layout L, u8 *Tbase, lbz_block_meta *meta, u32 nblk,
-                              unsigned long long *starts, u32 *ticket, lbz_seq_out *so);
+                              unsigned long long *starts, u32 *ticket, lbz_seq_out *so, u32 slot0);
 __global__ void k_bwt_part(const u8 *Tbase, lbz_block_meta *meta, lbz_layout L, u32 first, u32 count,
                            u8 *ws, u64 slot_bytes, u8 *ws_spill, u64 spill_bytes, const u32 *slabs);
 __global__ void k_bwt_part2(const u8 *Tbase, lbz_block_meta *meta, lbz_layout L, u32 first, u32 count,

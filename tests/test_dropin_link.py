@@ -58,6 +58,22 @@ def test_unmodified_reference_cli_drives_the_library(programs, level, workers, k
     assert _run(stock, ["-d"], got) == data                      # and the reference's decompressor takes it
 
 
+@pytest.mark.parametrize("level,workers,kind,n,seed", [(1, 1, "wiki", 350000, 7), (1, 3, "runs", 450000, 7), (1, 2, "rand", 250000, 7)])
+def test_reference_cli_sequential_mode(programs, level, workers, kind, n, seed):
+    """lbzip2 -u: compress.c:129-198 re-enters collect() on one encoder until its block is full; the drop-in
+    collect() serves that too (the block is re-tokenised from its start with the appended input)"""
+    import json
+    stock, dropin = programs
+    data = bytes(gen(kind, n, seed))
+    args = ["-u", f"-{level}", "-n", str(workers)]
+    want = _run(stock, args, data)
+    got = _run(dropin, args, data, env={"LBZAMD_POOL_SLABS": "8", "LBZ_EMU_THREADS": "2"})
+    assert got == want
+    recs = json.load(open(os.path.join(ROOT, "tests", "golden", "seq_fixtures.json")))["records"]
+    rec = [r for r in recs if (r["kind"], r["n"], r["seed"], r["level"]) == (kind, n, seed, level)]
+    assert rec and hashlib.md5(got).hexdigest() == rec[0]["ref_md5"]
+
+
 def test_empty_input_through_the_cli(programs):
     stock, dropin = programs
     assert _run(dropin, ["-9"], b"", env={"LBZAMD_POOL_SLABS": "2"}) == _run(stock, ["-9"], b"")
@@ -73,4 +89,18 @@ def test_reference_cli_on_the_gpu():
     rec = [r for r in bench_fixtures() if r["kind"] == "wiki" and r["n"] == 100_000_000][0]
     data = bytes(gen(rec["kind"], rec["n"], rec["seed"]))
     out = _run(exe, ["-9", "-n", "64"], data, timeout=300)
+    assert len(out) == rec["out_len"] and hashlib.md5(out).hexdigest() == rec["ref_md5"]
+
+
+@pytest.mark.gpu
+def test_reference_cli_sequential_mode_on_the_gpu():
+    """the same program with -u: the stream of tests/golden/seq_fixtures.json (tar-like, 5 * 10^7 bytes, -9)"""
+    import json
+    exe = os.path.join(REFDIR, "lbzip2_dropin_gpu")
+    if not os.path.exists(exe):
+        pytest.skip("oracle/_ref/lbzip2_dropin_gpu not built (needs the reference sources at build time)")
+    import oracle_lib as L
+    rec = [r for r in json.load(open(os.path.join(ROOT, "tests", "golden", "seq_fixtures.json")))["records"] if r["kind"] == "tar"][0]
+    data = bytes(L.gen_kind(rec["kind"], rec["n"], rec["seed"]))
+    out = _run(exe, ["-u", "-%d" % rec["level"], "-n", "16"], data, timeout=300)
     assert len(out) == rec["out_len"] and hashlib.md5(out).hexdigest() == rec["ref_md5"]

@@ -64,6 +64,25 @@ def test_edges_under_the_emulator(emu):
         assert ctx.compress(b"x" * 1000) == L.orc_compress(b"x" * 1000, 1)
 
 
+def test_drop_in_symbols_called_as_the_u_mode_calls_them(emu):
+    """collect() re-entered on one state until the block is full (compress.c:160-170), then encode / transmit"""
+    from lbzip2_amd._binding import compress_workunits_seq
+    for kind, n in (("wiki", 350000), ("runs", 450000), ("zeros", 700000), ("one", 1), ("empty", 0)):
+        d = bytes(gen(kind, n, 7)) if kind in ("wiki", "runs") else (bytes(n) if kind == "zeros" else b"a" * n)
+        assert compress_workunits_seq(emu, d, 1) == L.orc_compress_seq(d, 1), kind
+    assert emu.compress_workunits(bytes(gen("wiki", 250000, 3)), 1) == L.orc_compress(bytes(gen("wiki", 250000, 3)), 1)
+
+
+@pytest.mark.gpu
+def test_drop_in_symbols_u_mode_on_the_gpu():
+    import lbzip2_amd
+    from lbzip2_amd._binding import compress_workunits_seq
+    rec = [r for r in FIX if r["kind"] == "runs" and r["n"] == 20_000_000][0]
+    d = bytes(gen("runs", rec["n"], rec["seed"]))
+    z = compress_workunits_seq(lbzip2_amd.library(), d, rec["level"])
+    assert len(z) == rec["out_len"] and hashlib.md5(z).hexdigest() == rec["ref_md5"]
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("rec", FIX, ids=lambda r: f"{r['kind']}-{r['n']}-{r['level']}")
 def test_fixtures_on_the_gpu(rec):
