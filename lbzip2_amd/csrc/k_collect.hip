@@ -419,7 +419,7 @@ k_collect_seq(const u8 *in, u64 in_len, lbz_layout L, u8 *Tbase, lbz_block_meta 
     for (u32 spins = 0; spins < (1u << 26); spins++) {          /* bounded: a lost predecessor must not hang the device */
       v = __atomic_load_n(&starts[b], __ATOMIC_RELAXED);
       if (v) break;
-      __builtin_amdgcn_s_sleep(1);
+      __builtin_amdgcn_s_sleep(8);
     }
     __atomic_thread_fence(__ATOMIC_ACQUIRE);
     s_start = v;
