@@ -139,6 +139,13 @@ int  lbzamd_compress_host(lbzamd_ctx *ctx, const uint8_t *in, size_t len,
  * H2D/D2H of pinned memory run at link rate and overlap with kernels. */
 void *lbzamd_pinned_alloc(size_t bytes);
 void  lbzamd_pinned_free(void *p);
+/* HIP devices of this process (0 if none).  A host program drives several GPUs the way the reference drives its
+ * workers (process.c:515-548): one context per device (lbzamd_create's `device`), slab ranges dealt over them, the
+ * ranges muxed in order (lbzamd_compress_*_body + lbzamd_fold_parts); pinned buffers are usable from every device.
+ * The drop-in symbols do the same behind the caller's back: LBZAMD_DEVICES=N (default 1, "all" = every device) keeps
+ * one work-unit pool per device and leases the states' slabs round-robin over them, so the reference's unmodified
+ * splitter/muxer (process.c) feeds N GPUs.                                                                       */
+int   lbzamd_device_count(void);
 /* Upper bound of the stream size for len input bytes. */
 size_t lbzamd_bound(size_t len);
 int  lbzamd_get_stats(lbzamd_ctx *ctx, lbzamd_stats *st);

@@ -22,7 +22,7 @@ EXPORTS = [
     "lbzamd_compress_host", "lbzamd_bound", "lbzamd_get_stats", "lbzamd_stream", "lbzamd_slots", "lbzamd_set_sequential",
     "lbzamd_block_slots", "lbzamd_block_info_get", "lbzamd_read_stage", "lbzamd_run_stages",
     "lbzamd_compress_device_body", "lbzamd_compress_host_body", "lbzamd_fold_parts",
-    "lbzamd_pinned_alloc", "lbzamd_pinned_free",
+    "lbzamd_pinned_alloc", "lbzamd_pinned_free", "lbzamd_device_count",
     "lbzamd_dcreate", "lbzamd_ddestroy", "lbzamd_decompress_device", "lbzamd_decompress_host", "lbzamd_dget_stats",
 ]
 

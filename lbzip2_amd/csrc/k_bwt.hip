@@ -80,6 +80,18 @@
 #define SA_IDX(v) ((v) & 0x000FFFFFu)
 #define SA_CODE(v) (((v) >> 20) & 255u)
 #define SA_ENTRY(idx, code) ((idx) | ((u32)(code) << 20))
+/* a rank entry: the rotation's rank now, its rank before the launch that wrote the entry, and that launch's tag
+   (0 = k_bwt_batch / k_bwt_fix0, r + 1 = deep-tie round r).  A round reads ranks of rotations whose runs other
+   workgroups of the same launch are splitting; mixing ranks from before and after a split of ONE run would order
+   two rows wrongly (an old rank is only a lower bound of the new one).  With both values in one 8-byte word -- one
+   store, one gather, the same 64-byte transaction as a 4-byte rank -- a reader always takes the rank as it stood when
+   the launch began, whenever the word was written.                                                           */
+#define ISA_ENTRY(cur, prev, tag) ((u64)(cur) | ((u64)(prev) << 20) | ((u64)(tag) << 40))
+#define ISA_CUR(e) ((u32)(e) & 0x000FFFFFu)
+__device__ __forceinline__ u32 isa_before(u64 e, u32 tag)      /* the rank as of the start of the launch with this tag */
+{
+  return (u32)(e >> 40) == tag ? (u32)(e >> 20) & 0x000FFFFFu : (u32)e & 0x000FFFFFu;
+}
 static_assert(BATCH_CAP == LBZ_WG * 4u, "a batch is one 4-rows-per-thread tile");
 
 struct sort_lds {                       /* HBM radix passes (partition, oversized groups, doubling) */
@@ -104,12 +116,12 @@ struct batch_lds {                      /* one batch resident in LDS */
   u16 cstart[BATCH_CAP / 64u + 2u];     /* first row of the chunk that belongs to each claim window */
   u8 corder[BATCH_CAP / 64u + 2u];      /* chunks, longest first */
   u16 ctied[BATCH_CAP / 64u + 2u];      /* doubling: rows of each chunk that stay tied */
-  u32 oldhead[BATCH_CAP / 32u];         /* doubling: bit j = list position j was the first row of a run when the round began */
 };
 struct bwt_lds {
   wg_scratch sc;
   u32 bc[16];
   u32 isa_from, tied0;                /* k_bwt_batch: rows from isa_from on get their rank written with them; tied0 = rows tied on their first key so far */
+  u32 budget, pad_;                   /* k_bwt_batch: tied-row rounds this segment may spend on in-LDS refinement */
   u32 dbg[4];                         /* LDS_SORT_TICKS: whole-workgroup batch sorts (count, ticks), oversized groups (count, ticks) */
   u8 cmap[256];                       /* byte -> dense code */
   u8 inv[256];                        /* dense code -> byte */
@@ -121,7 +133,8 @@ struct bwt_lds {
 
 struct bwt_slot {
   u64 *k0, *k1;
-  u32 *v0, *v1, *sufx, *grp, *pos, *sa, *isa;
+  u32 *v0, *v1, *sufx, *grp, *pos, *sa;
+  u64 *isa;
 };
 
 struct keycfg {
@@ -142,14 +155,13 @@ __device__ __forceinline__ bwt_slot slot_carve(u8 *ws, u32 cap)
   s.grp = (u32 *)p; p += (size_t)cap * 4u;
   s.pos = (u32 *)p; p += (size_t)cap * 4u;
   s.sa = (u32 *)p; p += (size_t)cap * 4u;
-  s.isa = (u32 *)p;
+  s.isa = (u64 *)p;
   return s;
 }
 
 /* workspace of this workgroup in a round of `count` slabs (lbz_kernels.h) */
-__device__ __forceinline__ bwt_slot round_slot(u8 *ws, u64 slot_bytes, u8 *ws_spill, u64 spill_bytes, u32 count, lbz_layout L)
+__device__ __forceinline__ bwt_slot round_slot(u8 *ws, u64 slot_bytes, u8 *ws_spill, u64 spill_bytes, u32 count, lbz_layout L, u32 i)
 {
-  const u32 i = blockIdx.x;
   return i < count ? slot_carve(ws + (u64)i * slot_bytes, L.cap_a)
                    : slot_carve(ws_spill + (u64)(i - count) * spill_bytes, L.cap_b);
 }
@@ -239,7 +251,8 @@ __device__ u32 wg_radix_sort(u64 *k0, u32 *v0, u64 *k1, u32 *v1, u32 m, u32 nbit
  * the number of still-tied entries.                                                       */
 template <bool FLAGS>
 __device__ u32 wg_regroup(const u64 *key, const u32 *val, u32 rowbase, u32 out_base, u32 m,
-                          bwt_slot s, bwt_lds *S, const u8 *T, u32 n, u8 *bwt, u32 isa_below = 0xFFFFFFFFu)
+                          bwt_slot s, bwt_lds *S, const u8 *T, u32 n, u8 *bwt, u32 isa_below = 0xFFFFFFFFu,
+                          u32 oldrank = 0u, u32 tag = 0u)          /* !FLAGS: the run's rank so far and the round's tag */
 {
   const u32 tid = threadIdx.x;
   u32 carry_rank = 0, carry_cnt = out_base;
@@ -301,7 +314,8 @@ __device__ u32 wg_regroup(const u64 *key, const u32 *val, u32 rowbase, u32 out_b
       if (k < m) {
         if ((headmask >> i) & 1u) rank1 = row[i] + 1u;
         if (!FLAGS) s.sa[row[i]] = vv[i];
-        if (row[i] < isa_below) s.isa[SA_IDX(vv[i])] = rank1 - 1u;       /* rows from isa_below on got their rank in k_bwt_batch */
+        if (row[i] < isa_below)                                          /* rows from isa_below on got their rank in k_bwt_batch */
+          s.isa[SA_IDX(vv[i])] = FLAGS ? ISA_ENTRY(rank1 - 1u, rank1 - 1u, 0u) : ISA_ENTRY(rank1 - 1u, oldrank, tag);
         if ((actmask >> i) & 1u) {
           s.sufx[o] = vv[i];
           s.grp[o] = rank1 - 1u;
@@ -819,7 +833,7 @@ __device__ u32 wave_runs(batch_lds *B, u32 cs, u32 ce, u32 sh = 0u)
  * already are), refine runs of equal keys with further symbols of the text, emit.  No workgroup
  * barrier inside: the 16 waves of a batch run their chunks independently.                   */
 __device__ void wave_finish_chunk(batch_lds *B, u32 cs, u32 ce, bool need_sort, const u8 *T, u32 n, keycfg c,
-                                  u8 *bwt, u32 *sa, u32 *isa, u32 lo, lbz_block_meta *meta, bwt_lds *S)   /* isa == nullptr: ranks not wanted yet */
+                                  u8 *bwt, u32 *sa, u64 *isa, u32 lo, lbz_block_meta *meta, bwt_lds *S)   /* isa == nullptr: ranks not wanted yet */
 {
   const u32 lane = lane_id();
   u32 ntied;
@@ -854,7 +868,7 @@ __device__ void wave_finish_chunk(batch_lds *B, u32 cs, u32 ce, bool need_sort, 
   for (u32 r = 0; r < REFINE_ROUNDS && ntied && before && !isa; r++) {
     /* block-wide budget of tied-row rounds: a block that has burnt n/8 of them is a repetitive
        one that will need the doubling anyway -- stop refining its remaining chunks */
-    if ((u32)__builtin_amdgcn_readfirstlane((int)S->bc[9]) > n / REFINE_BUDGET_DIV) break;
+    if ((u32)__builtin_amdgcn_readfirstlane((int)S->bc[9]) > S->budget) break;
     if (lane == 0u) atomicAdd(&S->bc[9], ntied);
     /* every tied rotation trades its key for its next sy symbols; its run is re-sorted on them
        (counting for short runs, a per-run radix sort otherwise) and split where they differ */
@@ -881,7 +895,7 @@ __device__ void wave_finish_chunk(batch_lds *B, u32 cs, u32 ce, bool need_sort, 
        instead of being a pass of their own in a kernel that is bound by scattered HBM traffic.  Only once
        the block has shown that it will need k_bwt_fix (batch_process decides): text whose ties are
        shallow never pays for it.                                                                   */
-    if (isa) isa[idx] = lo + (u32)B->gh[j];
+    if (isa) { const u32 rk = lo + (u32)B->gh[j]; isa[idx] = ISA_ENTRY(rk, rk, 0u); }
     if (idx == 0u) meta->bwt_idx = lo + j;
   }
   if (ntied && lane == 0u) S->bc[8] = 1u;
@@ -1051,7 +1065,7 @@ __device__ void emit_tied_rows(u8 *bwt, bwt_slot s, bwt_lds *S, u32 lo, u32 hi)
     const u32 v = s.v0[j];
     bwt[j] = S->inv[v >> 24];
     s.sa[j] = SA_ENTRY(v & 0x00FFFFFFu, v >> 24) | (j > lo ? TIE_FLAG : 0u);
-    s.isa[v & 0x00FFFFFFu] = lo;
+    s.isa[v & 0x00FFFFFFu] = ISA_ENTRY(lo, lo, 0u);
   }
   if (threadIdx.x == 0) S->bc[8] = 1u;
   __syncthreads();
@@ -1141,7 +1155,7 @@ __device__ void big_group(const u8 *T, u32 n, u8 *bwt, lbz_block_meta *meta, bwt
  * into LDS (the rank lookups are the only random HBM reads), each wave orders the runs of its
  * window, and rows leave the list as soon as they are unique.  A run longer than a batch goes
  * through the HBM radix sorter.                                                            */
-__device__ u32 doubling_round(const u8 *T, u32 n, u8 *bwt, bwt_slot s, bwt_lds *S, u32 h, u32 m)
+__device__ u32 doubling_round(const u8 *T, u32 n, u8 *bwt, bwt_slot s, bwt_lds *S, u32 h, u32 m, u32 tag)
 {
   batch_lds *B = &S->u.B;
   const u32 tid = threadIdx.x, lane = lane_id();
@@ -1159,12 +1173,12 @@ __device__ u32 doubling_round(const u8 *T, u32 n, u8 *bwt, bwt_slot s, bwt_lds *
           const u32 sf = s.sufx[k0 + i];
           u32 t = SA_IDX(sf) + h;
           if (t >= n) t -= n;
-          s.k0[i] = (u64)s.isa[t];
+          s.k0[i] = (u64)isa_before(s.isa[t], tag);
           s.v0[i] = sf;
         }
         __syncthreads();
         const u32 which = wg_radix_sort(s.k0, s.v0, s.k1, s.v1, g, RANK_BITS, S);
-        out_m = wg_regroup<false>(which ? s.k1 : s.k0, which ? s.v1 : s.v0, rowbase, out_m, g, s, S, T, n, bwt);
+        out_m = wg_regroup<false>(which ? s.k1 : s.k0, which ? s.v1 : s.v0, rowbase, out_m, g, s, S, T, n, bwt, 0xFFFFFFFFu, s.grp[k0], tag);
         k0 = end;
         continue;
       }
@@ -1177,7 +1191,7 @@ __device__ u32 doubling_round(const u8 *T, u32 n, u8 *bwt, bwt_slot s, bwt_lds *
       const u32 sf = s.sufx[k0 + i];
       u32 t = SA_IDX(sf) + h;
       if (t >= n) t -= n;
-      B->kA[i] = (u64)s.isa[t];
+      B->kA[i] = (u64)isa_before(s.isa[t], tag);
       B->vA[i] = sf;
       B->kB[i] = (u64)s.grp[k0 + i];
     }
@@ -1185,14 +1199,6 @@ __device__ u32 doubling_round(const u8 *T, u32 n, u8 *bwt, bwt_slot s, bwt_lds *
     const u64 td1 = wall_clock64();
     u32 maxrun;
     batch_runs(B, B->kB, cnt, 0u, &maxrun, S);            /* the runs as they stand */
-    /* remember the run heads: the first piece of a run that splits keeps the run's rank, so its rows need
-       no rank store (a third of the scattered stores of a block with deep ties) */
-    if (tid < BATCH_CAP / 32u) {
-      u32 bits = 0;
-#pragma unroll 8
-      for (u32 q = 0; q < 32u; q++) { const u32 j = tid * 32u + q; if (j < cnt && B->gh[j] == j) bits |= 1u << q; }
-      B->oldhead[tid] = bits;
-    }
     const u64 td2 = wall_clock64();
     /* sort phase: waves claim chunks, longest first (as in batch_process) */
     const u32 nwin = chunk_plan(B, cnt);
@@ -1208,6 +1214,7 @@ __device__ u32 doubling_round(const u8 *T, u32 n, u8 *bwt, bwt_slot s, bwt_lds *
         for (u32 j = cs + lane; j < ce; j += 64u) {
           const u32 gs = B->gh[j];
           B->kB[j] = (u64)(s.pos[k0 + gs] + (j - gs));
+          B->ghn[j] = (u16)gs;                  /* first position of the run as it stood: its row is the rank so far */
         }
         wave_sync();
         mytied = wave_runs<true>(B, cs, ce);
@@ -1234,8 +1241,10 @@ __device__ u32 doubling_round(const u8 *T, u32 n, u8 *bwt, bwt_slot s, bwt_lds *
           const u32 newrank = (u32)B->kB[B->gh[j]];
           /* the suffix array itself is not read again: ranks (isa) and the list carry the rounds, the
              BWT byte of a row that became unique is written below */
-          const u32 nh = B->gh[j];
-          if (!((B->oldhead[nh >> 5] >> (nh & 31u)) & 1u)) s.isa[SA_IDX(sf)] = newrank;
+          /* the first piece of a run that splits keeps the run's rank: no rank store for its rows (a third of the
+             scattered stores of a block with deep ties) */
+          const u32 oh = B->ghn[j];
+          if ((u32)B->gh[j] != oh) s.isa[SA_IDX(sf)] = ISA_ENTRY(newrank, (u32)B->kB[oh], tag);
           if (td) {
             const u32 o = off + (u32)__popcll(mask & lanes_below());
             s.sufx[o] = sf; s.grp[o] = newrank; s.pos[o] = row;
@@ -1255,34 +1264,6 @@ __device__ u32 doubling_round(const u8 *T, u32 n, u8 *bwt, bwt_slot s, bwt_lds *
     k0 = e;
   }
   return out_m;
-}
-
-__device__ void finish_by_doubling(const u8 *T, u32 n, u8 *bwt, lbz_block_meta *meta, bwt_slot s,
-                                   bwt_lds *S, u32 h0, u32 *rounds_out, u32 *work_out)
-{
-  const u32 tid = threadIdx.x;
-  const u64 tk0 = wall_clock64();
-  u32 m = wg_regroup<true>(nullptr, s.sa, 0u, 0u, n, s, S, T, n, nullptr, meta->isa_from);
-  if (tid == 0) { meta->fticks[6] = (u32)(wall_clock64() - tk0); meta->fticks[1] = m; }
-  u32 rounds = 0, work = 0;
-  for (u32 h = h0; m > 0u && h < n; h <<= 1) {
-    work += m;
-    m = doubling_round(T, n, bwt, s, S, h, m);
-    rounds++;
-  }
-  /* rows that are tied for good (exactly periodic block): their bytes are all equal anyway */
-  for (u32 k = tid; k < m; k += LBZ_WG) {
-    const u32 sf = s.sufx[k];
-    bwt[s.pos[k]] = S->inv[SA_CODE(sf)];
-  }
-  if (tid == 0) {
-    meta->bwt_idx = s.isa[0];
-    meta->periodic = m > 0u ? 1u : 0u;
-    meta->fticks[7] = (u32)(wall_clock64() - tk0);
-  }
-  *rounds_out = rounds;
-  *work_out = work;
-  __syncthreads();
 }
 
 /* dense symbol codes of the used bytes and the key geometry they allow (every kernel) */
@@ -1312,6 +1293,7 @@ struct part_lds {
   wg_scratch sc;
   u32 bc[16];
   u32 isa_from, tied0;
+  u32 budget, pad_;
   u32 dbg[4];
   u8 cmap[256];
   u8 inv[256];
@@ -1326,8 +1308,15 @@ __device__ __forceinline__ void part_block(bwt_lds &S, const u8 *Tbase, lbz_bloc
   const u32 tid = threadIdx.x;
   const u32 blk = lbz_round_block(first, count, blockIdx.x, slabs);
   const u32 n = meta[blk].n;
+  if (tid == 0) {                             /* the sorter's part of the block record: the segment workgroups add to it */
+    lbz_block_meta *M = &meta[blk];
+    M->periodic = 0; M->rounds = 0; M->sort_elems = 0; M->isa_from = 0; M->nseg = 0;
+    for (u32 i = 0; i < 8u; i++) M->ticks[i] = 0;
+    for (u32 i = 0; i < 16u; i++) M->fticks[i] = 0;
+    for (u32 i = 0; i < LBZ_BWT_SEGS; i++) M->seg_m[i] = 0;
+  }
   if (n <= BATCH_CAP) return;                 /* small blocks are sorted whole by k_bwt_batch */
-  const bwt_slot s = round_slot(ws, slot_bytes, ws_spill, spill_bytes, count, L);
+  const bwt_slot s = round_slot(ws, slot_bytes, ws_spill, spill_bytes, count, L, blockIdx.x);
   const u8 *T = Tbase + lbz_elem_off(L, blk);
   const u64 tk0 = wall_clock64();
   const keycfg c = bwt_setup(&meta[blk], &S);
@@ -1369,28 +1358,77 @@ k_bwt_part2(const u8 *Tbase, lbz_block_meta *meta, lbz_layout L, u32 first, u32 
   part_block(*reinterpret_cast<bwt_lds *>(&S_), Tbase, meta, L, first, count, ws, slot_bytes, ws_spill, spill_bytes, slabs);
 }
 
+/* ---- segments -------------------------------------------------------------------------------------------
+ * After the partition the rows of a block are grouped by their top MSD_BITS and the groups are independent of
+ * each other, so the rest of the sort does not need one workgroup per block: the rows are cut into up to
+ * LBZ_BWT_SEGS segments at group boundaries and every (block, segment) is a workgroup of its own -- in
+ * k_bwt_batch and in each launch of the deep-tie rounds.  Eight times as many, eight times shorter work items:
+ * a launch no longer ends on a device that is a fifth full (1112 blocks on 512 resident workgroups were three
+ * waves of workgroups, the last one 17 % full), an input of a hundred blocks fills the chip, and a block's
+ * chain of stages is short enough for the work-unit interface.  The segment workgroups of a block share its
+ * workspace slot; what they share beyond that is isa[]: see k_bwt_fixr.                                       */
+__device__ __forceinline__ u32 bwt_nseg(u32 n)
+{
+  const u32 p = n / (4u * BATCH_CAP);
+  return p < 1u ? 1u : (p > LBZ_BWT_SEGS ? LBZ_BWT_SEGS : p);
+}
+
+/* (block of the round, segment) of this workgroup.  Hardware deals workgroup j to XCD j mod 8: the segment
+ * workgroups of one block sit on ONE XCD (they share the block's text and ranks in that L2) and within 64
+ * positions of each other in dispatch order.  Grid = ceil(nblk / 8) * 8 * LBZ_BWT_SEGS.                       */
+__device__ __forceinline__ bool seg_item(u32 nblk, u32 *i, u32 *seg)
+{
+  const u32 j = blockIdx.x, k = j >> 3;
+  *i = (k / LBZ_BWT_SEGS) * 8u + (j & 7u);
+  *seg = k % LBZ_BWT_SEGS;
+  return *i < nblk;
+}
+
+/* first row at or behind x that starts a group of the partition; n if there is none */
+__device__ u32 seg_cut(const u64 *k0, u32 x, u32 n, bwt_lds *S)
+{
+  if (x == 0u) return 0u;
+  if (x >= n) return n;
+  return find_run_end(k0, x - 1u, x, n, MSD_SHIFT, S);
+}
+
 /* ---- kernel 2: LDS batches of whole groups; emits BWT bytes + rows; flags deep ties ---- */
 __global__ void __launch_bounds__(LBZ_WG, 4)
-k_bwt_batch(const u8 *Tbase, u8 *Bbase, lbz_block_meta *meta, lbz_layout L, u32 first, u32 count,
+k_bwt_batch(const u8 *Tbase, u8 *Bbase, lbz_block_meta *meta, lbz_layout L, u32 first, u32 count, u32 nblk,
             u8 *ws, u64 slot_bytes, u8 *ws_spill, u64 spill_bytes, const u32 *slabs)
 {
   __shared__ bwt_lds S;
   const u32 tid = threadIdx.x;
-  const u32 blk = lbz_round_block(first, count, blockIdx.x, slabs);
+  u32 bi, seg;
+  if (!seg_item(nblk, &bi, &seg)) return;
+  const u32 blk = lbz_round_block(first, count, bi, slabs);
   lbz_block_meta *M = &meta[blk];
   const u32 n = M->n;
   if (n == 0u) return;
-  const bwt_slot s = round_slot(ws, slot_bytes, ws_spill, spill_bytes, count, L);
+  const u32 nseg = n <= BATCH_CAP ? 1u : bwt_nseg(n);
+  if (seg >= nseg) return;
+  const bwt_slot s = round_slot(ws, slot_bytes, ws_spill, spill_bytes, count, L, bi);
   const size_t off = lbz_elem_off(L, blk);
   const u8 *T = Tbase + off;
   u8 *bwt = Bbase + off;
   if (n == 1u) {                              /* divbwt.c:1712 */
-    if (tid == 0) { bwt[0] = T[0]; M->bwt_idx = 0; M->periodic = 0; M->rounds = 0; M->sort_elems = 0; }
+    if (tid == 0) { bwt[0] = T[0]; M->bwt_idx = 0; M->periodic = 0; M->nseg = 1; M->seg_lo[0] = 0; M->seg_lo[1] = 1; }
     return;
   }
   const u64 tk0 = wall_clock64();
   const keycfg c = bwt_setup(M, &S);
-  if (tid == 0) { S.isa_from = n; S.tied0 = 0; for (u32 i = 0; i < 4; i++) S.dbg[i] = 0; }
+  u32 lo = 0, hi = n;
+  if (nseg > 1u) {
+    lo = seg_cut(s.k0, (u32)((u64)seg * n / nseg), n, &S);
+    hi = seg + 1u == nseg ? n : seg_cut(s.k0, (u32)((u64)(seg + 1u) * n / nseg), n, &S);
+  }
+  if (tid == 0) {
+    S.isa_from = hi; S.tied0 = 0; S.budget = (hi - lo) / REFINE_BUDGET_DIV;
+    for (u32 i = 0; i < 4; i++) S.dbg[i] = 0;
+    M->seg_lo[seg] = lo;
+    if (seg + 1u == nseg) M->seg_lo[nseg] = n;
+    if (seg == 0u) M->nseg = nseg;
+  }
   __syncthreads();
   if (n <= BATCH_CAP) {
     batch_lds *B = &S.u.B;
@@ -1401,16 +1439,16 @@ k_bwt_batch(const u8 *Tbase, u8 *Bbase, lbz_block_meta *meta, lbz_layout L, u32 
     __syncthreads();
     batch_process(T, n, bwt, M, s, &S, c, 0u, n, false, true);
   } else {
-    u32 pos = 0;
-    while (pos < n) {
-      /* a block whose rows keep tying (more than a fifth so far) will go through k_bwt_fix: from here on
-         the batches write the ranks along with the rows */
-      if (S.isa_from == n && pos >= 2u * BATCH_CAP && 5u * S.tied0 > pos) {
+    u32 pos = lo;
+    while (pos < hi) {
+      /* a segment whose rows keep tying (more than a fifth so far) will go through the deep-tie rounds: from here
+         on its batches write the ranks along with the rows */
+      if (S.isa_from == hi && pos - lo >= 2u * BATCH_CAP && 5u * S.tied0 > pos - lo) {
         __syncthreads();
         if (tid == 0) S.isa_from = pos;
         __syncthreads();
       }
-      const u32 want = n - pos < BATCH_CAP ? n - pos : BATCH_CAP;
+      const u32 want = hi - pos < BATCH_CAP ? hi - pos : BATCH_CAP;
       const u32 used = batch_process(T, n, bwt, M, s, &S, c, pos, want, false, false, true);
       if (used == 0u) {                          /* one group fills the batch: sort it in HBM first */
 #ifdef LDS_SORT_TICKS
@@ -1429,46 +1467,130 @@ k_bwt_batch(const u8 *Tbase, u8 *Bbase, lbz_block_meta *meta, lbz_layout L, u32 
   }
   __syncthreads();
   if (tid == 0) {
-    M->periodic = S.bc[8] ? 2u : 0u;          /* 2 = ties left for k_bwt_fix */
-    M->isa_from = S.isa_from;
-    M->rounds = 0;
-    M->sort_elems = n;
-    M->ticks[0] = (u32)(wall_clock64() - tk0);
-    for (u32 i = 0; i < 3; i++) M->ticks[3 + i] = S.bc[10 + i];   /* load, group scan (+block sorts), per-wave part */
+    if (S.bc[8]) atomicMax(&M->periodic, 2u);  /* 2 = ties left for the deep-tie rounds */
+    M->seg_isa_from[seg] = S.isa_from;
+    atomicAdd(&M->isa_from, hi - S.isa_from);
+    atomicAdd(&M->sort_elems, hi - lo);
+    /* diagnostics, summed over the block's segments (tests/quickperf.py) */
+    atomicAdd(&M->ticks[0], (u32)(wall_clock64() - tk0));
+    for (u32 i = 0; i < 3; i++) atomicAdd(&M->ticks[3 + i], S.bc[10 + i]);   /* load, group scan (+block sorts), per-wave part */
 #ifndef COL_TICKS
-    M->ticks[6] = S.bc[13]; M->ticks[7] = S.bc[14];
+    atomicAdd(&M->ticks[6], S.bc[13]); atomicAdd(&M->ticks[7], S.bc[14]);
 #endif
-#ifdef SORT_TICKS
-    M->ticks[0] = S.bc[15]; M->ticks[2] = S.bc[2];      /* summed over waves: radix sorts of long groups in the first sort */
-#endif
-#ifndef SORT_TICKS
-    M->ticks[2] = S.bc[4];
-#endif
-    M->ticks[1] = S.bc[3];              /* summed over waves: busy, of which first sort */
 #ifdef LDS_SORT_TICKS
-    M->ticks[1] = S.dbg[0]; M->ticks[2] = S.dbg[1]; M->ticks[6] = S.dbg[2]; M->ticks[7] = S.dbg[3]; M->rounds = S.bc[15];
+    atomicAdd(&M->ticks[1], S.dbg[0]); atomicAdd(&M->ticks[2], S.dbg[1]);
+#else
+    atomicAdd(&M->ticks[1], S.bc[3]); atomicAdd(&M->ticks[2], S.bc[4]);    /* summed over waves: busy, of which first sort */
 #endif
   }
 }
 
-/* ---- kernel 3: blocks with ties deeper than the LDS refinements: prefix doubling ---- */
+/* ---- kernels 3: blocks with ties deeper than the LDS refinements: prefix doubling, ONE LAUNCH PER ROUND ----
+ * k_bwt_fix0   every segment of a block that has ties left builds its list of tied rows (suffix, rank, row) in
+ *              row order -- in its own stretch [seg_lo, ..) of the slot's list columns -- and writes the ranks
+ *              k_bwt_batch did not write.
+ * k_bwt_fixr   round r, depth h = sy << r: every segment re-sorts its runs on isa[suffix + h] (doubling_round).
+ *              The kernel boundary is the only synchronisation the segments of a block need: a round reads
+ *              ranks of ANY rotation of the block, i.e. ranks that another workgroup may be refining in the same
+ *              launch.  That is harmless: a rank is the first row of the rotation's run, a refined rank orders at
+ *              least as deep as the one it replaces and never contradicts it (runs only split), 4-byte stores do
+ *              not tear, and at the next launch every rank is at least 2h deep -- which is all the next round
+ *              assumes.  A launch whose segment has nothing tied (or whose h has passed n) exits at once; the
+ *              host enqueues the log2(M / 8) launches a block can need without looking.
+ * k_bwt_fixend origin pointer and "exactly periodic" flag, the bytes of rows that stay tied for good.           */
+__device__ __forceinline__ bwt_slot seg_view(bwt_slot s, u32 lo)
+{
+  s.sufx += lo; s.grp += lo; s.pos += lo;          /* the segment's list */
+  s.k0 += lo; s.k1 += lo; s.v0 += lo; s.v1 += lo;  /* scratch of the HBM sorter (runs longer than a batch) */
+  return s;
+}
+
 __global__ void __launch_bounds__(LBZ_WG, 4)
-k_bwt_fix(const u8 *Tbase, u8 *Bbase, lbz_block_meta *meta, lbz_layout L, u32 first, u32 count,
-          u8 *ws, u64 slot_bytes, u8 *ws_spill, u64 spill_bytes, const u32 *slabs)
+k_bwt_fix0(const u8 *Tbase, u8 *Bbase, lbz_block_meta *meta, lbz_layout L, u32 first, u32 count, u32 nblk,
+           u8 *ws, u64 slot_bytes, u8 *ws_spill, u64 spill_bytes, const u32 *slabs)
 {
   __shared__ bwt_lds S;
-  const u32 blk = lbz_round_block(first, count, blockIdx.x, slabs);
+  u32 bi, seg;
+  if (!seg_item(nblk, &bi, &seg)) return;
+  const u32 blk = lbz_round_block(first, count, bi, slabs);
   lbz_block_meta *M = &meta[blk];
   const u32 n = M->n;
-  if (n < 2u || M->periodic != 2u) return;
-  const bwt_slot s = round_slot(ws, slot_bytes, ws_spill, spill_bytes, count, L);
+  if (n < 2u || M->periodic != 2u || seg >= M->nseg) return;
+  const u32 lo = M->seg_lo[seg], hi = M->seg_lo[seg + 1u];
+  if (lo >= hi) return;
+  const u64 tk0 = wall_clock64();
+  const bwt_slot s = seg_view(round_slot(ws, slot_bytes, ws_spill, spill_bytes, count, L, bi), lo);
+  const size_t off = lbz_elem_off(L, blk);
+  bwt_setup(M, &S);
+  const u32 m = wg_regroup<true>(nullptr, s.sa + lo, lo, 0u, hi - lo, s, &S, Tbase + off, n, nullptr, M->seg_isa_from[seg]);
+  if (threadIdx.x == 0) {
+    M->seg_m[seg] = m;
+    atomicAdd(&M->fticks[1], m);
+    atomicAdd(&M->fticks[6], (u32)(wall_clock64() - tk0));
+  }
+}
+
+__global__ void __launch_bounds__(LBZ_WG, 4)
+k_bwt_fixr(const u8 *Tbase, u8 *Bbase, lbz_block_meta *meta, lbz_layout L, u32 first, u32 count, u32 nblk,
+           u8 *ws, u64 slot_bytes, u8 *ws_spill, u64 spill_bytes, const u32 *slabs, u32 round)
+{
+  __shared__ bwt_lds S;
+  u32 bi, seg;
+  if (!seg_item(nblk, &bi, &seg)) return;
+  const u32 blk = lbz_round_block(first, count, bi, slabs);
+  lbz_block_meta *M = &meta[blk];
+  const u32 n = M->n;
+  if (n < 2u || M->periodic != 2u || seg >= M->nseg) return;
+  const u32 m = M->seg_m[seg];
+  if (m == 0u) return;
+  const u64 tk0 = wall_clock64();
+  const u32 lo = M->seg_lo[seg];
+  const bwt_slot s = seg_view(round_slot(ws, slot_bytes, ws_spill, spill_bytes, count, L, bi), lo);
   const size_t off = lbz_elem_off(L, blk);
   const keycfg c = bwt_setup(M, &S);
-  u32 rounds = 0, work = 0;
-  finish_by_doubling(Tbase + off, n, Bbase + off, M, s, &S, c.sy, &rounds, &work);
+  const u64 h = (u64)c.sy << round;
+  if (h >= n) return;                           /* tied at depth >= n: tied for good (k_bwt_fixend) */
+  const u32 m2 = doubling_round(Tbase + off, n, Bbase + off, s, &S, (u32)h, m, round + 1u);
   if (threadIdx.x == 0) {
-    M->rounds = rounds; M->sort_elems = n + work;
-    M->fticks[0] = S.bc[14];                                   /* LDS batches of the doubling rounds */
-    for (u32 i = 0; i < 4; i++) M->fticks[2 + i] = S.bc[10 + i];  /* load, run scan, per-wave sort, write-back */
+    M->seg_m[seg] = m2;
+    atomicMax(&M->rounds, round + 1u);
+    atomicAdd(&M->sort_elems, m);
+    atomicAdd(&M->fticks[0], S.bc[14]);                                       /* LDS batches of the doubling rounds */
+    for (u32 i = 0; i < 4; i++) atomicAdd(&M->fticks[2 + i], S.bc[10 + i]);     /* load, run scan, per-wave sort, write-back */
+    atomicAdd(&M->fticks[7], (u32)(wall_clock64() - tk0));
+  }
+}
+
+/* one workgroup per block of the round */
+__global__ void __launch_bounds__(LBZ_WG, 4)
+k_bwt_fixend(u8 *Bbase, lbz_block_meta *meta, lbz_layout L, u32 first, u32 count,
+             u8 *ws, u64 slot_bytes, u8 *ws_spill, u64 spill_bytes, const u32 *slabs)
+{
+  __shared__ u8 inv[256];
+  __shared__ wg_scratch sc;
+  const u32 tid = threadIdx.x;
+  const u32 blk = lbz_round_block(first, count, blockIdx.x, slabs);
+  lbz_block_meta *M = &meta[blk];
+  if (M->n < 2u || M->periodic != 2u) return;
+  const bwt_slot s = round_slot(ws, slot_bytes, ws_spill, spill_bytes, count, L, blockIdx.x);
+  u8 *bwt = Bbase + lbz_elem_off(L, blk);
+  {
+    u32 tot;
+    const u32 f = (tid < 256u && M->inuse[tid]) ? 1u : 0u;
+    const u32 ex = wg_excl_add(f, &tot, &sc);
+    if (f) inv[ex] = (u8)tid;
+    __syncthreads();
+  }
+  /* rows that are tied for good (exactly periodic block): their bytes are all equal anyway */
+  u32 left = 0;
+  for (u32 g = 0; g < M->nseg; g++) {
+    const u32 lo = M->seg_lo[g], m = M->seg_m[g];
+    left += m;
+    for (u32 k = tid; k < m; k += LBZ_WG) bwt[s.pos[lo + k]] = inv[SA_CODE(s.sufx[lo + k])];
+  }
+  __syncthreads();
+  if (tid == 0) {
+    M->bwt_idx = ISA_CUR(s.isa[0]);
+    M->periodic = left > 0u ? 1u : 0u;
   }
 }

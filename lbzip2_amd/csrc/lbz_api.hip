@@ -225,6 +225,34 @@ static int timed_end(lbzamd_ctx *c, size_t *nbev, hipStream_t s)
   return 0;
 }
 
+/* The sorter's launches for the blocks of one round (nblk = 2 * count: primaries then spills; or count: the
+ * listed primaries only): partition (one workgroup per block), then batches, tie lists, the deep-tie rounds --
+ * one launch per doubling depth, every (block, segment) a workgroup (k_bwt.hip) -- and the origin pointers.     */
+static void launch_sort(lbzamd_ctx *c, hipStream_t q, u32 first, u32 count, u32 nblk, u8 *ws, u8 *wsp, const u32 *lst,
+                        int phase /* 0 = partition, 1 = batches, 2 = deep ties */)
+{
+  if (phase == 0) {
+    if (LBZ_BWT_WG >= 1024 && count > c->ncus)      /* 512-thread workgroups share a CU two by two at 128 VGPRs already */
+      hipLaunchKernelGGL(k_bwt_part2, dim3(nblk), dim3(LBZ_BWT_WG), 0, q, (const u8 *)c->T, c->meta, c->L,
+                         first, count, ws, (u64)c->slot_bytes, wsp, (u64)c->spill_bytes, lst);
+    else
+      hipLaunchKernelGGL(k_bwt_part, dim3(nblk), dim3(LBZ_BWT_WG), 0, q, (const u8 *)c->T, c->meta, c->L,
+                         first, count, ws, (u64)c->slot_bytes, wsp, (u64)c->spill_bytes, lst);
+  } else if (phase == 1) {
+    hipLaunchKernelGGL(k_bwt_batch, dim3(lbz_seg_grid(nblk)), dim3(LBZ_BWT_WG), 0, q, (const u8 *)c->T, c->B, c->meta, c->L,
+                       first, count, nblk, ws, (u64)c->slot_bytes, wsp, (u64)c->spill_bytes, lst);
+  } else {
+    hipLaunchKernelGGL(k_bwt_fix0, dim3(lbz_seg_grid(nblk)), dim3(LBZ_BWT_WG), 0, q, (const u8 *)c->T, c->B, c->meta, c->L,
+                       first, count, nblk, ws, (u64)c->slot_bytes, wsp, (u64)c->spill_bytes, lst);
+    const u32 R = lbz_fix_rounds(c->L.M);
+    for (u32 r = 0; r < R; r++)
+      hipLaunchKernelGGL(k_bwt_fixr, dim3(lbz_seg_grid(nblk)), dim3(LBZ_BWT_WG), 0, q, (const u8 *)c->T, c->B, c->meta, c->L,
+                         first, count, nblk, ws, (u64)c->slot_bytes, wsp, (u64)c->spill_bytes, lst, r);
+    hipLaunchKernelGGL(k_bwt_fixend, dim3(nblk), dim3(LBZ_BWT_WG), 0, q, c->B, c->meta, c->L,
+                       first, count, ws, (u64)c->slot_bytes, wsp, (u64)c->spill_bytes, lst);
+  }
+}
+
 static int run_chunk(lbzamd_ctx *c, const u8 *d_in, size_t len, uint32_t nsl, int upto, bool collected = false)
 {
   hipStream_t s = c->stream;
@@ -263,18 +291,11 @@ static int run_chunk(lbzamd_ctx *c, const u8 *d_in, size_t len, uint32_t nsl, in
         if (timed_end(c, &nbev, q)) return -1;
       }
       if (timed_begin(c, &nbev, 0, q)) return -1;
-      if (LBZ_BWT_WG >= 1024 && count > c->ncus)      /* 512-thread workgroups share a CU two by two at 128 VGPRs already */
-        hipLaunchKernelGGL(k_bwt_part2, dim3(grid), dim3(LBZ_BWT_WG), 0, q, (const u8 *)c->T, c->meta, c->L,
-                           first, count, ws, (u64)c->slot_bytes, wsp, (u64)c->spill_bytes, nullptr);
-      else
-        hipLaunchKernelGGL(k_bwt_part, dim3(grid), dim3(LBZ_BWT_WG), 0, q, (const u8 *)c->T, c->meta, c->L,
-                           first, count, ws, (u64)c->slot_bytes, wsp, (u64)c->spill_bytes, nullptr);
+      launch_sort(c, q, first, count, grid, ws, wsp, nullptr, 0);
       if (timed_end(c, &nbev, q) || timed_begin(c, &nbev, 1, q)) return -1;
-      hipLaunchKernelGGL(k_bwt_batch, dim3(grid), dim3(LBZ_BWT_WG), 0, q, (const u8 *)c->T, c->B, c->meta, c->L,
-                         first, count, ws, (u64)c->slot_bytes, wsp, (u64)c->spill_bytes, nullptr);
+      launch_sort(c, q, first, count, grid, ws, wsp, nullptr, 1);
       if (timed_end(c, &nbev, q) || timed_begin(c, &nbev, 2, q)) return -1;
-      hipLaunchKernelGGL(k_bwt_fix, dim3(grid), dim3(LBZ_BWT_WG), 0, q, (const u8 *)c->T, c->B, c->meta, c->L,
-                         first, count, ws, (u64)c->slot_bytes, wsp, (u64)c->spill_bytes, nullptr);
+      launch_sort(c, q, first, count, grid, ws, wsp, nullptr, 2);
       if (timed_end(c, &nbev, q)) return -1;
       if (upto >= 2) {
         if (timed_begin(c, &nbev, 3, q)) return -1;
@@ -532,8 +553,13 @@ static int compress_host(lbzamd_ctx *c, const uint8_t *in, size_t len, uint8_t *
 extern "C" void *lbzamd_pinned_alloc(size_t bytes)
 {
   void *p = nullptr;
-  if (hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault) != hipSuccess) return nullptr;
+  if (hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocPortable) != hipSuccess) return nullptr;   /* every device may DMA it */
   return p;
+}
+extern "C" int lbzamd_device_count(void)
+{
+  int n = 0;
+  return hipGetDeviceCount(&n) == hipSuccess ? n : 0;
 }
 extern "C" void lbzamd_pinned_free(void *p) { if (p) (void)hipHostFree(p); }
 
@@ -681,65 +707,78 @@ extern "C" int lbzamd_decompress_device(lbzamd_dctx *c, const void *d_in_v, size
   u32 nm = 0;
   HIPCHK(hipMemcpyAsync(&nm, c->nmarks, sizeof nm, hipMemcpyDeviceToHost, q));
   HIPCHK(hipStreamSynchronize(q));
-  if (nm > c->marks_cap) { g_err = "lbzamd_decompress: too many block magics"; return -3; }
+  if (nm > c->marks_cap) {                      /* more magics than the list holds (many tiny blocks): grow it and scan again */
+    (void)hipFree(c->marks); c->marks = nullptr;
+    HIPCHK(hipMalloc((void **)&c->marks, (size_t)nm * sizeof(u64)));
+    c->marks_cap = nm;
+    HIPCHK(hipMemsetAsync(c->nmarks, 0, sizeof(u32), q));
+    hipLaunchKernelGGL(k_dscan, dim3((u32)((len + 255u) / 256u)), dim3(256), 0, q, d_in, (u64)len, c->marks, c->nmarks, c->marks_cap);
+    HIPCHK(hipMemcpyAsync(&nm, c->nmarks, sizeof nm, hipMemcpyDeviceToHost, q));
+    HIPCHK(hipStreamSynchronize(q));
+    if (nm > c->marks_cap) { g_err = "lbzamd_decompress: the list of magics changed between two scans"; return -1; }
+  }
   std::vector<u64> marks(nm);
   if (nm) HIPCHK(hipMemcpy(marks.data(), c->marks, nm * sizeof(u64), hipMemcpyDeviceToHost));
   std::sort(marks.begin(), marks.end());
-  /* 2. streams: "BZh" level | blocks | end-of-stream magic + CRC, then (byte aligned) maybe another stream */
+  /* 2. candidates.  A 48-bit magic can also occur by chance (or by design) inside a block's payload, so a mark is
+     only a HINT, as parse.c's scan() is for the reference: every block mark is decoded as a candidate, and what the
+     stream really consists of is decided afterwards by walking the chain header -> block -> (where that block's last
+     code ended) next magic -> ... -> end-of-stream magic (step 4).  Here the candidates only need the block size
+     limit of the stream they would belong to: the level of the last plausible stream header before them.        */
   std::vector<uint8_t> head(4);
   std::vector<lbz_dblock> hb;
-  struct trailer { uint64_t bit; size_t first_block, nblocks; };
-  std::vector<trailer> trailers;
+  std::vector<long> cand_of(marks.size(), -1);
+  auto header_at = [&](uint64_t sbyte, unsigned *level) -> int {       /* 1 = "BZh[1-9]" at sbyte, 0 = something else, -1 = HIP error */
+    if (sbyte + 4 > len) return 0;
+    if (hipMemcpy(head.data(), d_in + sbyte, 4, hipMemcpyDeviceToHost) != hipSuccess) return -1;
+    if (head[0] != 'B' || head[1] != 'Z' || head[2] != 'h' || head[3] < '1' || head[3] > '9') return 0;
+    *level = (unsigned)(head[3] - '0');
+    return 1;
+  };
+  unsigned level0 = 0;
   {
-    uint64_t sbyte = 0;                         /* where the current stream's header is */
-    size_t mi = 0;
-    while (sbyte + 14 <= len) {
-      HIPCHK(hipMemcpy(head.data(), d_in + sbyte, 4, hipMemcpyDeviceToHost));
-      if (head[0] != 'B' || head[1] != 'Z' || head[2] != 'h' || head[3] < '1' || head[3] > '9') {
-        if (sbyte == 0) { g_err = "lbzamd_decompress: not a bzip2 stream (bad header)"; return -3; }
-        break;                                  /* trailing garbage is ignored, as bzip2 does */
+    const int h = header_at(0, &level0);
+    if (h < 0) return fail_msg("hipMemcpy", hipGetLastError());
+    if (h == 0) { g_err = "lbzamd_decompress: not a bzip2 stream (bad header)"; return -3; }
+    unsigned lvl = level0;
+    for (size_t i = 0; i < marks.size(); i++) {
+      const uint64_t bit = marks[i] >> 1;
+      if (bit < 32) continue;
+      if (marks[i] & 1u) {
+        unsigned l2;
+        const int h2 = header_at((bit + 48 + 32 + 7) / 8, &l2);
+        if (h2 < 0) return fail_msg("hipMemcpy", hipGetLastError());
+        if (h2 == 1) lvl = l2;
+        continue;
       }
-      const u32 mbs = (u32)(head[3] - '0') * 100000u;
-      const uint64_t first_bit = (sbyte + 4) * 8;
-      while (mi < marks.size() && (marks[mi] >> 1) < first_bit) mi++;
-      const size_t fb = hb.size();
-      bool closed = false;
-      uint64_t expect = first_bit;
-      while (mi < marks.size()) {
-        const uint64_t bit = marks[mi] >> 1;
-        const int kind = (int)(marks[mi] & 1u);
-        if (fb == hb.size() && bit != expect) { g_err = "lbzamd_decompress: no block magic behind the stream header"; return -3; }
-        mi++;
-        if (kind == 1) {
-          trailers.push_back({ bit, fb, hb.size() - fb });
-          sbyte = (bit + 48 + 32 + 7) / 8;
-          closed = true;
-          break;
-        }
-        lbz_dblock b{};
-        b.bit_start = bit + 48;
-        b.max_block = mbs;
-        hb.push_back(b);
-      }
-      if (!closed) { g_err = "lbzamd_decompress: stream without end-of-stream marker (truncated?)"; return -3; }
+      lbz_dblock b{};
+      b.bit_start = bit + 48;
+      b.max_block = lvl * 100000u;
+      cand_of[i] = (long)hb.size();
+      hb.push_back(b);
     }
   }
-  c->stats.nblocks = (uint32_t)hb.size();
-  c->stats.nstreams = (uint32_t)trailers.size();
-  /* 3. blocks, max_blocks at a time */
+  /* 3. + 4. candidates decoded max_blocks at a time; behind every batch the chain is walked as far as it is decoded */
+  struct trailer { uint64_t bit; uint32_t cc; };
+  std::vector<trailer> trailers;
   float ms[6] = { 0, 0, 0, 0, 0, 0 };
   { float t = 0; HIPCHK(hipEventElapsedTime(&t, c->ev[0], c->ev[1])); ms[0] = t; }
   uint64_t total = 0;
-  for (size_t b0 = 0; b0 < hb.size(); b0 += c->max_blocks) {
+  size_t mi = 0;                                /* next mark the walk looks at */
+  uint64_t expect = 32;                         /* bit position at which the chain's next magic must sit */
+  unsigned level = level0;
+  bool in_stream = true, finished = false;      /* finished: the last stream is closed and what follows is not a header */
+  uint32_t cc = 0, nblocks = 0, stream_blocks = 0;
+  for (size_t b0 = 0; b0 < hb.size() || b0 == 0; b0 += c->max_blocks) {
     const u32 nb = (u32)std::min<size_t>(c->max_blocks, hb.size() - b0);
-    HIPCHK(hipMemcpyAsync(c->blocks, hb.data() + b0, nb * sizeof(lbz_dblock), hipMemcpyHostToDevice, q));
-    HIPCHK(hipEventRecord(c->ev[1], q));
-    hipLaunchKernelGGL(k_dblock, dim3(nb), dim3(256), 0, q, d_in, (u64)len, c->blocks, nb, c->tt8, c->tt, c->W, c->pinfo, c->cap);
-    HIPCHK(hipEventRecord(c->ev[2], q));
-    HIPCHK(hipMemcpyAsync(hb.data() + b0, c->blocks, nb * sizeof(lbz_dblock), hipMemcpyDeviceToHost, q));
-    HIPCHK(hipStreamSynchronize(q));
-    HIPCHK(hipGetLastError());
-    {
+    if (nb) {
+      HIPCHK(hipMemcpyAsync(c->blocks, hb.data() + b0, nb * sizeof(lbz_dblock), hipMemcpyHostToDevice, q));
+      HIPCHK(hipEventRecord(c->ev[1], q));
+      hipLaunchKernelGGL(k_dblock, dim3(nb), dim3(256), 0, q, d_in, (u64)len, c->blocks, nb, c->tt8, c->tt, c->W, c->pinfo, c->cap);
+      HIPCHK(hipEventRecord(c->ev[2], q));
+      HIPCHK(hipMemcpyAsync(hb.data() + b0, c->blocks, nb * sizeof(lbz_dblock), hipMemcpyDeviceToHost, q));
+      HIPCHK(hipStreamSynchronize(q));
+      HIPCHK(hipGetLastError());
       /* the three stages of a block run back to back in one kernel: the stage figures are the slowest
          block's (100 MHz ticks), the pass as a whole is timed by events */
       float t = 0;
@@ -747,21 +786,50 @@ extern "C" int lbzamd_decompress_device(lbzamd_dctx *c, const void *d_in_v, size
       u32 tk[3] = { 0, 0, 0 };
       for (u32 i = 0; i < nb; i++) for (int k = 0; k < 3; k++) tk[k] = std::max(tk[k], hb[b0 + i].tk[k]);
       for (int k = 0; k < 3; k++) ms[1 + k] = std::max(ms[1 + k], tk[k] * 1e-5f);
-      c->stats.ms_scan = ms[0]; c->stats.ms_huff = ms[1]; c->stats.ms_sort = ms[2]; c->stats.ms_walk = ms[3];
-      c->stats.ms_blocks = ms[5];
     }
-    for (u32 i = 0; i < nb; i++) {
-      lbz_dblock &b = hb[b0 + i];
+    /* the walk: marks in stream order, up to the last candidate of this batch */
+    const bool last_batch = b0 + nb >= hb.size();
+    for (; mi < marks.size(); mi++) {
+      const long ci = cand_of[mi];
+      if (ci >= (long)(b0 + nb)) break;                     /* not decoded yet */
+      const uint64_t bit = marks[mi] >> 1;
+      const bool is_end = (marks[mi] & 1u) != 0;
+      if (finished || !in_stream || bit < expect) {         /* off the chain: inside a payload, a header or a trailer; or in trailing garbage */
+        if (ci >= 0) { hb[ci].err = 99; hb[ci].out_len = 0; }
+        continue;
+      }
+      if (bit > expect) {
+        g_err = stream_blocks ? "lbzamd_decompress: no block or end-of-stream magic where the previous block ends (damaged or overrun block)"
+                              : "lbzamd_decompress: no block magic behind the stream header";
+        return -3;
+      }
+      if (is_end) {
+        trailers.push_back({ bit, cc });
+        in_stream = false;
+        const uint64_t sbyte = (bit + 48 + 32 + 7) / 8;
+        unsigned l2;
+        const int h2 = sbyte + 14 <= len ? header_at(sbyte, &l2) : 0;
+        if (h2 < 0) return fail_msg("hipMemcpy", hipGetLastError());
+        if (h2 == 1) { in_stream = true; level = l2; expect = (sbyte + 4) * 8; cc = 0; stream_blocks = 0; }
+        else finished = true;                                  /* trailing garbage is ignored, as bzip2 does */
+        continue;
+      }
+      lbz_dblock &b = hb[ci];
+      if (b.max_block != level * 100000u) { g_err = "lbzamd_decompress: block decoded for another stream's block size (crafted input?)"; return -3; }
       if (b.err) {
         char buf[128];
-        snprintf(buf, sizeof buf, "lbzamd_decompress: block %zu: %s (code %u)", b0 + i, b.err == 11 ? "CRC mismatch" : "malformed block", b.err);
+        snprintf(buf, sizeof buf, "lbzamd_decompress: block %u: %s (code %u)", nblocks, b.err == 11 ? "CRC mismatch" : "malformed block", b.err);
         g_err = buf;
         return -3;
       }
       b.out_off = total;
       total += b.out_len;
+      cc = ((cc << 1) | (cc >> 31)) ^ b.stored_crc;            /* encode.h:38 written for the inverted values */
+      expect = b.bit_used;
+      nblocks++; stream_blocks++;
     }
-    if (total <= out_cap && d_out) {
+    if (last_batch && in_stream) { g_err = "lbzamd_decompress: stream without end-of-stream marker (truncated?)"; return -3; }
+    if (nb && total <= out_cap && d_out) {
       HIPCHK(hipMemcpyAsync(c->blocks, hb.data() + b0, nb * sizeof(lbz_dblock), hipMemcpyHostToDevice, q));
       HIPCHK(hipEventRecord(c->ev[5], q));
       hipLaunchKernelGGL(k_demit, dim3(nb * 8u), dim3(256), 0, q, (const lbz_dblock *)c->blocks, nb, (const u8 *)c->W, (const u32 *)c->pinfo, d_out, (u64)out_cap, c->cap);
@@ -771,19 +839,20 @@ extern "C" int lbzamd_decompress_device(lbzamd_dctx *c, const void *d_in_v, size
       float t = 0;
       HIPCHK(hipEventElapsedTime(&t, c->ev[5], c->ev[6])); ms[4] += t;
     }
+    if (hb.empty()) break;
   }
-  /* 4. stream CRCs: the fold of the block CRCs as stored (encode.h:38 written for the inverted values) */
+  c->stats.nblocks = nblocks;
+  c->stats.nstreams = (uint32_t)trailers.size();
+  /* 5. stream CRCs: the fold of the accepted blocks' stored CRCs against each trailer */
   {
     std::vector<uint8_t> tail(8);
     for (const trailer &tr : trailers) {
-      uint32_t cc = 0;
-      for (size_t i = 0; i < tr.nblocks; i++) cc = ((cc << 1) | (cc >> 31)) ^ hb[tr.first_block + i].stored_crc;
       const uint64_t by = (tr.bit + 48) >> 3;
       const size_t nbytes = std::min<size_t>(8, len - by);
       HIPCHK(hipMemcpy(tail.data(), d_in + by, nbytes, hipMemcpyDeviceToHost));
       std::vector<uint8_t> h(tail.begin(), tail.begin() + nbytes);
       const uint32_t want = rd_be32_bits(h, (tr.bit + 48) & 7u);
-      if (want != cc) { g_err = "lbzamd_decompress: stream CRC mismatch"; return -3; }
+      if (want != tr.cc) { g_err = "lbzamd_decompress: stream CRC mismatch"; return -3; }
     }
   }
   c->stats.n_out = total;
@@ -892,19 +961,48 @@ struct wu_pool {
   std::vector<std::pair<u8 *, uint32_t>> seq_free;     /* buffers of finished blocks, kept for the next ones */
 };
 
+/* One pool per (device, block size).  LBZAMD_DEVICES = N ("all": every device; default 1) spreads the states over
+ * N devices: a state leases its slab from the pool of device (lease counter mod N), so the worker threads of the
+ * reference's unmodified pipeline (process.c:515-548) keep every GPU's rounds full.                            */
+#define WU_MAX_DEV 16
 static std::mutex g_pools_mu;
-static wu_pool *g_pools[10];
+static wu_pool *g_pools[WU_MAX_DEV][10];
+static int g_pool_devs = 0;                  /* 0 = not read yet */
+static unsigned g_pool_next = 0;
 
+static wu_pool *pool_on(int device, unsigned bs100k);
 static wu_pool *pool_for(unsigned bs100k)
 {
+  int dev = -1;
+  {
+    std::lock_guard<std::mutex> lk(g_pools_mu);
+    if (!g_pool_devs) {
+      const char *env = getenv("LBZAMD_DEVICES");
+      int have = 0;
+      if (hipGetDeviceCount(&have) != hipSuccess || have < 1) { g_err = "no HIP device (this library has no CPU path)"; die("work-unit pool"); }
+      int want = env ? (!strcmp(env, "all") ? have : atoi(env)) : 1;
+      if (want < 1) want = 1;
+      if (want > have) want = have;
+      if (want > WU_MAX_DEV) want = WU_MAX_DEV;
+      g_pool_devs = want;
+    }
+    if (g_pool_devs > 1) dev = (int)(g_pool_next++ % (unsigned)g_pool_devs);
+  }
+  return pool_on(dev, bs100k);
+}
+
+static wu_pool *pool_on(int device, unsigned bs100k)
+{
   std::lock_guard<std::mutex> lk(g_pools_mu);
-  if (g_pools[bs100k]) return g_pools[bs100k];
+  if (device < 0) HIPDIE(hipGetDevice(&device), "work-unit pool");
+  if (device >= WU_MAX_DEV) device = WU_MAX_DEV - 1;
+  if (g_pools[device][bs100k]) return g_pools[device][bs100k];
   wu_pool *p = new wu_pool;
   const char *env = getenv("LBZAMD_POOL_SLABS");
   p->P = env ? (uint32_t)atoi(env) : 1024u;
   if (p->P < 1u) p->P = 1u;
   /* one slot set: encode rounds run one at a time, up to 512 blocks (two per CU) each */
-  if (ctx_create(&p->c, -1, bs100k, p->P, p->P < 512u ? p->P : 512u, 1u)) die("cannot create the work-unit pool");
+  if (ctx_create(&p->c, device, bs100k, p->P, p->P < 512u ? p->P : 512u, 1u)) die("cannot create the work-unit pool");
   lbzamd_ctx *c = p->c;
   if (ensure_staging(c, (size_t)p->P * c->L.M, 0)) die("work-unit pool staging");
   for (wu_lane &l : p->lane) {
@@ -912,16 +1010,16 @@ static wu_pool *pool_for(unsigned bs100k)
     HIPDIE(hipMalloc((void **)&l.d_list, p->P * sizeof(u32)), "pool");
     HIPDIE(hipMalloc((void **)&l.d_len, p->P * sizeof(u32)), "pool");
     HIPDIE(hipMalloc((void **)&l.d_pick, p->P * 4u * sizeof(u32)), "pool");
-    HIPDIE(hipHostMalloc((void **)&l.h_pick, p->P * 4u * sizeof(u32), hipHostMallocDefault), "pool");
+    HIPDIE(hipHostMalloc((void **)&l.h_pick, p->P * 4u * sizeof(u32), hipHostMallocPortable), "pool");
   }
-  HIPDIE(hipHostMalloc((void **)&p->h_in, (size_t)p->P * c->L.M, hipHostMallocDefault), "pool");
-  HIPDIE(hipHostMalloc((void **)&p->h_out, (size_t)p->P * c->L.out_a, hipHostMallocDefault), "pool");
+  HIPDIE(hipHostMalloc((void **)&p->h_in, (size_t)p->P * c->L.M, hipHostMallocPortable), "pool");
+  HIPDIE(hipHostMalloc((void **)&p->h_out, (size_t)p->P * c->L.out_a, hipHostMallocPortable), "pool");
   for (uint32_t i = p->P; i-- > 0;) p->free_slabs.push_back(i);
   HIPDIE(hipStreamCreateWithFlags(&p->seq_q, hipStreamNonBlocking), "pool");
   HIPDIE(hipMalloc((void **)&p->seq_starts, 4u * sizeof(unsigned long long)), "pool");
   HIPDIE(hipMalloc((void **)&p->seq_ticket, sizeof(u32)), "pool");
   HIPDIE(hipMalloc((void **)&p->seq_out, sizeof(lbz_seq_out)), "pool");
-  g_pools[bs100k] = p;
+  g_pools[device][bs100k] = p;
   return p;
 }
 
@@ -955,16 +1053,7 @@ static void pool_round(wu_pool *p, int stage, const std::vector<wu_req *> &batch
       /* primaries only (grid = count): what collect() left over went back to the caller */
       const u32 count = cnt - o < c->nslots ? cnt - o : c->nslots;
       const u32 *lst = ln.d_list + o;
-      if (LBZ_BWT_WG >= 1024 && count > c->ncus)
-        hipLaunchKernelGGL(k_bwt_part2, dim3(count), dim3(LBZ_BWT_WG), 0, ln.q, (const u8 *)c->T, c->meta, c->L, 0u, count,
-                           ws, (u64)c->slot_bytes, wsp, (u64)c->spill_bytes, lst);
-      else
-        hipLaunchKernelGGL(k_bwt_part, dim3(count), dim3(LBZ_BWT_WG), 0, ln.q, (const u8 *)c->T, c->meta, c->L, 0u, count,
-                           ws, (u64)c->slot_bytes, wsp, (u64)c->spill_bytes, lst);
-      hipLaunchKernelGGL(k_bwt_batch, dim3(count), dim3(LBZ_BWT_WG), 0, ln.q, (const u8 *)c->T, c->B, c->meta, c->L, 0u, count,
-                         ws, (u64)c->slot_bytes, wsp, (u64)c->spill_bytes, lst);
-      hipLaunchKernelGGL(k_bwt_fix, dim3(count), dim3(LBZ_BWT_WG), 0, ln.q, (const u8 *)c->T, c->B, c->meta, c->L, 0u, count,
-                         ws, (u64)c->slot_bytes, wsp, (u64)c->spill_bytes, lst);
+      for (int ph = 0; ph < 3; ph++) launch_sort(c, ln.q, 0u, count, count, ws, wsp, lst, ph);
       hipLaunchKernelGGL(k_mtf, dim3(count), dim3(LBZ_WG), 0, ln.q, (const u8 *)c->B, c->R, c->V, c->freq, c->meta, c->L, 0u, count, lst);
       hipLaunchKernelGGL(k_encode, dim3(count), dim3(LBZ_WG), 0, ln.q, (const u16 *)c->V, (const u32 *)c->freq, c->O, c->meta, c->L, 0u, count, lst);
     }

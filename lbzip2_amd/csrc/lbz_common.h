@@ -37,6 +37,10 @@
                                LDS: +10 % on byte-alphabet text over 1024 threads / 4096 rows (equal on the word soup) */
 #endif
 
+#ifndef LBZ_BWT_SEGS
+#define LBZ_BWT_SEGS 8u     /* segments of a block's sorted rows = workgroups per block in k_bwt_batch / k_bwt_fix* */
+#endif
+
 /* Per-block record in HBM.  Blocks are numbered 2*slab (primary) and 2*slab+1 (spill). */
 typedef struct lbz_block_meta {
   uint32_t n;          /* RLE1'd length (nblock); 0 = block absent */
@@ -52,7 +56,13 @@ typedef struct lbz_block_meta {
   uint32_t err;        /* non-zero: internal capacity problem */
   uint32_t rounds;     /* prefix-doubling rounds run (diagnostic) */
   uint32_t sort_elems; /* sum of elements passed through the radix sorter (diagnostic) */
-  uint32_t isa_from;   /* k_bwt_batch wrote the ranks (isa) of the rotations in rows >= isa_from; k_bwt_fix fills in the rest */
+  uint32_t isa_from;   /* (diagnostic) rows whose ranks k_bwt_batch wrote itself, summed over the block's segments */
+  /* The sorted rows of a block are cut into up to LBZ_BWT_SEGS segments at boundaries of the partition's groups; from
+     k_bwt_batch on every (block, segment) is a workgroup of its own (k_bwt.hip).  Rows [seg_lo[s], seg_lo[s+1]).    */
+  uint32_t nseg;
+  uint32_t seg_lo[LBZ_BWT_SEGS + 1];
+  uint32_t seg_isa_from[LBZ_BWT_SEGS];  /* k_bwt_batch wrote the ranks (isa) of the segment's rows >= this; k_bwt_fix0 fills in the rest */
+  uint32_t seg_m[LBZ_BWT_SEGS];         /* rows of the segment that are still tied (length of its list, k_bwt_fix*) */
   uint32_t ticks[8];   /* wall_clock64 ticks of k_bwt_part / k_bwt_batch phases (diagnostic) */
   uint32_t fticks[16];  /* wall_clock64 ticks of k_bwt_fix phases (diagnostic) */
   uint8_t  inuse[256]; /* used-byte map (encode.c:63) */
@@ -89,8 +99,8 @@ size_t lbz_out_off(const lbz_layout L, uint32_t blk)
 
 /* BWT workspace of one resident workgroup ("slot"), elements of capacity cap_a:
  *   k0,k1 : u64 sort keys (ping-pong)      v0,v1 : u32 sort values (ping-pong)
- *   sufx,grp,pos : u32 active-list columns  sa,isa : u32 suffix array and ranks
+ *   sufx,grp,pos : u32 active-list columns  sa : u32 suffix array  isa : u64 rank entries (k_bwt.hip, ISA_ENTRY)
  *   gb : 32769 u32 bucket starts                                                      */
-#define LBZ_BWT_SLOT_BYTES(cap) ((size_t)(cap) * (8u * 2u + 4u * 2u + 4u * 5u) + 33024u * 4u)
+#define LBZ_BWT_SLOT_BYTES(cap) ((size_t)(cap) * (8u * 2u + 4u * 2u + 4u * 4u + 8u) + 33024u * 4u)
 
 #endif

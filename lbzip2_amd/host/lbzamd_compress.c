@@ -20,8 +20,13 @@
  *             (lbzamd_fold_parts).  The file is never resident as a whole; the stream is the same
  *             single stream the batch call and reference lbzip2 produce.
  *
+ *   -g N      (with -f/-o) the pipelines' contexts live on N devices, pipeline i on device i mod N (0 = every
+ *             device; -p then counts pipelines PER device): the reader and the writer stay single threads, the
+ *             chunks go to the GPUs by direct H2D from the pinned ring -- the C-side form of the reference's N
+ *             workers behind one splitter/muxer (process.c:515-548, compress.c:73-118, :238-250).
+ *
  *   lbzamd_compress [-1..-9] [-w N] < input > output.bz2
- *   lbzamd_compress [-1..-9] -f input -o output.bz2 [-c slabs] [-p pipelines] [-t]
+ *   lbzamd_compress [-1..-9] -f input -o output.bz2 [-c slabs] [-p pipelines] [-g devices] [-t]
  *
  * Not a CLI clone of lbzip2; it exists so the drop-in boundary is exercised
  * from C the way the reference would.
@@ -101,7 +106,7 @@ enum { SL_FREE = 0, SL_FULL = 1, SL_BUSY = 2, SL_DONE = 3 };
 struct slot { unsigned char *in, *out; size_t len, out_len; lbzamd_part part; int state; size_t seq; };
 struct pipe {
   int fd_in, fd_out;
-  unsigned level, nslots;
+  unsigned level, nslots, ndev, next_pipe;
   size_t chunk_bytes, out_cap;
   struct slot *slots;
   size_t next_read, next_compute, next_write;     /* chunk sequence numbers */
@@ -145,7 +150,10 @@ static void *pipeline_thread(void *arg)
   struct pipe *p = arg;
   lbzamd_ctx *ctx = NULL;
   const size_t mbs = p->level * 100000ul;
-  if (lbzamd_create(&ctx, -1, p->level, (unsigned)(p->chunk_bytes / mbs), 0)) {
+  pthread_mutex_lock(&p->mu);
+  const int device = p->ndev ? (int)(p->next_pipe++ % p->ndev) : -1;      /* -g: pipeline i on device i mod N */
+  pthread_mutex_unlock(&p->mu);
+  if (lbzamd_create(&ctx, device, p->level, (unsigned)(p->chunk_bytes / mbs), 0)) {
     fprintf(stderr, "lbzamd: %s\n", lbzamd_last_error());
     pthread_mutex_lock(&p->mu); p->failed = 1; pthread_cond_broadcast(&p->cv); pthread_mutex_unlock(&p->mu);
     return NULL;
@@ -217,11 +225,14 @@ static void *writer_thread(void *arg)
   return NULL;
 }
 
-static int stream_files(const char *in_path, const char *out_path, unsigned level, unsigned chunk_slabs, unsigned npipes, int timing)
+static int stream_files(const char *in_path, const char *out_path, unsigned level, unsigned chunk_slabs, unsigned npipes, int timing,
+                        unsigned ndev)
 {
   struct pipe p;
   memset(&p, 0, sizeof p);
   p.level = level;
+  p.ndev = ndev;
+  if (ndev) npipes *= ndev;                       /* -p pipelines on each device */
   p.fd_in = strcmp(in_path, "-") ? open(in_path, O_RDONLY) : 0;
   p.fd_out = strcmp(out_path, "-") ? open(out_path, O_WRONLY | O_CREAT | O_TRUNC, 0644) : 1;
   if (p.fd_in < 0 || p.fd_out < 0) { perror("open"); return 1; }
@@ -246,8 +257,8 @@ static int stream_files(const char *in_path, const char *out_path, unsigned leve
   pthread_join(wr, NULL);
   const double t1 = now_s();
   if (timing)
-    fprintf(stderr, "file splitter/muxer: %zu B -> %zu B in %.3f s = %.0f MB/s (%u pipelines, chunks of %u slabs, contexts included)\n",
-            p.total_in, p.total_out, t1 - t0, (double)p.total_in / (t1 - t0) / 1e6, npipes, chunk_slabs);
+    fprintf(stderr, "file splitter/muxer: %zu B -> %zu B in %.3f s = %.0f MB/s (%u pipelines on %u device(s), chunks of %u slabs, contexts included)\n",
+            p.total_in, p.total_out, t1 - t0, (double)p.total_in / (t1 - t0) / 1e6, npipes, ndev ? ndev : 1u, chunk_slabs);
   for (unsigned i = 0; i < p.nslots; i++) { lbzamd_pinned_free(p.slots[i].in); lbzamd_pinned_free(p.slots[i].out); }
   if (p.fd_in > 0) close(p.fd_in);
   if (p.fd_out > 1) close(p.fd_out);
@@ -256,20 +267,22 @@ static int stream_files(const char *in_path, const char *out_path, unsigned leve
 
 int main(int argc, char **argv)
 {
-  unsigned level = 9, nworkers = 0, timing = 0, repeat = 1, chunk_slabs = 256, npipes = 2, decompress = 0, sequential = 0;
+  unsigned level = 9, nworkers = 0, timing = 0, repeat = 1, chunk_slabs = 256, npipes = 2, decompress = 0, sequential = 0, ndev = 0;
+  int want_dev = -1;
   const char *in_path = NULL, *out_path = NULL;
   for (int i = 1; i < argc; i++) {
     if (!strcmp(argv[i], "-f") && i + 1 < argc) { in_path = argv[++i]; continue; }
     if (!strcmp(argv[i], "-o") && i + 1 < argc) { out_path = argv[++i]; continue; }
     if (!strcmp(argv[i], "-c") && i + 1 < argc) { chunk_slabs = (unsigned)atoi(argv[++i]); continue; }
     if (!strcmp(argv[i], "-p") && i + 1 < argc) { npipes = (unsigned)atoi(argv[++i]); continue; }
+    if (!strcmp(argv[i], "-g") && i + 1 < argc) { want_dev = atoi(argv[++i]); continue; }
     if (!strcmp(argv[i], "-t")) { timing = 1; continue; }            /* phase times on stderr */
     if (!strcmp(argv[i], "-d")) { decompress = 1; continue; }        /* the inverse path: .bz2 -> bytes */
     if (!strcmp(argv[i], "-u")) { sequential = 1; continue; }        /* the reference's -u: blocks cut where they are full (batch mode) */
     if (!strcmp(argv[i], "-r") && i + 1 < argc) { repeat = (unsigned)atoi(argv[++i]); continue; }   /* run the codec phase N times */
     if (argv[i][0] == '-' && argv[i][1] >= '1' && argv[i][1] <= '9' && !argv[i][2]) level = argv[i][1] - '0';
     else if (!strcmp(argv[i], "-w") && i + 1 < argc) nworkers = (unsigned)atoi(argv[++i]);
-    else { fprintf(stderr, "usage: %s [-1..-9] [-w N] [-t] [-r N] < in > out.bz2 | -f IN -o OUT [-c slabs] [-p pipelines] | -d [-f IN] [-o OUT]\n", argv[0]); return 2; }
+    else { fprintf(stderr, "usage: %s [-1..-9] [-w N] [-t] [-r N] < in > out.bz2 | -f IN -o OUT [-c slabs] [-p pipelines] [-g devices] | -d [-f IN] [-o OUT]\n", argv[0]); return 2; }
   }
   if (decompress) {
     /* whole file in, every block decoded at once (lbzamd_decompress_host), whole file out */
@@ -296,8 +309,8 @@ int main(int argc, char **argv)
       fprintf(stderr, "decode: %zu B -> %zu B, %u blocks in %u stream(s); context + size pass %.3f s, decode %.3f s = %.0f MB/s (device: scan %.1f blocks %.1f emit %.1f ms)\n",
               zlen, n, ds.nblocks, ds.nstreams, t1 - t0, t2 - t1, (double)n / (t2 - t1) / 1e6, ds.ms_scan, ds.ms_blocks, ds.ms_emit);
     }
-    fwrite(out, 1, n, fo);
-    if (fo != stdout) fclose(fo);
+    if (fwrite(out, 1, n, fo) != n || fflush(fo)) { perror("lbzamd_compress -d: write"); return 1; }
+    if (fo != stdout && fclose(fo)) { perror("lbzamd_compress -d: close"); return 1; }
     lbzamd_ddestroy(d);
     free(out); free(z);
     return 0;
@@ -305,7 +318,12 @@ int main(int argc, char **argv)
   if (in_path || out_path) {
     if (chunk_slabs < 1) chunk_slabs = 1;
     if (npipes < 1) npipes = 1;
-    return stream_files(in_path ? in_path : "-", out_path ? out_path : "-", level, chunk_slabs, npipes, (int)timing);
+    if (want_dev >= 0) {
+      const int have = lbzamd_device_count();
+      if (have < 1) { fprintf(stderr, "lbzamd: no HIP device\n"); return 1; }
+      ndev = (unsigned)(want_dev == 0 || want_dev > have ? have : want_dev);
+    }
+    return stream_files(in_path ? in_path : "-", out_path ? out_path : "-", level, chunk_slabs, npipes, (int)timing, ndev);
   }
   size_t len;
   unsigned char *in = read_all(stdin, &len);

@@ -1,0 +1,114 @@
+"""Hand-made bzip2 streams whose block PAYLOAD contains a 48-bit block magic (0x314159265359) or end-of-stream
+magic (0x177245385090) -- what a magic scan alone cannot tell from a real block boundary.  TEST INFRASTRUCTURE.
+
+The block uses 6 distinct bytes, so its alphabet is RUNA, RUNB, five move-to-front positions and the end-of-block
+symbol: 8 symbols, all given 3-bit codes (canonical: symbol k = code k, end of block = 111).  Any bit string cut
+into 3-bit groups none of which is 111 is therefore a valid symbol sequence, and the symbols are chosen to spell
+the magic.  The stream is a valid .bz2 file: Python's bz2 (libbzip2) decodes it; the tests compare with that.
+"""
+BLOCK_MAGIC = 0x314159265359
+END_MAGIC = 0x177245385090
+
+
+def _crc32_bz(data):
+    crc = 0xFFFFFFFF
+    for b in data:
+        crc ^= b << 24
+        for _ in range(8):
+            crc = ((crc << 1) ^ 0x04C11DB7) & 0xFFFFFFFF if crc & 0x80000000 else (crc << 1) & 0xFFFFFFFF
+    return crc ^ 0xFFFFFFFF
+
+
+def _spell(magic):
+    """3-bit symbols (never 7) whose bits contain the 48-bit magic; returns the symbols."""
+    bits = format(magic, "048b")
+    for pre in ("", "0", "1", "00", "01", "10", "11"):          # bits of a symbol in front of the magic
+        s = pre + bits
+        s += "0" * (-len(s) % 3)
+        groups = [int(s[i:i + 3], 2) for i in range(0, len(s), 3)]
+        if 7 not in groups:
+            return groups
+    raise AssertionError("magic cannot be spelled")
+
+
+def _decode_symbols(syms, used):
+    """MTF + zero-run decoding of the symbol list (without the end-of-block symbol) -> BWT bytes."""
+    order = list(used)
+    out = []
+    run, weight = 0, 1
+    for s in syms + [None]:
+        if s in (0, 1):
+            run += weight << s
+            weight <<= 1
+            continue
+        if run:
+            out += [order[0]] * run
+            run, weight = 0, 1
+        if s is None:
+            break
+        b = order.pop(s - 1)
+        order.insert(0, b)
+        out.append(b)
+    return out
+
+
+def _inverse_bwt(L, orig):
+    n = len(L)
+    order = sorted(range(n), key=lambda i: (L[i], i))            # stable: the k-th occurrence maps to the k-th
+    out, p = [], order[orig]
+    for _ in range(n):
+        out.append(L[p])
+        p = order[p]
+    return out
+
+
+def _inverse_rle1(b):
+    out, i = [], 0
+    while i < len(b):
+        c, run = b[i], 1
+        out.append(c)
+        i += 1
+        while i < len(b) and run < 4 and b[i] == c:
+            out.append(c); run += 1; i += 1
+        if run == 4 and i < len(b):
+            out += [c] * b[i]
+            i += 1
+    return bytes(out)
+
+
+def crafted_stream(magic=BLOCK_MAGIC, level=9, filler=60):
+    """A complete one-block .bz2 stream whose payload contains `magic`; returns (stream, decoded bytes)."""
+    used = [65, 66, 67, 68, 69, 70]
+    # the walk over the move-to-front list must stay meaningful: a prelude that touches every byte, the magic, a tail
+    body = [2, 3, 4, 5, 6, 2, 3] * 3 + [0, 1, 4] * (filler // 3)
+    syms = body + _spell(magic) + [2, 6, 3, 0, 5]
+    L = _decode_symbols(syms, used)
+    n = len(L)
+    orig = n // 3
+    data = _inverse_rle1(_inverse_bwt(L, orig))
+    crc = _crc32_bz(data)
+
+    bits = []
+
+    def put(nb, v):
+        bits.append(format(v, "0%db" % nb))
+
+    put(48, BLOCK_MAGIC); put(32, crc); put(1, 0); put(24, orig)
+    put(16, 1 << (15 - 4))                                         # bytes 64..79 in use
+    put(16, sum(1 << (15 - (u - 64)) for u in used))
+    all_syms = syms + [7]
+    nsel = (len(all_syms) + 49) // 50
+    put(3, 2); put(15, nsel)
+    for _ in range(nsel):
+        put(1, 0)                                                  # every group uses table 0
+    for _ in range(2):                                             # two identical tables: every length 3
+        put(5, 3)
+        for _ in range(8):
+            put(1, 0)
+    for s in all_syms:
+        put(3, s)
+    put(48, END_MAGIC); put(32, crc)                               # one block: combined CRC = rotl(0,1) ^ crc
+    s = "".join(bits)
+    s += "0" * (-len(s) % 8)
+    stream = b"BZh" + bytes([48 + level]) + int(s, 2).to_bytes(len(s) // 8, "big")
+    return stream, data

@@ -227,14 +227,24 @@ void launch(const std::function<void()> &body, dim3 grid, dim3 block, size_t)
   if (nt < 1) nt = 1;
   if (nt > grid.x) nt = grid.x;
   std::atomic<unsigned> next{0};
+  /* block contexts (fiber stacks) are pooled across launches: a launch's worker threads are short-lived, the
+     touched stack pages are not given back */
+  static std::mutex pool_mu;
+  static std::vector<BlockCtx *> pool;
   auto worker = [&]() {
-    static thread_local BlockCtx *my = nullptr;
+    BlockCtx *my = nullptr;
+    {
+      std::lock_guard<std::mutex> lk(pool_mu);
+      if (!pool.empty()) { my = pool.back(); pool.pop_back(); }
+    }
     if (!my) my = new_ctx();
     for (;;) {
       unsigned b = next.fetch_add(1);
       if (b >= grid.x) break;
       run_block(my, body, grid, block, b);
     }
+    std::lock_guard<std::mutex> lk(pool_mu);
+    pool.push_back(my);
   };
   if (nt == 1) { worker(); return; }
   std::vector<std::thread> th;

@@ -167,9 +167,12 @@ static inline hipError_t hipMemcpy(void *d, const void *s, size_t n, hipMemcpyKi
 static inline hipError_t hipMemcpyAsync(void *d, const void *s, size_t n, hipMemcpyKind, hipStream_t = nullptr) { memcpy(d, s, n); return hipSuccess; }
 static inline hipError_t hipMemset(void *d, int v, size_t n) { memset(d, v, n); return hipSuccess; }
 static inline hipError_t hipMemsetAsync(void *d, int v, size_t n, hipStream_t = nullptr) { memset(d, v, n); return hipSuccess; }
-static inline hipError_t hipSetDevice(int) { return hipSuccess; }
-static inline hipError_t hipGetDevice(int *d) { *d = 0; return hipSuccess; }
-static inline hipError_t hipGetDeviceCount(int *n) { *n = 1; return hipSuccess; }
+/* LBZ_EMU_DEVICES=N: N fake devices (one address space), so that the per-device code paths of the host runtime run */
+static inline int emu_ndev() { const char *e = getenv("LBZ_EMU_DEVICES"); const int n = e ? atoi(e) : 1; return n < 1 ? 1 : n; }
+static inline int &emu_curdev() { static thread_local int d = 0; return d; }
+static inline hipError_t hipSetDevice(int d) { if (d < 0 || d >= emu_ndev()) return hipErrorInvalidValue; emu_curdev() = d; return hipSuccess; }
+static inline hipError_t hipGetDevice(int *d) { *d = emu_curdev(); return hipSuccess; }
+static inline hipError_t hipGetDeviceCount(int *n) { *n = emu_ndev(); return hipSuccess; }
 static inline hipError_t hipDeviceSynchronize() { return hipSuccess; }
 static inline hipError_t hipStreamCreate(hipStream_t *s) { *s = nullptr; return hipSuccess; }
 static inline hipError_t hipStreamCreateWithFlags(hipStream_t *s, unsigned) { *s = nullptr; return hipSuccess; }
@@ -191,5 +194,6 @@ static inline const char *hipGetErrorString(hipError_t e) { return e == hipSucce
 #define hipEventDisableTiming 2
 static inline hipError_t hipEventCreateWithFlags(hipEvent_t *e, unsigned) { return hipEventCreate(e); }
 #define hipHostMallocDefault 0
+#define hipHostMallocPortable 1
 
 #endif

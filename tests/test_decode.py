@@ -121,6 +121,36 @@ def test_damaged_streams_are_refused(emu):
             emu.decompress(bytes(bad))
 
 
+def check_planted_magics(lib):
+    """A 48-bit block magic or end-of-stream magic INSIDE a block's payload (tests/craft_bz2.py; libbzip2 decodes
+    these files): the scan reports it, the chain header -> block -> where the block ended -> next magic must not
+    follow it.  Also between other blocks and streams, and with real garbage between two blocks (refused)."""
+    import craft_bz2 as cb
+    for magic in (cb.BLOCK_MAGIC, cb.END_MAGIC):
+        z, want = cb.crafted_stream(magic)
+        assert bz2.decompress(z) == want
+        assert lib.decompress(z) == want, hex(magic)
+        d1 = bytes(gen("text", 150000, 12))
+        multi = bz2.compress(d1, 1) + z + L.orc_compress(d1[:50000], 1) + b"garbage" + z
+        assert lib.decompress(multi) == d1 + want + d1[:50000]
+    # two byte-aligned blocks with four stray bytes between them: no magic where block 1 ends
+    d = bytes(gen("text", 230000, 3))
+    good = L.orc_compress(d, 1)
+    cut = good.index(bytes.fromhex("314159265359"), 20)
+    with pytest.raises(LbzError):
+        lib.decompress(good[:cut] + b"\0\0\0\0" + good[cut:])
+
+
+def test_magic_inside_a_payload(emu):
+    check_planted_magics(emu)
+
+
+@pytest.mark.gpu
+def test_magic_inside_a_payload_on_the_gpu():
+    import lbzip2_amd
+    check_planted_magics(lbzip2_amd.library())
+
+
 def test_cli_decompress(emu):
     """lbzip2_amd/host/lbzamd_compress.c -d: file in, every block at once, file out"""
     d = bytes(gen("wiki", 200000, 5))
@@ -149,7 +179,7 @@ def test_cli_decompress_on_the_gpu(tmp_path):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("kind,n,seed,level", [("wiki", 100_000_000, 1, 9), ("rand", 30_000_000, 4, 9), ("mixed", 120_000_000, 3, 1),
-                                               ("tar", 175_000_000, 5, 9), ("text", 50_000_000, 2, 5)])
+                                               ("tar", 175_000_000, 5, 9), ("tar", 1_400_000_000, 5, 9), ("text", 50_000_000, 2, 5)])
 def test_round_trip_full_size(kind, n, seed, level):
     """compress on the device, decode on the device, compare on the device (C5: tar-like stream, round trip)"""
     import torch

@@ -113,3 +113,30 @@ def test_file_splitter_muxer(emu, tmp_path):
         src.write_bytes(data)
         subprocess.check_call([exe, "-1", "-f", str(src), "-o", str(dst), "-c", str(chunk), "-p", str(pipes)], timeout=600)
         assert dst.read_bytes() == L.orc_compress(data, 1), (n, chunk, pipes)
+
+
+def test_c_side_multi_device(emu, tmp_path):
+    """The C host side on several devices (north star: lbzip2's splitter/muxer feeding N GPUs; process.c:515-548):
+    `lbzamd_compress -f/-o -g N` puts pipeline i's context on device i mod N, and LBZAMD_DEVICES=N keeps one work-unit
+    pool per device behind the drop-in symbols.  The emulator shows N fake devices (LBZ_EMU_DEVICES): the per-device
+    code paths run, the stream must be the single-device one."""
+    exe = os.path.join(EMU_DIR, "_build", "lbzamd_compress_emu")
+    data = bytes(gen("wiki", 730000, 4))
+    want = L.orc_compress(data, 1)
+    src, dst = tmp_path / "in.bin", tmp_path / "out.bz2"
+    src.write_bytes(data)
+    env = dict(os.environ, LBZ_EMU_DEVICES="3")
+    for g, p in (("3", "1"), ("0", "2"), ("2", "1")):
+        r = subprocess.run([exe, "-1", "-f", str(src), "-o", str(dst), "-c", "2", "-p", p, "-g", g, "-t"], env=env,
+                           capture_output=True, timeout=900)
+        assert r.returncode == 0, r.stderr[-400:]
+        assert dst.read_bytes() == want, (g, p)
+        assert (b"on %d device(s)" % (3 if g in ("0", "3") else 2)) in r.stderr, r.stderr[-300:]
+    # the reference's work-unit calls from 4 threads, the states' slabs leased round-robin from 2 and 3 pools
+    for ndev in ("2", "all"):
+        r = subprocess.run([exe, "-1", "-w", "4"], input=data, env=dict(env, LBZAMD_DEVICES=ndev, LBZAMD_POOL_SLABS="3"),
+                           capture_output=True, timeout=900)
+        assert r.returncode == 0 and r.stdout == want, (ndev, r.stderr[-400:])
+    r = subprocess.run([exe, "-1", "-f", str(src), "-o", str(dst), "-g", "2"], env=dict(os.environ, LBZ_EMU_DEVICES="1"),
+                       capture_output=True, timeout=900)
+    assert r.returncode == 0 and dst.read_bytes() == want           # more devices asked for than there are: clamped

@@ -260,6 +260,60 @@ def test_file_splitter_muxer_full_size(lib, tmp_path):
     assert len(out) == rec["out_len"] and hashlib.md5(out).hexdigest() == rec["ref_md5"]
 
 
+def test_c_side_multi_gpu(lib, tmp_path):
+    """The C host side over every device of the box (one on the test box -- the per-device code path still runs):
+    `lbzamd_compress -f/-o -g 0` (pipelines' contexts dealt over the devices, one reader, one writer) and the
+    reference's work-unit calls with LBZAMD_DEVICES=all (one pool per device, slabs leased round-robin) must both
+    write the reference's stream.  process.c:515-548, compress.c:73-118,238-250."""
+    import hashlib
+    import subprocess
+    exe = os.path.join(os.path.dirname(lib.path), "..", "host", "lbzamd_compress")
+    if not os.path.exists(exe):
+        pytest.skip("C driver not built")
+    rec = [r for r in bench_fixtures() if r["kind"] == "tar" and r["n"] == 175_000_000][0]
+    data = bytes(gen(rec["kind"], rec["n"], rec["seed"]))
+    src, dst = tmp_path / "tar.bin", tmp_path / "tar.bz2"
+    src.write_bytes(data)
+    env = dict(os.environ, LD_LIBRARY_PATH="/opt/rocm/lib:" + os.environ.get("LD_LIBRARY_PATH", ""))
+    p = subprocess.run([exe, "-9", "-f", str(src), "-o", str(dst), "-c", "64", "-p", "2", "-g", "0", "-t"], capture_output=True, env=env, timeout=300)
+    assert p.returncode == 0 and b"device(s)" in p.stderr, p.stderr[-500:]
+    out = dst.read_bytes()
+    assert len(out) == rec["out_len"] and hashlib.md5(out).hexdigest() == rec["ref_md5"]
+    p = subprocess.run([exe, "-9", "-w", "64"], input=data, capture_output=True, env=dict(env, LBZAMD_DEVICES="all"), timeout=300)
+    assert p.returncode == 0, p.stderr[-500:]
+    assert len(p.stdout) == rec["out_len"] and hashlib.md5(p.stdout).hexdigest() == rec["ref_md5"]
+
+
+def test_rccl_leg_of_the_stream_mux(tmp_path):
+    """lbzip2_amd.shard.StreamMux over RCCL (all_gather of the partials, grouped send/recv of the bodies between device
+    buffers): two ranks of `bench.py --scaling strong`.  The test box has ONE GPU; RCCL may refuse two ranks on one
+    device ("Duplicate GPU detected") -- then the leg can only run in the driver's multi-GPU bench and this test says so."""
+    import json
+    import subprocess
+    import sys
+    import torch
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    ndev = torch.cuda.device_count()
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    if ndev < 2:
+        env["LBZ_BENCH_ONE_DEVICE"] = "1"            # both ranks on cuda:0
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+           "--master-port", "29631", os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1", "--scaling", "strong",
+           "--bytes", "100000000", "--seed", "1", "--no-cpu", "--no-host", "--no-isolated", "--no-decode", "--no-seq", "--no-legs"]
+    try:
+        p = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=240)
+    except subprocess.TimeoutExpired:
+        pytest.skip("two RCCL ranks on one device did not finish in 240 s: the RCCL leg needs two GPUs (driver's SCALE run)")
+    if p.returncode != 0:
+        tail = (p.stdout + p.stderr)[-1500:]
+        if ndev < 2 and ("Duplicate GPU" in tail or "invalid usage" in tail or "NCCL" in tail or "RCCL" in tail):
+            pytest.skip("RCCL refuses two ranks on one device here; the leg runs in the driver's multi-GPU bench: " + tail[-300:])
+        assert False, tail
+    line = [l for l in p.stdout.splitlines() if l.startswith("{")][-1]
+    res = json.loads(line)
+    assert res["n_gpus"] == 2 and res["scaling"] == "strong" and res["verified"] is True, line[:600]
+
+
 def test_full_size_property(lib):
     """BASELINE-sized behaviour by properties: 60 MB of text at -9 with chunked streaming
     (resident capacity smaller than the input) round-trips through an independent decoder,
