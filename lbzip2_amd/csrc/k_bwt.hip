@@ -33,7 +33,7 @@
  *
  * Algorithmic traffic of the stage as priced in SURVEY.md 8(d): read T (1) + write SA (4) +
  * read SA (4) + gather T (1) + write BWT (1) = 11 B per block byte; measured HBM traffic is in
- * profiles/README.md.  ticks[] in the block record are diagnostics (tests/quickperf.py).
+ * profiles/README.md.  ticks[] in the block record are diagnostics (tests/tools/quickperf.py).
  */
 /* The kernels' geometry is their own constant.  One 1024-thread workgroup per CU (16 waves) is
  * what the 149 KB of LDS of a batch allow; 512 threads with 2048-row batches (two workgroups per
@@ -1471,7 +1471,7 @@ k_bwt_batch(const u8 *Tbase, u8 *Bbase, lbz_block_meta *meta, lbz_layout L, u32 
     M->seg_isa_from[seg] = S.isa_from;
     atomicAdd(&M->isa_from, hi - S.isa_from);
     atomicAdd(&M->sort_elems, hi - lo);
-    /* diagnostics, summed over the block's segments (tests/quickperf.py) */
+    /* diagnostics, summed over the block's segments (tests/tools/quickperf.py) */
     atomicAdd(&M->ticks[0], (u32)(wall_clock64() - tk0));
     for (u32 i = 0; i < 3; i++) atomicAdd(&M->ticks[3 + i], S.bc[10 + i]);   /* load, group scan (+block sorts), per-wave part */
 #ifndef COL_TICKS

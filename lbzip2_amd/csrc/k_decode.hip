@@ -233,7 +233,7 @@ __device__ __forceinline__ void dhuff_block(const u8 *in, u64 nbytes, lbz_dblock
     u32 es = 0, N = 0;
     for (;;) {
       /* The common cases run in huff_fast() (lbz_asm.h): a dependent instruction costs a lone wave ~2.5 ns
-         whatever its kind and the table lookup ~37 ns (tests/micro/chain.hip), so that loop is written by
+         whatever its kind and the table lookup ~37 ns (tests/tools/micro/chain.hip), so that loop is written by
          hand; it returns for anything else and one general step follows.                               */
       if (k < LBZ_GROUP) {
         u32 dwl = (u32)b.dw;

@@ -1,6 +1,6 @@
 #!/bin/bash
 # Ad-hoc tuning helper: build liblbzamd variants with extra -D flags into lbzip2_amd/csrc/variants/<name>.so
-# usage: tests/build_variant.sh name "-DMSD_BITS=32u ..."
+# usage: tests/tools/build_variant.sh name "-DMSD_BITS=32u ..."
 set -e
 cd /root/repo/lbzip2_amd/csrc
 mkdir -p variants/$1

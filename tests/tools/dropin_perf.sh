@@ -1,7 +1,7 @@
 #!/bin/bash
 # Ad-hoc: throughput of the drop-in work-unit interface driven from C (lbzamd_compress -w N -t -r 3),
 # codec phase only (no process start, no file I/O); the batch interface beside it.
-# usage: tests/dropin_perf.sh [MB] [threads...]
+# usage: tests/tools/dropin_perf.sh [MB] [threads...]
 cd /root/repo
 MB=${1:-450}; shift
 python - <<PY

@@ -1,5 +1,5 @@
 #!/bin/bash
-# Round-3 GPU session helper: suite, quick A/B of library variants, bench lines.  usage: tests/gpu_r3.sh <tag> [steps...]
+# Round-3 GPU session helper: suite, quick A/B of library variants, bench lines.  usage: tests/tools/gpu_r3.sh <tag> [steps...]
 cd /root/repo
 TAG=${1:-r03}; shift
 export PYTHONPATH=/root/repo:/root/repo/tests
@@ -14,17 +14,17 @@ for step in "$@"; do
       for cfg in "2 601" "1 1112" "1 556" "2 1112"; do
         set -- $cfg
         echo "== default lib streams=$1 slots=$2"
-        LBZAMD_STREAMS=$1 LBZ_SLOTS=$2 timeout 200 python tests/quickperf.py 1112 wiki 2>&1 | grep -E "MB/s"
+        LBZAMD_STREAMS=$1 LBZ_SLOTS=$2 timeout 200 python tests/tools/quickperf.py 1112 wiki 2>&1 | grep -E "MB/s"
       done
       for v in ${VARIANTS:-}; do
         echo "== variant $v streams=2 slots=601"
-        LBZ_LIB=/root/repo/lbzip2_amd/csrc/variants/$v.so LBZAMD_STREAMS=2 LBZ_SLOTS=601 timeout 200 python tests/quickperf.py 1112 wiki 2>&1 | grep -E "MB/s"
+        LBZ_LIB=/root/repo/lbzip2_amd/csrc/variants/$v.so LBZAMD_STREAMS=2 LBZ_SLOTS=601 timeout 200 python tests/tools/quickperf.py 1112 wiki 2>&1 | grep -E "MB/s"
       done
       echo "== 112 slabs (10^8 bytes)"
-      LBZ_SLOTS=112 timeout 200 python tests/quickperf.py 112 wiki 2>&1 | grep -E "MB/s"
+      LBZ_SLOTS=112 timeout 200 python tests/tools/quickperf.py 112 wiki 2>&1 | grep -E "MB/s"
       for v in ${VARIANTS:-}; do
         echo "== variant $v 112 slabs"
-        LBZ_LIB=/root/repo/lbzip2_amd/csrc/variants/$v.so LBZ_SLOTS=112 timeout 200 python tests/quickperf.py 112 wiki 2>&1 | grep -E "MB/s"
+        LBZ_LIB=/root/repo/lbzip2_amd/csrc/variants/$v.so LBZ_SLOTS=112 timeout 200 python tests/tools/quickperf.py 112 wiki 2>&1 | grep -E "MB/s"
       done;;
     bench)
       timeout 600 python bench.py > gpurun_out/${TAG}_bench.json 2> gpurun_out/${TAG}_bench.err; tail -c 4000 gpurun_out/${TAG}_bench.json; tail -3 gpurun_out/${TAG}_bench.err;;

@@ -1,5 +1,5 @@
 #!/bin/bash
-# GPU box: the -m gpu suite, smoke, and the bench lines (all with hard timeouts).  usage: tests/gpu_suite.sh <tag>
+# GPU box: the -m gpu suite, smoke, and the bench lines (all with hard timeouts).  usage: tests/tools/gpu_suite.sh <tag>
 cd /root/repo
 TAG=${1:-r02}
 export PYTHONPATH=/root/repo:/root/repo/tests

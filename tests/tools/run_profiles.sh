@@ -1,6 +1,6 @@
 #!/bin/bash
 # Round evidence on the GPU box: rocprofv3 kernel stats + PMC passes of bench.py (same command), summaries -> profiles/.
-# usage: tests/run_profiles.sh <tag> [bench args]     (writes gpurun_out/<tag>_*; copy to profiles/ and commit)
+# usage: tests/tools/run_profiles.sh <tag> [bench args]     (writes gpurun_out/<tag>_*; copy to profiles/ and commit)
 set -u
 TAG=${1:-r02}; shift
 ARGS="$*"
@@ -14,8 +14,8 @@ B="python $PWD/bench.py --steps 2 --warmup 1 --no-cpu --no-isolated --no-host --
 ( cd /tmp && timeout 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/prof_$TAG/pmc_fetch -- $B > /dev/null 2>&1 )
 ( cd /tmp && timeout 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/prof_$TAG/pmc_write -- $B > /dev/null 2>&1 )
 # the inverse path: kernel stats of one decode of the same workload's stream (3 timed passes + the size of the context)
-( cd /tmp && LBZ_DEC_CASES=$KIND:1000000000 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_$TAG/dec -- python $REPO/tests/quickdec.py > $OUT/${TAG}_decode.log 2>&1 )
+( cd /tmp && LBZ_DEC_CASES=$KIND:1000000000 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_$TAG/dec -- python $REPO/tests/tools/quickdec.py > $OUT/${TAG}_decode.log 2>&1 )
 f=$(find $OUT/prof_$TAG/dec -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && grep -E "Name|k_d" "$f" > $OUT/${TAG}_decode_kernel_stats.csv
-python tests/summarize_prof.py $OUT/prof_$TAG $OUT/$TAG 1112 3 "$KIND -9"
+python tests/tools/summarize_prof.py $OUT/prof_$TAG $OUT/$TAG 1112 3 "$KIND -9"
 ls $OUT | grep $TAG | head -30
 cat $OUT/${TAG}_kernel_stats.csv
