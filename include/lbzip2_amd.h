@@ -94,6 +94,7 @@ typedef struct lbzamd_stats {
      streams, so launches overlap and the sums exceed ms_total (LBZAMD_STREAMS=1: no overlap). */
   float ms_collect, ms_bwt, ms_mtf, ms_encode, ms_finish, ms_total;
   float ms_bwt_part, ms_bwt_batch, ms_bwt_fix;   /* the BWT stage's three kernels (sum = ms_bwt) */
+  uint32_t seq_fast_links;   /* sequential mode: blocks whose start was found through the step tables (the others walked) */
 } lbzamd_stats;
 
 /* device < 0: current device.  max_slabs: slabs resident at once (input beyond that is

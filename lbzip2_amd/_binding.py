@@ -38,7 +38,8 @@ class Stats(C.Structure):
                 ("nblocks", C.c_uint32), ("nperiodic", C.c_uint32),
                 ("ms_collect", C.c_float), ("ms_bwt", C.c_float), ("ms_mtf", C.c_float),
                 ("ms_encode", C.c_float), ("ms_finish", C.c_float), ("ms_total", C.c_float),
-                ("ms_bwt_part", C.c_float), ("ms_bwt_batch", C.c_float), ("ms_bwt_fix", C.c_float)]
+                ("ms_bwt_part", C.c_float), ("ms_bwt_batch", C.c_float), ("ms_bwt_fix", C.c_float),
+                ("seq_fast_links", C.c_uint32)]
 
 
 class Part(C.Structure):

@@ -38,23 +38,42 @@
 /* The kernels' geometry is their own constant.  One 1024-thread workgroup per CU (16 waves) is
  * what the 149 KB of LDS of a batch allow; 512 threads with 2048-row batches (two workgroups per
  * CU, the same 16 waves) measured the same.                                                */
+#ifdef LBZ_BWT_WIDE
+/* Second build of this file (k_bwt_wide.o): the partition kernel with 1024-thread workgroups, under its own name.  The
+   partition is one workgroup per block whatever the input size; when a round has fewer blocks than the device has CUs
+   (small inputs, the work-unit interface) a block is better served by sixteen waves than by four.                  */
+#define LBZ_WIDE_WG 1024
+#define k_bwt_part k_bwt_part_w
+#define k_bwt_part2 k_bwt_part2_w
+#endif
 #include "lbz_common.h"
 #undef LBZ_WG
+#ifdef LBZ_BWT_WIDE
+#define LBZ_WG LBZ_WIDE_WG
+#else
 #define LBZ_WG LBZ_BWT_WG
+#endif
 #undef LBZ_NW
 #define LBZ_NW (LBZ_WG / 64)
 #include "lbz_kernels.h"
+#if defined(LBZ_BWT_WIDE) && defined(LBZ_EMULATED)
+#undef __device__
+#define __device__ static        /* the emulator links both builds of this file into one host library */
+#endif
 
 #define SORT_IPT 4u
 #define SORT_TILE (LBZ_WG * SORT_IPT)
 #define RANK_BITS 20u                   /* n <= 900000 < 2^20 */
 #ifndef MSD_BITS
-#define MSD_BITS 24u                    /* 8-bit partition passes in HBM: 16 = two, 24 = three, 32 = four */
+#define MSD_BITS 32u                    /* 8-bit partition passes in HBM: 16 = two, 24 = three, 32 = four.  With 1024-row batches a fourth
+                                           pass pays: groups of more than a batch (HBM sorter) and of more than 256 rows (one wave's
+                                           job) become rare: k_bwt_part +6.5 ms, k_bwt_batch -11 ms per 10^9 bytes of text */
 #endif
 #define MSD_PASSES (MSD_BITS / 8u)
 #define MSD_SHIFT (64u - MSD_BITS)
 #define PART_HALO 48u
 #define BATCH_CAP (LBZ_WG * 4u)
+#define SMALL_BLOCK (LBZ_BWT_WG * 4u)    /* blocks of at most one batch of k_bwt_batch are sorted whole in LDS, without a partition */
 #ifndef COUNT_GROUP
 #define COUNT_GROUP 128u                /* groups this short are ordered by counting */
 #endif
@@ -895,7 +914,9 @@ __device__ void wave_finish_chunk(batch_lds *B, u32 cs, u32 ce, bool need_sort, 
        instead of being a pass of their own in a kernel that is bound by scattered HBM traffic.  Only once
        the block has shown that it will need k_bwt_fix (batch_process decides): text whose ties are
        shallow never pays for it.                                                                   */
+#ifndef DIAG_NO_ISA          /* timing experiments only: what the scattered rank stores cost this kernel */
     if (isa) { const u32 rk = lo + (u32)B->gh[j]; isa[idx] = ISA_ENTRY(rk, rk, 0u); }
+#endif
     if (idx == 0u) meta->bwt_idx = lo + j;
   }
   if (ntied && lane == 0u) S->bc[8] = 1u;
@@ -1315,7 +1336,7 @@ __device__ __forceinline__ void part_block(bwt_lds &S, const u8 *Tbase, lbz_bloc
     for (u32 i = 0; i < 16u; i++) M->fticks[i] = 0;
     for (u32 i = 0; i < LBZ_BWT_SEGS; i++) M->seg_m[i] = 0;
   }
-  if (n <= BATCH_CAP) return;                 /* small blocks are sorted whole by k_bwt_batch */
+  if (n <= SMALL_BLOCK) return;               /* small blocks are sorted whole by k_bwt_batch */
   const bwt_slot s = round_slot(ws, slot_bytes, ws_spill, spill_bytes, count, L, blockIdx.x);
   const u8 *T = Tbase + lbz_elem_off(L, blk);
   const u64 tk0 = wall_clock64();
@@ -1358,6 +1379,7 @@ k_bwt_part2(const u8 *Tbase, lbz_block_meta *meta, lbz_layout L, u32 first, u32 
   part_block(*reinterpret_cast<bwt_lds *>(&S_), Tbase, meta, L, first, count, ws, slot_bytes, ws_spill, spill_bytes, slabs);
 }
 
+#ifndef LBZ_BWT_WIDE
 /* ---- segments -------------------------------------------------------------------------------------------
  * After the partition the rows of a block are grouped by their top MSD_BITS and the groups are independent of
  * each other, so the rest of the sort does not need one workgroup per block: the rows are cut into up to
@@ -1594,3 +1616,4 @@ k_bwt_fixend(u8 *Bbase, lbz_block_meta *meta, lbz_layout L, u32 first, u32 count
     M->periodic = left > 0u ? 1u : 0u;
   }
 }
+#endif   /* !LBZ_BWT_WIDE */

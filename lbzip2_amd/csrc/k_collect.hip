@@ -298,6 +298,78 @@ k_collect(const u8 *in, u64 in_len, lbz_layout L, u8 *Tbase, lbz_block_meta *met
  * bytes so far, run start carried) at the first step the block might fill in.                              */
 #define SKIP_IPT 64u
 #define SKIP_TILE (LBZ_WG * SKIP_IPT)
+static_assert((SKIP_TILE & (SKIP_TILE - 1u)) == 0u, "steps are a power of two (tile tables of the sequential mode)");
+
+/* a thread's 64 bytes at x + p0 (bytes at or behind `hi` read as zero), the byte before them (valid if p0 > xlo: xlo =
+   first position of the view that may be read) and, bit i of eq: byte i equals the byte before it */
+struct skip_regs { u32 w[SKIP_IPT / 4u]; u32 prevb; u64 eq; };
+__device__ __forceinline__ void skip_load(const u8 *x, bool vec_ok, u32 p0, u32 xlo, u32 hi, skip_regs *r)
+{
+  if (vec_ok && p0 + SKIP_IPT <= hi) {
+#pragma unroll
+    for (u32 q = 0; q < SKIP_IPT / 16u; q++) {
+      const uint4 v = *reinterpret_cast<const uint4 *>(x + p0 + 16u * q);
+      r->w[4u * q] = v.x; r->w[4u * q + 1u] = v.y; r->w[4u * q + 2u] = v.z; r->w[4u * q + 3u] = v.w;
+    }
+  } else {
+#pragma unroll
+    for (u32 q = 0; q < SKIP_IPT / 4u; q++) {
+      r->w[q] = 0;
+      for (u32 j = 0; j < 4u; j++) if (p0 + 4u * q + j < hi) r->w[q] |= (u32)x[p0 + 4u * q + j] << (8u * j);
+    }
+  }
+  u32 prevb = lane_from_below(r->w[SKIP_IPT / 4u - 1u] >> 24);
+  if (lane_id() == 0u) prevb = (p0 > xlo && p0 <= hi) ? x[p0 - 1] : 0u;
+  r->prevb = prevb;
+  /* four bytes per step: zero bytes of w ^ (w shifted in by one) */
+  u64 eq = 0;
+  u32 pbyte = prevb;
+#pragma unroll
+  for (u32 q = 0; q < SKIP_IPT / 4u; q++) {
+    const u32 xw = r->w[q] ^ ((r->w[q] << 8) | pbyte);
+    const u32 nz = (((xw & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | xw) & 0x80808080u;     /* 0x80 in every non-zero byte */
+    const u32 y = (~nz & 0x80808080u) >> 7;
+    eq |= (u64)((y | (y >> 7) | (y >> 14) | (y >> 21)) & 15u) << (4u * q);
+    pbyte = r->w[q] >> 24;
+  }
+  r->eq = eq;
+}
+
+/* Bytes the thread's active positions emit: one each, one more where a run reaches its fourth byte (the count byte),
+   none for the run's bytes after that -- counted on the bit masks.  A run that comes in from the left has `lead` bytes
+   before me (rs = its start + 1) and t of mine; inside my range three continuing positions in a row mark the fourth
+   byte of a run that began here.  Only a run that could pass its 259-byte chunk inside my range is walked byte by byte. */
+__device__ __forceinline__ u32 skip_count(const skip_regs &r, u64 act, u64 heads, u32 p0, u32 rs)
+{
+  const u64 cont = act & ~heads;                      /* positions that continue the run of the byte before */
+  const u32 first = act ? (u32)__ffsll((long long)act) - 1u : 0u;
+  const bool leftrun = act && ((cont >> first) & 1ull);
+  const u64 cf = cont >> first;
+  const u32 t = leftrun ? (~cf ? (u32)__ffsll((long long)~cf) - 1u : 64u) : 0u;
+  const u32 lead = leftrun ? p0 + first - (rs - 1u) : 0u;
+  if (!leftrun || lead + t < LBZ_RUN_CAP) {
+    const u64 tm = t >= 64u ? ~0ull : ((1ull << t) - 1ull) << first;
+    const u64 inner = cont & ~tm;
+    const u64 c3 = inner & (inner << 1) & (inner << 2);
+    const u32 n3 = (u32)__popcll(c3 & ~(c3 << 1)), n4 = (u32)__popcll(c3) - n3;
+    const u32 n3l = (leftrun && lead <= 3u && lead + t > 3u) ? 1u : 0u;
+    const u32 n4l = (leftrun && lead + t > 4u) ? lead + t - (lead > 4u ? lead : 4u) : 0u;
+    return (u32)__popcll(act) + n3 + n3l - n4 - n4l;
+  }
+  u32 k = 0, nout = 0;
+  bool have = false;
+#pragma unroll
+  for (u32 i = 0; i < SKIP_IPT; i++) {
+    if ((act >> i) & 1ull) {
+      if ((heads >> i) & 1ull) { k = 0; have = true; }
+      else if (!have) { k = (p0 + i - (rs - 1u)) % LBZ_RUN_CAP; have = true; }
+      else { k++; if (k == LBZ_RUN_CAP) k = 0; }
+      nout += k < 3u ? 1u : (k == 3u ? 2u : 0u);
+    }
+  }
+  return nout;
+}
+
 __device__ void seq_skip(const u8 *x, u32 base, u32 end, u32 cap, collect_lds *S, u32 *t_out, u32 *o_out, u32 *rs_out)
 {
   const u32 tid = threadIdx.x;
@@ -306,89 +378,118 @@ __device__ void seq_skip(const u8 *x, u32 base, u32 end, u32 cap, collect_lds *S
   u32 t0 = base & ~(COL_TILE - 1u);
   for (; t0 < end; t0 += SKIP_TILE) {
     const u32 p0 = t0 + tid * SKIP_IPT;
-    u32 w[SKIP_IPT / 4u];
-    if (vec_ok && p0 + SKIP_IPT <= end) {
-#pragma unroll
-      for (u32 q = 0; q < SKIP_IPT / 16u; q++) {
-        const uint4 v = *reinterpret_cast<const uint4 *>(x + p0 + 16u * q);
-        w[4u * q] = v.x; w[4u * q + 1u] = v.y; w[4u * q + 2u] = v.z; w[4u * q + 3u] = v.w;
-      }
-    } else {
-#pragma unroll
-      for (u32 q = 0; q < SKIP_IPT / 4u; q++) {
-        w[q] = 0;
-        for (u32 j = 0; j < 4u; j++) if (p0 + 4u * q + j < end) w[q] |= (u32)x[p0 + 4u * q + j] << (8u * j);
-      }
-    }
-    u32 prevb = lane_from_below(w[SKIP_IPT / 4u - 1u] >> 24);
-    if (lane_id() == 0u) prevb = (p0 > base && p0 <= end) ? x[p0 - 1] : 0u;
-    /* bit i of eq: byte i equals the byte before it -- four bytes per step (zero bytes of w ^ (w shifted in by one)) */
-    u64 eq = 0;
-    {
-      u32 pbyte = prevb;
-#pragma unroll
-      for (u32 q = 0; q < SKIP_IPT / 4u; q++) {
-        const u32 xw = w[q] ^ ((w[q] << 8) | pbyte);
-        const u32 nz = (((xw & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | xw) & 0x80808080u;     /* 0x80 in every non-zero byte */
-        const u32 y = (~nz & 0x80808080u) >> 7;
-        eq |= (u64)((y | (y >> 7) | (y >> 14) | (y >> 21)) & 15u) << (4u * q);
-        pbyte = w[q] >> 24;
-      }
-    }
+    skip_regs r;
+    skip_load(x, vec_ok, p0, base, end, &r);
     /* my positions inside [base, end), run heads among them (the block's first byte always is one) */
     const u32 nlo = base > p0 ? (base - p0 < SKIP_IPT ? base - p0 : SKIP_IPT) : 0u;
     const u32 nhi = end > p0 ? (end - p0 < SKIP_IPT ? end - p0 : SKIP_IPT) : 0u;
     const u64 mlo = nlo >= 64u ? ~0ull : (1ull << nlo) - 1ull, mhi = nhi >= 64u ? ~0ull : (1ull << nhi) - 1ull;
     const u64 act = mhi & ~mlo;
-    u64 heads = act & ~eq;
+    u64 heads = act & ~r.eq;
     if (base >= p0 && base < p0 + SKIP_IPT) heads |= 1ull << (base - p0);
     heads &= act;
-    const u64 cont = act & ~heads;                      /* positions that continue the run of the byte before */
     const u32 lh = heads ? p0 + 64u - (u32)__clzll((long long)heads) : 0u;      /* (last head) + 1 */
     u32 emax, e_unused, tmax, t_unused;
     wg_excl_max_add(lh, 0u, &emax, &e_unused, &tmax, &t_unused, &S->sc);
-    u32 rs = emax > carry_rs ? emax : carry_rs;
-    /* Bytes my positions emit: one each, one more where a run reaches its fourth byte (the count byte), none for
-       the run's bytes after that -- counted on the bit masks.  A run that comes in from the left has `lead` bytes
-       before me and t of mine; inside my range three continuing positions in a row mark the fourth byte of a run
-       that began here.  Only a run that could pass its 259-byte chunk inside my range is walked byte by byte. */
-    u32 nout;
-    const u32 first = act ? (u32)__ffsll((long long)act) - 1u : 0u;
-    const bool leftrun = act && ((cont >> first) & 1ull);
-    const u64 cf = cont >> first;
-    const u32 t = leftrun ? (~cf ? (u32)__ffsll((long long)~cf) - 1u : 64u) : 0u;
-    const u32 lead = leftrun ? p0 + first - (rs - 1u) : 0u;
-    if (!leftrun || lead + t < LBZ_RUN_CAP) {
-      const u64 tm = t >= 64u ? ~0ull : ((1ull << t) - 1ull) << first;
-      const u64 inner = cont & ~tm;
-      const u64 c3 = inner & (inner << 1) & (inner << 2);
-      const u32 n3 = (u32)__popcll(c3 & ~(c3 << 1)), n4 = (u32)__popcll(c3) - n3;
-      const u32 n3l = (leftrun && lead <= 3u && lead + t > 3u) ? 1u : 0u;
-      const u32 n4l = (leftrun && lead + t > 4u) ? lead + t - (lead > 4u ? lead : 4u) : 0u;
-      nout = (u32)__popcll(act) + n3 + n3l - n4 - n4l;
-    } else {
-      u32 k = 0, pb = prevb;
-      bool have = false;
-      nout = 0;
-#pragma unroll
-      for (u32 i = 0; i < SKIP_IPT; i++) {
-        const u32 p = p0 + i, bi = (w[i >> 2] >> (8u * (i & 3u))) & 255u;
-        if ((act >> i) & 1ull) {
-          if ((heads >> i) & 1ull) { k = 0; have = true; }
-          else if (!have) { k = (p - (rs - 1u)) % LBZ_RUN_CAP; have = true; }
-          else { k++; if (k == LBZ_RUN_CAP) k = 0; }
-          nout += k < 3u ? 1u : (k == 3u ? 2u : 0u);
-        }
-        pb = bi;
-      }
-      (void)pb;
-    }
+    const u32 rs = emax > carry_rs ? emax : carry_rs;
+    const u32 nout = skip_count(r, act, heads, p0, rs);
     const u32 total = wg_sum(nout, &S->sc);
     if (o_base + total > cap) break;                 /* the block may end in this step: collect_pass takes over here */
     o_base += total;
     carry_rs = tmax > carry_rs ? tmax : carry_rs;
   }
   *t_out = t0; *o_out = o_base; *rs_out = carry_rs;
+}
+
+/* ---- tables of the sequential mode: what a 32 KB step of the INPUT emits, whoever's block it falls into -------------
+ * A block's tokens differ from the tokens of the input read as one piece only in the run its first byte sits in (a
+ * block starts a run afresh).  So the step totals, their prefix sums and the run start carried into every step can
+ * be computed for the whole input in parallel, ahead of the chain: a link of the chain then tokenises the stretch up
+ * to the next step boundary, finds the step its block fills in by a search in the prefix sums and makes the exact cut
+ * there -- two short passes instead of ~28 steps (k_collect_seq).  Steps are aligned to in16 = `in` rounded down to 16
+ * bytes; positions below are indices from in16 (the input's first byte has index a0 = in - in16).
+ *   k_seq_tiles   one workgroup per step: last and first run head inside, bytes emitted if the step began a run
+ *   k_seq_prefix  one workgroup: the run start carried into each step, the totals corrected for the run that
+ *                 continues into the step, exclusive prefix sums                                                  */
+__device__ __forceinline__ u64 run_emits(u64 m)          /* bytes the first m bytes of a run emit: 4 + count per 259 */
+{
+  const u64 r = m % LBZ_RUN_CAP;
+  return 5ull * (m / LBZ_RUN_CAP) + (r <= 3ull ? r : 5ull);
+}
+
+__global__ void __launch_bounds__(LBZ_WG, 4)
+k_seq_tiles(const u8 *in, u64 in_len, u32 *last_head, u32 *first_head, u32 *emits)
+{
+  __shared__ collect_lds S;
+  const u32 tid = threadIdx.x;
+  const u32 a0 = (u32)((uintptr_t)in & 15u);
+  const u64 tile = blockIdx.x;
+  const u64 lo64 = tile * SKIP_TILE;                      /* index of the step's first position */
+  const u64 total = (u64)a0 + in_len;
+  if (lo64 >= total) return;
+  /* view: the step's positions are [OFF, OFF + SKIP_TILE) of x, so that the byte before the step can be read */
+  const u32 OFF = tile ? 16u : 0u;
+  const u8 *x = in - a0 + lo64 - OFF;
+  const u32 lo = OFF + (tile ? 0u : a0);                  /* the first step begins at the input's first byte */
+  const u32 hi = OFF + (u32)(total - lo64 < SKIP_TILE ? total - lo64 : SKIP_TILE);
+  const u32 p0 = OFF + tid * SKIP_IPT;
+  skip_regs r;
+  skip_load(x, true, p0, tile ? 0u : lo, hi, &r);
+  const u32 nlo = lo > p0 ? (lo - p0 < SKIP_IPT ? lo - p0 : SKIP_IPT) : 0u;
+  const u32 nhi = hi > p0 ? (hi - p0 < SKIP_IPT ? hi - p0 : SKIP_IPT) : 0u;
+  const u64 mlo = nlo >= 64u ? ~0ull : (1ull << nlo) - 1ull, mhi = nhi >= 64u ? ~0ull : (1ull << nhi) - 1ull;
+  const u64 act = mhi & ~mlo;
+  u64 heads = act & ~r.eq;
+  if (tile == 0 && lo >= p0 && lo < p0 + SKIP_IPT) heads |= 1ull << (lo - p0);     /* the input's first byte */
+  heads &= act;
+  const u32 lh = heads ? p0 + 64u - (u32)__clzll((long long)heads) : 0u;      /* (last head) + 1 */
+  const u32 fh = heads ? p0 + (u32)__ffsll((long long)heads) - 1u : 0xFFFFFFFFu;
+  u32 emax, e_unused, tmax, t_unused;
+  wg_excl_max_add(lh, 0u, &emax, &e_unused, &tmax, &t_unused, &S.sc);
+  const u32 rs = emax > lo + 1u ? emax : lo + 1u;         /* as if a run began with the step */
+  const u32 nout = skip_count(r, act, heads, p0, rs);
+  const u32 tot = wg_sum(nout, &S.sc);
+  const u32 fmin = wg_min(fh, &S.sc);
+  if (tid == 0) {
+    last_head[tile] = tmax ? tmax - OFF : 0u;             /* (offset of the last head in the step) + 1, 0 = none */
+    first_head[tile] = fmin == 0xFFFFFFFFu ? hi - lo : fmin - lo;   /* positions in front of the first head */
+    emits[tile] = tot;
+  }
+}
+
+__global__ void __launch_bounds__(LBZ_WG, 4)
+k_seq_prefix(const u32 *last_head, const u32 *first_head, const u32 *emits, u32 ntiles, u32 a0,
+             unsigned long long *carry, unsigned long long *gpre)
+{
+  __shared__ wg_scratch sc;
+  const u32 tid = threadIdx.x;
+  u32 carry_tile = 0;          /* (last step before this chunk that holds a head) + 1 */
+  u64 run = 0;
+  for (u32 k0 = 0; k0 < ntiles; k0 += LBZ_WG) {
+    const u32 k = k0 + tid;
+    const u32 lhd = k < ntiles ? last_head[k] : 0u;
+    u32 emax, e_unused, tmax, t_unused;
+    wg_excl_max_add(lhd ? k + 1u : 0u, 0u, &emax, &e_unused, &tmax, &t_unused, &sc);
+    const u32 jj = emax > carry_tile ? emax : carry_tile;           /* step jj - 1 holds the head of the run that reaches step k */
+    u32 g = 0;
+    if (k < ntiles) {
+      /* index of that head; the input's first byte (index a0, step 0) is one, so steps k >= 1 always have one */
+      const u64 cpos = jj ? (u64)(jj - 1u) * SKIP_TILE + (last_head[jj - 1u] - 1u) : (u64)a0;
+      carry[k] = cpos;
+      const u64 t = first_head[k];                                   /* positions of step k that continue that run */
+      g = emits[k];
+      if (k > 0 && t > 0) {
+        const u64 lead = (u64)k * SKIP_TILE - cpos;
+        g = (u32)((u64)g - run_emits(t) + run_emits(lead + t) - run_emits(lead));
+      }
+    }
+    u32 tot;
+    const u32 ex = wg_excl_add(g, &tot, &sc);
+    if (k < ntiles) gpre[k] = run + ex;
+    run += tot;
+    carry_tile = tmax > carry_tile ? tmax : carry_tile;
+  }
+  if (tid == 0) gpre[ntiles] = run;
 }
 
 /* ---- -u / --sequential (compress.c:129-198, do_collect_seq): a block takes input until it is full, whatever
@@ -399,7 +500,8 @@ __device__ void seq_skip(const u8 *x, u32 base, u32 end, u32 cap, collect_lds *S
  * starts[b] = (input position of block b) + 1, 0 = not known yet; starts[0] comes from the host.            */
 __global__ void __launch_bounds__(LBZ_WG, 4)
 k_collect_seq(const u8 *in, u64 in_len, lbz_layout L, u8 *Tbase, lbz_block_meta *meta, u32 nblk,
-              unsigned long long *starts, u32 *ticket, lbz_seq_out *so, u32 slot0)
+              unsigned long long *starts, u32 *ticket, lbz_seq_out *so, u32 slot0,
+              const unsigned long long *carry, const unsigned long long *gpre, u32 ntiles)   /* tables of k_seq_prefix, or null */
 {
   __shared__ collect_lds S;
   __shared__ unsigned long long s_start;
@@ -441,15 +543,43 @@ k_collect_seq(const u8 *in, u64 in_len, lbz_layout L, u8 *Tbase, lbz_block_meta 
     }
     return;
   }
-  /* an aligned view of the input: x16 + base = in + p.  A block takes at most M / 5 runs of 259 bytes. */
-  const u32 mis = (u32)(((uintptr_t)in + p) & 15u);
+  /* an aligned view of the input: x + base = in + p.  A block takes at most M / 5 runs of 259 bytes.  With the step
+     tables the view begins at the step the block starts in (steps are aligned to `in` rounded down to 16 bytes). */
+  const u32 a0 = (u32)((uintptr_t)in & 15u);
+  const u64 j = p + a0;
+  const u64 kp = gpre ? j / SKIP_TILE : 0ull;
+  const u32 mis = gpre ? (u32)(j - kp * SKIP_TILE) : (u32)(((uintptr_t)in + p) & 15u);
   const u8 *x = in + p - mis;
   const u64 left = in_len - p;
   const u64 maxraw = (u64)L.M * 52u + 1024u;
   const u32 end = mis + (u32)(left < maxraw ? left : maxraw);
   u32 t_res, o_res, rs_res;
   __builtin_amdgcn_s_setprio(3);            /* the chain's link goes first on its SIMDs; its neighbours are off the chain */
-  seq_skip(x, mis, end, L.M, &S, &t_res, &o_res, &rs_res);    /* 64 KB steps up to where the block might end ... */
+  /* the tables apply from the first true run head behind the block's first byte: it must come before the next step */
+  const bool fast = gpre && end > SKIP_TILE && kp + 1u < ntiles && carry[kp + 1u] >= j;
+  if (fast) {
+    seq_skip(x, mis, SKIP_TILE, L.M, &S, &t_res, &o_res, &rs_res);        /* the stretch up to the step boundary: o_res bytes */
+    /* out(k) = o_res + gpre[k] - gpre[kp + 1] bytes are emitted in front of step k; the block fills in the last step
+       whose out(k) still fits -- a search over the steps that hold positions in front of `end` */
+    const u64 g0 = gpre[kp + 1u];
+    u64 klo = kp + 1u, khi = kp + (u64)((end - 1u) / SKIP_TILE);
+    if (khi > (u64)ntiles - 1u) khi = (u64)ntiles - 1u;
+    while (klo < khi) {
+      const u64 span = khi - klo + 1u, step = (span + LBZ_WG - 1u) / LBZ_WG;
+      const u64 k = klo + (u64)tid * step;
+      const u32 okv = (k <= khi && (u64)o_res + (gpre[k] - g0) <= (u64)L.M) ? tid + 1u : 0u;
+      const u32 best = wg_max(okv, &S.sc);                          /* >= 1: out(klo) fits */
+      const u64 kb = klo + (u64)(best - 1u) * step;
+      klo = kb;
+      khi = kb + step - 1u < khi ? kb + step - 1u : khi;
+      if (step == 1u) break;
+    }
+    t_res = (u32)(klo - kp) * SKIP_TILE;
+    o_res = (u32)((u64)o_res + (gpre[klo] - g0));
+    rs_res = (u32)(carry[klo] - kp * SKIP_TILE) + 1u;
+  } else {
+    seq_skip(x, mis, end, L.M, &S, &t_res, &o_res, &rs_res);    /* 32 KB steps up to where the block might end ... */
+  }
   collect_pass<false>(x, mis, end, L.M, nullptr, &S, t_res, o_res, rs_res);   /* ... and the cut itself: the successor can start */
   const u32 stop = S.bc[1];
   if (tid == 0) {
@@ -457,6 +587,7 @@ k_collect_seq(const u8 *in, u64 in_len, lbz_layout L, u8 *Tbase, lbz_block_meta 
     __atomic_store_n(&starts[b + 1u], nx + 1ull, __ATOMIC_RELEASE);
     if (b + 1u == nblk || nx >= in_len) so->next = nx;
     atomicAdd(&so->nblocks, 1u);
+    if (fast) atomicAdd(&so->nfast, 1u);
   }
   __builtin_amdgcn_s_setprio(0);
   __syncthreads();

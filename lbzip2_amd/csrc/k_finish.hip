@@ -9,6 +9,11 @@
  * block sizes plus a copy.  The fold  cc' = rotl(cc,1) ^ ~crc  is order dependent and tiny:
  * one lane walks the blocks.
  */
+#include "lbz_common.h"
+#undef LBZ_WG
+#define LBZ_WG LBZ_FINISH_WG
+#undef LBZ_NW
+#define LBZ_NW (LBZ_WG / 64)
 #include "lbz_kernels.h"
 
 
@@ -80,29 +85,34 @@ k_offsets(const lbz_block_meta *meta, u32 nblk, u32 bs100k, u32 first, u32 last,
   st->crc = cc;
 }
 
-/* one workgroup per block: byte copy into the (arbitrarily aligned) stream position */
+/* byte copy of the blocks into their (arbitrarily aligned) stream positions: a workgroup per block when `out` is device
+ * memory; when `out` is page-locked host memory the copy runs at the speed of the link, so a few small workgroups walk
+ * the blocks (grid-stride) -- sixteen-wave workgroups waiting on PCIe writes would hold the CUs the other rounds need */
 __global__ void __launch_bounds__(LBZ_WG)
 k_gather(const u8 *Obase, const lbz_block_meta *meta, lbz_layout L, const u64 *offs,
          const lbz_stream_state *st, u8 *out, u32 nslabs)
 {
-  const u32 blk = lbz_queue_block(blockIdx.x, nslabs);
-  const lbz_block_meta *m = &meta[blk];
-  if (m->n == 0u || st->err) return;
-  const u8 *src = Obase + lbz_out_off(L, blk);
-  u8 *dst = out + offs[blk];
-  const u32 len = m->out_len;
-  /* dword stores where dst is aligned; src is always 4-byte aligned */
-  const u32 head = (u32)((4u - ((uintptr_t)dst & 3u)) & 3u);
-  const u32 h = head < len ? head : len;
-  if (threadIdx.x < h) dst[threadIdx.x] = src[threadIdx.x];
-  const u32 nw = (len - h) >> 2;
-  u32 *d32 = reinterpret_cast<u32 *>(dst + h);
-  for (u32 i = threadIdx.x; i < nw; i += LBZ_WG) {
-    const u8 *s = src + h + 4u * i;
-    d32[i] = (u32)s[0] | ((u32)s[1] << 8) | ((u32)s[2] << 16) | ((u32)s[3] << 24);
+  if (st->err) return;
+  for (u32 q = blockIdx.x; q < 2u * nslabs; q += gridDim.x) {
+    const u32 blk = lbz_queue_block(q, nslabs);
+    const lbz_block_meta *m = &meta[blk];
+    if (m->n == 0u) continue;
+    const u8 *src = Obase + lbz_out_off(L, blk);
+    u8 *dst = out + offs[blk];
+    const u32 len = m->out_len;
+    /* dword stores where dst is aligned; src is always 4-byte aligned */
+    const u32 head = (u32)((4u - ((uintptr_t)dst & 3u)) & 3u);
+    const u32 h = head < len ? head : len;
+    if (threadIdx.x < h) dst[threadIdx.x] = src[threadIdx.x];
+    const u32 nw = (len - h) >> 2;
+    u32 *d32 = reinterpret_cast<u32 *>(dst + h);
+    for (u32 i = threadIdx.x; i < nw; i += blockDim.x) {
+      const u8 *s = src + h + 4u * i;
+      d32[i] = (u32)s[0] | ((u32)s[1] << 8) | ((u32)s[2] << 16) | ((u32)s[3] << 24);
+    }
+    const u32 done = h + 4u * nw;
+    if (threadIdx.x < len - done) dst[done + threadIdx.x] = src[done + threadIdx.x];
   }
-  const u32 done = h + 4u * nw;
-  if (threadIdx.x < len - done) dst[done + threadIdx.x] = src[done + threadIdx.x];
 }
 
 /* work-unit rounds: the four words a caller waits for, of the listed slabs' primary blocks, packed for one

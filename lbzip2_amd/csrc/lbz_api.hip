@@ -49,6 +49,13 @@ struct lbzamd_ctx {
   hipEvent_t ev[8] = {};
   std::vector<hipEvent_t> bev;                /* a start/end pair around every per-round launch of a chunk */
   std::vector<hipEvent_t> jev;                /* side streams -> caller's stream joins */
+  std::vector<hipEvent_t> fev;                /* a round's stream offsets are known: the next round's may follow */
+  /* host-buffer calls: every round's slabs come in on ONE copy stream, in round order at the full rate of the link (copies
+     on several streams share it and all arrive late); a short head round on a lane of its own starts the device early */
+  hipStream_t copy_q = nullptr, head_q = nullptr;
+  std::vector<hipEvent_t> cev;                /* round i's slabs are in device memory */
+  hipEvent_t head_ev = nullptr;
+  u8 *ws_head = nullptr;                      /* BWT workspaces of the head round */
   std::vector<int> bkind;                     /* which kernel each pair times (index into kms) */
   float kms[6] = { 0, 0, 0, 0, 0, 0 };       /* partition, batch, fix, mtf, encode, collect: accumulated per call */
   /* device */
@@ -61,9 +68,13 @@ struct lbzamd_ctx {
   u8 *d_in = nullptr, *d_out = nullptr;      /* staging for the host-buffer path */
   const u8 *h2d_host = nullptr;              /* host-buffer call in progress: rounds copy their own slabs in */
   bool sequential = false;                   /* -u: blocks span slab boundaries (k_collect_seq) */
+  bool out_is_host = false;                  /* host-buffer call in progress whose output is page-locked: the device writes it */
   unsigned long long *seq_starts = nullptr;  /* max_slabs + 1 chain entries, ticket, lbz_seq_out */
   u32 *seq_ticket = nullptr;
   lbz_seq_out *seq_out = nullptr;
+  u32 *seq_tab32 = nullptr;                  /* step tables of the sequential mode: last head, first head, emitted bytes per step */
+  unsigned long long *seq_tab64 = nullptr;   /* run start carried into each step, prefix sums of the emitted bytes */
+  size_t seq_tab_cap = 0;                    /* steps the tables hold */
   size_t d_in_cap = 0, d_out_cap = 0;
   /* host */
   std::vector<lbz_block_meta> h_meta;
@@ -79,9 +90,16 @@ static int ctx_free(lbzamd_ctx *c)
   (void)hipFree(c->freq); (void)hipFree(c->offs); (void)hipFree(c->meta); (void)hipFree(c->st);
   (void)hipFree(c->d_in); (void)hipFree(c->d_out);
   (void)hipFree(c->seq_starts); (void)hipFree(c->seq_ticket); (void)hipFree(c->seq_out);
+  (void)hipFree(c->seq_tab32); (void)hipFree(c->seq_tab64);
   for (auto &e : c->ev) if (e) (void)hipEventDestroy(e);
   for (auto &e : c->bev) if (e) (void)hipEventDestroy(e);
   for (auto &e : c->jev) if (e) (void)hipEventDestroy(e);
+  for (auto &e : c->fev) if (e) (void)hipEventDestroy(e);
+  for (auto &e : c->cev) if (e) (void)hipEventDestroy(e);
+  if (c->head_ev) (void)hipEventDestroy(c->head_ev);
+  if (c->copy_q) (void)hipStreamDestroy(c->copy_q);
+  if (c->head_q) (void)hipStreamDestroy(c->head_q);
+  (void)hipFree(c->ws_head);
   if (c->stream) (void)hipStreamDestroy(c->stream);
   for (auto &q : c->side) if (q) (void)hipStreamDestroy(q);
   delete c;
@@ -125,29 +143,27 @@ static int ctx_create(lbzamd_ctx **out, int device, unsigned bs100k, unsigned ma
   c->spill_bytes = (LBZ_BWT_SLOT_BYTES(c->L.cap_b) + 255u) & ~(uint64_t)255u;
   {
     const char *env = getenv("LBZAMD_STREAMS");
-    c->nstreams = env ? (unsigned)atoi(env) : 2u;
+    c->nstreams = env ? (unsigned)atoi(env) : 3u;
     if (c->nstreams < 1u) c->nstreams = 1u;
     if (c->nstreams > 8u) c->nstreams = 8u;
     if (force_streams) c->nstreams = force_streams;
   }
   if (nslots == 0) {
-    /* Slabs per round.  At least one full-size block per CU; with several streams the slabs of a
-       chunk are dealt evenly over them (rounds of equal size overlap best), as far as half of
-       the free device memory allows (a slot is 44 B per block byte, + 1/4 for the spill).   */
+    /* Slabs per round: the chunk's slabs dealt evenly over the streams (rounds of equal size overlap best), as far as
+       half of the free device memory allows (a slot is 48 B per block byte, + 1/4 for the spill).  A round of a few
+       dozen blocks already fills the device -- from k_bwt_batch on a block is LBZ_BWT_SEGS workgroups -- so there is
+       no floor beyond that.                                                                                         */
     const char *env = getenv("LBZAMD_SLOTS");
-    const unsigned cus = (unsigned)prop.multiProcessorCount * (1024u / LBZ_BWT_WG);
+    const unsigned floor_slots = 64u;
     if (env) {
       nslots = (unsigned)atoi(env);
     } else {
       nslots = (max_slabs + c->nstreams - 1u) / c->nstreams;
-      /* two streams: a slightly uneven deal (54 : 46, the shorter round is issued first and has
-         the device to itself for a moment) measured 1 % faster than an even one */
-      if (c->nstreams == 2u) nslots = (max_slabs * 27u + 49u) / 50u;
-      if (nslots < cus) nslots = cus;
+      if (nslots < floor_slots) nslots = floor_slots;
       size_t free_b = 0, total_b = 0;
       if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
         const size_t fit = free_b / 2u / ((size_t)c->nstreams * (c->slot_bytes + c->spill_bytes));
-        if (nslots > fit) nslots = fit > cus ? (unsigned)fit : cus;
+        if (nslots > fit) nslots = fit > floor_slots ? (unsigned)fit : floor_slots;
       }
     }
     if (nslots == 0) nslots = 1;
@@ -232,8 +248,8 @@ static void launch_sort(lbzamd_ctx *c, hipStream_t q, u32 first, u32 count, u32 
                         int phase /* 0 = partition, 1 = batches, 2 = deep ties */)
 {
   if (phase == 0) {
-    if (LBZ_BWT_WG >= 1024 && count > c->ncus)      /* 512-thread workgroups share a CU two by two at 128 VGPRs already */
-      hipLaunchKernelGGL(k_bwt_part2, dim3(nblk), dim3(LBZ_BWT_WG), 0, q, (const u8 *)c->T, c->meta, c->L,
+    if (count <= c->ncus)      /* fewer blocks than CUs: sixteen waves per block instead of four (k_bwt_wide.o) */
+      hipLaunchKernelGGL(k_bwt_part_w, dim3(nblk), dim3(1024), 0, q, (const u8 *)c->T, c->meta, c->L,
                          first, count, ws, (u64)c->slot_bytes, wsp, (u64)c->spill_bytes, lst);
     else
       hipLaunchKernelGGL(k_bwt_part, dim3(nblk), dim3(LBZ_BWT_WG), 0, q, (const u8 *)c->T, c->meta, c->L,
@@ -253,7 +269,20 @@ static void launch_sort(lbzamd_ctx *c, hipStream_t q, u32 first, u32 count, u32 
   }
 }
 
-static int run_chunk(lbzamd_ctx *c, const u8 *d_in, size_t len, uint32_t nsl, int upto, bool collected = false)
+/* Stream assembly of a chunk, round by round (compress.c:238-250, :291-321): as soon as a round's blocks are packed and the
+ * round before it has its offsets, the round's blocks get theirs (k_offsets continues the stream position and the CRC fold
+ * in lbz_stream_state) and are copied to their place in `out` (k_gather) -- on the round's own stream, beside the kernels of
+ * the later rounds.  `out` may be page-locked HOST memory (the host-buffer calls): the stream then crosses PCIe while the
+ * device still sorts, and nothing is left to copy at the end.                                                          */
+struct finish_plan {
+  u8 *out;
+  u64 out_cap;
+  bool first, last, body;       /* this chunk opens / closes the stream; blocks only (no header, no trailer) */
+  bool host_out;                /* `out` is page-locked host memory */
+};
+
+static int run_chunk(lbzamd_ctx *c, const u8 *d_in, size_t len, uint32_t nsl, int upto, bool collected = false,
+                     const finish_plan *fin = nullptr)
 {
   hipStream_t s = c->stream;
   HIPCHK(hipEventRecord(c->ev[0], s));
@@ -265,26 +294,70 @@ static int run_chunk(lbzamd_ctx *c, const u8 *d_in, size_t len, uint32_t nsl, in
   }
   HIPCHK(hipEventRecord(c->ev[1], s));
   if (upto >= 1) {
-    const uint32_t nrounds = (nsl + c->nslots - 1u) / c->nslots;
+    /* the rounds: slab ranges of at most nslots slabs, in slab order when the stream is assembled round by round (each
+       round continues the previous one's stream position), of equal size; a host-buffer call begins with a short round,
+       so that the device starts after 2 ms of PCIe traffic instead of waiting for a third of the input */
+    std::vector<std::pair<uint32_t, uint32_t>> plan;
+    const uint32_t head = LBZ_HEAD_SLABS;
+    bool has_head = false;
+    const bool host_in = c->h2d_host && !collected;
+    if (fin) {
+      uint32_t at = 0;
+      if (host_in && nsl > 4u * head && nsl > c->nslots) {
+        if (!c->head_q) HIPCHK(hipStreamCreate(&c->head_q));
+        if (!c->head_ev) HIPCHK(hipEventCreateWithFlags(&c->head_ev, hipEventDisableTiming));
+        if (!c->ws_head) HIPCHK(hipMalloc((void **)&c->ws_head, (size_t)head * (c->slot_bytes + c->spill_bytes)));
+        plan.push_back({ 0u, head }); at = head; has_head = true;
+      }
+      const uint32_t rem = nsl - at, nr = (rem + c->nslots - 1u) / c->nslots, per = nr ? (rem + nr - 1u) / nr : 0u;
+      for (uint32_t k = 0; k < nr; k++) {
+        const uint32_t f = at + k * per;
+        plan.push_back({ f, nsl - f < per ? nsl - f : per });
+      }
+    } else {
+      const uint32_t nr = (nsl + c->nslots - 1u) / c->nslots;
+      const bool short_last = (nsl % c->nslots) != 0u;                       /* issue the short round first */
+      for (uint32_t i = 0; i < nr; i++) {
+        const uint32_t r = short_last ? (i == 0 ? nr - 1u : i - 1u) : i;
+        const uint32_t f = r * c->nslots;
+        plan.push_back({ f, nsl - f < c->nslots ? nsl - f : c->nslots });
+      }
+    }
+    const uint32_t nrounds = (uint32_t)plan.size();
     const bool two = c->nstreams > 1 && nrounds > 1;
     if (two) for (unsigned k = 0; k + 1 < c->nstreams; k++) HIPCHK(hipStreamWaitEvent(c->side[k], c->ev[1], 0));
-    const bool short_last = (nsl % c->nslots) != 0u;                         /* issue the short round first */
-    for (uint32_t i = 0; i < nrounds; i++) {
-      const uint32_t r = short_last ? (i == 0 ? nrounds - 1u : i - 1u) : i;
-      const uint32_t first = r * c->nslots;
-      const uint32_t count = nsl - first < c->nslots ? nsl - first : c->nslots;
-      const uint32_t grid = 2u * count;
-      const unsigned lane = two ? i % c->nstreams : 0u;
-      hipStream_t q = lane ? c->side[lane - 1u] : s;
-      u8 *ws = c->ws + (size_t)lane * c->nslots * (c->slot_bytes + c->spill_bytes);
-      u8 *wsp = ws + (size_t)c->nslots * c->slot_bytes;
-      if (c->h2d_host && !collected) {
-        /* host-buffer path: the round's slabs come in on the round's stream, so the copy of one
-           round overlaps the kernels of the other stream's round */
-        const size_t o = (size_t)first * c->L.M;
-        const size_t nb = (size_t)count * c->L.M < len - o ? (size_t)count * c->L.M : len - o;
-        HIPCHK(hipMemcpyAsync(const_cast<u8 *>(d_in) + o, c->h2d_host + (d_in - c->d_in) + o, nb, hipMemcpyHostToDevice, q));
+    if (has_head) HIPCHK(hipStreamWaitEvent(c->head_q, c->ev[1], 0));
+    if (host_in) {
+      if (!c->copy_q) HIPCHK(hipStreamCreate(&c->copy_q));
+      while (c->cev.size() < nrounds) {
+        hipEvent_t e;
+        HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        c->cev.push_back(e);
       }
+      HIPCHK(hipStreamWaitEvent(c->copy_q, c->ev[1], 0));
+      for (uint32_t i = 0; i < nrounds; i++) {
+        const size_t o = (size_t)plan[i].first * c->L.M;
+        const size_t nb = (size_t)plan[i].second * c->L.M < len - o ? (size_t)plan[i].second * c->L.M : len - o;
+        HIPCHK(hipMemcpyAsync(const_cast<u8 *>(d_in) + o, c->h2d_host + (d_in - c->d_in) + o, nb, hipMemcpyHostToDevice, c->copy_q));
+        HIPCHK(hipEventRecord(c->cev[i], c->copy_q));
+      }
+    }
+    while (fin && c->fev.size() < nrounds) {
+      hipEvent_t e;
+      HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+      c->fev.push_back(e);
+    }
+    for (uint32_t i = 0; i < nrounds; i++) {
+      const uint32_t first = plan[i].first;
+      const uint32_t count = plan[i].second;
+      const uint32_t grid = 2u * count;
+      const bool is_head = has_head && i == 0;
+      const uint32_t li = has_head ? i - 1u : i;                  /* the head round does not take a lane */
+      const unsigned lane = (two && !is_head) ? li % c->nstreams : 0u;
+      hipStream_t q = is_head ? c->head_q : (lane ? c->side[lane - 1u] : s);
+      u8 *ws = is_head ? c->ws_head : c->ws + (size_t)lane * c->nslots * (c->slot_bytes + c->spill_bytes);
+      u8 *wsp = ws + (size_t)(is_head ? head : c->nslots) * c->slot_bytes;
+      if (host_in) HIPCHK(hipStreamWaitEvent(q, c->cev[i], 0));   /* the round's slabs have arrived */
       if (!collected) {
         if (timed_begin(c, &nbev, 5, q)) return -1;
         hipLaunchKernelGGL(k_collect, dim3(count), dim3(LBZ_COLLECT_WG), 0, q, d_in, (u64)len, c->L, c->T, c->meta, first, nullptr, nullptr);
@@ -307,6 +380,21 @@ static int run_chunk(lbzamd_ctx *c, const u8 *d_in, size_t len, uint32_t nsl, in
         hipLaunchKernelGGL(k_encode, dim3(grid), dim3(LBZ_WG), 0, q, (const u16 *)c->V, (const u32 *)c->freq, c->O, c->meta, c->L, first, count, nullptr);
         if (timed_end(c, &nbev, q)) return -1;
       }
+      if (fin && upto >= 3) {
+        if (i > 0) HIPCHK(hipStreamWaitEvent(q, c->fev[i - 1u], 0));
+        hipLaunchKernelGGL(k_offsets, dim3(1), dim3(LBZ_FINISH_WG), 0, q, (const lbz_block_meta *)(c->meta + 2u * (size_t)first), grid,
+                           (u32)c->bs100k, (u32)(fin->first && i == 0), (u32)(fin->last && i + 1u == nrounds), (u32)fin->body,
+                           c->offs + 2u * (size_t)first, c->st, fin->out, fin->out_cap);
+        HIPCHK(hipEventRecord(c->fev[i], q));
+        hipLaunchKernelGGL(k_gather, dim3(fin->host_out && grid > 64u ? 64u : grid), dim3(LBZ_FINISH_WG), 0, q,
+                           (const u8 *)(c->O + lbz_out_off(c->L, 2u * first)),
+                           (const lbz_block_meta *)(c->meta + 2u * (size_t)first), c->L, (const u64 *)(c->offs + 2u * (size_t)first),
+                           (const lbz_stream_state *)c->st, fin->out, count);
+      }
+    }
+    if (has_head) {
+      HIPCHK(hipEventRecord(c->head_ev, c->head_q));
+      HIPCHK(hipStreamWaitEvent(s, c->head_ev, 0));
     }
     if (two)
       for (unsigned k = 0; k + 1 < c->nstreams; k++) {
@@ -384,6 +472,7 @@ static int compress_device(lbzamd_ctx *c, const void *d_in_v, size_t len, void *
   float acc[6] = { 0, 0, 0, 0, 0, 0 };
   hipStream_t s = c->stream;
   for (float &k : c->kms) k = 0;
+  c->stats.seq_fast_links = 0;
 
   if (c->sequential) {
     /* -u / --sequential (compress.c:129-198): chunks of up to max_slabs BLOCKS; where a block starts is known
@@ -398,8 +487,26 @@ static int compress_device(lbzamd_ctx *c, const void *d_in_v, size_t len, void *
     if (c->h2d_host) {                           /* host-buffer call: the cuts are not known slab by slab, copy up front */
       HIPCHK(hipMemcpyAsync(const_cast<u8 *>(d_in), c->h2d_host, len, hipMemcpyHostToDevice, s));
     }
+    /* what every 32 KB step of the input emits, and the prefix sums: a link of the block chain then needs two short
+       passes instead of a walk over the whole block (k_collect.hip, k_seq_tiles / k_seq_prefix) */
+    const u32 a0 = (u32)((uintptr_t)d_in & 15u);
+    const size_t ntiles = len ? ((size_t)a0 + len + LBZ_SEQ_STEP - 1u) / LBZ_SEQ_STEP : 0u;
+    const bool tables = ntiles > 0 && ntiles < 0x7FFFFFFFu && !getenv("LBZAMD_SEQ_NO_TABLES");
+    if (tables) {
+      if (ntiles > c->seq_tab_cap) {
+        (void)hipFree(c->seq_tab32); (void)hipFree(c->seq_tab64); c->seq_tab32 = nullptr; c->seq_tab64 = nullptr; c->seq_tab_cap = 0;
+        HIPCHK(hipMalloc((void **)&c->seq_tab32, 3u * ntiles * sizeof(u32)));
+        HIPCHK(hipMalloc((void **)&c->seq_tab64, (2u * ntiles + 1u) * sizeof(unsigned long long)));
+        c->seq_tab_cap = ntiles;
+      }
+      hipLaunchKernelGGL(k_seq_tiles, dim3((u32)ntiles), dim3(LBZ_COLLECT_WG), 0, s, d_in, (u64)len,
+                         c->seq_tab32, c->seq_tab32 + ntiles, c->seq_tab32 + 2u * ntiles);
+      hipLaunchKernelGGL(k_seq_prefix, dim3(1), dim3(LBZ_COLLECT_WG), 0, s, (const u32 *)c->seq_tab32, (const u32 *)(c->seq_tab32 + ntiles),
+                         (const u32 *)(c->seq_tab32 + 2u * ntiles), (u32)ntiles, a0, c->seq_tab64, c->seq_tab64 + ntiles);
+    }
     uint64_t pos = 0;
     bool first = true;
+    uint32_t nfast = 0;
     do {
       const unsigned long long start0 = pos + 1ull;
       HIPCHK(hipMemsetAsync(c->seq_starts, 0, ((size_t)c->max_slabs + 2u) * sizeof(unsigned long long), s));
@@ -408,7 +515,9 @@ static int compress_device(lbzamd_ctx *c, const void *d_in_v, size_t len, void *
       HIPCHK(hipMemcpyAsync(c->seq_starts, &start0, sizeof start0, hipMemcpyHostToDevice, s));
       HIPCHK(hipEventRecord(c->ev[4], s));
       if (len) hipLaunchKernelGGL(k_collect_seq, dim3(c->max_slabs), dim3(LBZ_COLLECT_WG), 0, s, d_in, (u64)len, c->L, c->T, c->meta,
-                                  (u32)c->max_slabs, c->seq_starts, c->seq_ticket, c->seq_out, 0u);
+                                  (u32)c->max_slabs, c->seq_starts, c->seq_ticket, c->seq_out, 0u,
+                                  (const unsigned long long *)(tables ? c->seq_tab64 : nullptr),
+                                  (const unsigned long long *)(tables ? c->seq_tab64 + ntiles : nullptr), (u32)ntiles);
       HIPCHK(hipEventRecord(c->ev[5], s));
       lbz_seq_out so{};
       if (len) {
@@ -421,6 +530,7 @@ static int compress_device(lbzamd_ctx *c, const void *d_in_v, size_t len, void *
         acc[3] += t;
       }
       const uint32_t nb = so.nblocks;
+      nfast += so.nfast;
       const bool last = !len || so.next >= len;
       if (nb) {
         if (run_chunk(c, d_in, len, nb, 3, true)) return -1;
@@ -428,10 +538,10 @@ static int compress_device(lbzamd_ctx *c, const void *d_in_v, size_t len, void *
         c->nbev_used = 0;
         for (int i = 0; i <= 2; i++) HIPCHK(hipEventRecord(c->ev[i], s));
       }
-      hipLaunchKernelGGL(k_offsets, dim3(1), dim3(LBZ_WG), 0, s, (const lbz_block_meta *)c->meta, (u32)(2u * nb),
+      hipLaunchKernelGGL(k_offsets, dim3(1), dim3(LBZ_FINISH_WG), 0, s, (const lbz_block_meta *)c->meta, (u32)(2u * nb),
                          (u32)c->bs100k, (u32)first, (u32)last, 0u, c->offs, c->st, d_out, (u64)out_cap);
       if (nb)
-        hipLaunchKernelGGL(k_gather, dim3((u32)(2u * nb)), dim3(LBZ_WG), 0, s, (const u8 *)c->O,
+        hipLaunchKernelGGL(k_gather, dim3((u32)(2u * nb)), dim3(LBZ_FINISH_WG), 0, s, (const u8 *)c->O,
                            (const lbz_block_meta *)c->meta, c->L, (const u64 *)c->offs,
                            (const lbz_stream_state *)c->st, d_out, (u32)nb);
       HIPCHK(hipEventRecord(c->ev[3], s));
@@ -444,6 +554,7 @@ static int compress_device(lbzamd_ctx *c, const void *d_in_v, size_t len, void *
       if (last) break;
     } while (true);
     c->kms[5] += acc[3];
+    c->stats.seq_fast_links = nfast;
   }
   size_t done = 0;
   bool first = true;
@@ -453,17 +564,14 @@ static int compress_device(lbzamd_ctx *c, const void *d_in_v, size_t len, void *
     const size_t off = done * (size_t)M;
     const size_t clen = last ? len - off : nsl * (size_t)M;
     if (nsl) {
-      if (run_chunk(c, d_in + off, clen, (uint32_t)nsl, 3)) return -1;
+      const finish_plan fin = { d_out, (u64)out_cap, first, last, body, c->out_is_host };
+      if (run_chunk(c, d_in + off, clen, (uint32_t)nsl, 3, false, &fin)) return -1;      /* assembles the stream round by round */
     } else {
       c->nbev_used = 0;
       for (int i = 0; i <= 2; i++) HIPCHK(hipEventRecord(c->ev[i], s));
+      hipLaunchKernelGGL(k_offsets, dim3(1), dim3(LBZ_FINISH_WG), 0, s, (const lbz_block_meta *)c->meta, 0u,
+                         (u32)c->bs100k, (u32)first, (u32)last, (u32)body, c->offs, c->st, d_out, (u64)out_cap);   /* the empty stream */
     }
-    hipLaunchKernelGGL(k_offsets, dim3(1), dim3(LBZ_WG), 0, s, (const lbz_block_meta *)c->meta, (u32)(2u * nsl),
-                       (u32)c->bs100k, (u32)first, (u32)last, (u32)body, c->offs, c->st, d_out, (u64)out_cap);
-    if (nsl)
-      hipLaunchKernelGGL(k_gather, dim3((u32)(2u * nsl)), dim3(LBZ_WG), 0, s, (const u8 *)c->O,
-                         (const lbz_block_meta *)c->meta, c->L, (const u64 *)c->offs,
-                         (const lbz_stream_state *)c->st, d_out, (u32)nsl);
     HIPCHK(hipEventRecord(c->ev[3], s));
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(s));
@@ -537,14 +645,23 @@ static int compress_host(lbzamd_ctx *c, const uint8_t *in, size_t len, uint8_t *
   if (!c || !out || !out_len || (len && !in)) { g_err = "lbzamd_compress_host: bad argument"; return -1; }
   HIPCHK(hipSetDevice(c->device));
   const size_t bound = lbzamd_bound(len);
-  if (ensure_staging(c, len ? len : 1, bound)) return -1;
+  /* a page-locked output buffer (lbzamd_pinned_alloc, hipHostMalloc, torch's pin_memory) is written by the device itself,
+     round by round; anything else gets the stream through a device staging buffer and one copy at the end */
+  void *mapped = nullptr;
+  bool direct = !c->sequential && out_cap > 0 && !getenv("LBZAMD_NO_DIRECT_OUT")
+                && hipHostGetDevicePointer(&mapped, out, 0) == hipSuccess && mapped != nullptr;
+  if (!direct) (void)hipGetLastError();
+  if (ensure_staging(c, len ? len : 1, direct ? 0 : bound)) return -1;
   size_t n = 0;
   c->h2d_host = in;                           /* run_chunk copies round by round */
-  const int rc = compress_device(c, c->d_in, len, c->d_out, bound, &n, body, part);
+  c->out_is_host = direct;
+  const int rc = direct ? compress_device(c, c->d_in, len, mapped, out_cap, &n, body, part)
+                        : compress_device(c, c->d_in, len, c->d_out, bound, &n, body, part);
   c->h2d_host = nullptr;
+  c->out_is_host = false;
   if (rc) return rc;
   if (n > out_cap) { g_err = "lbzamd_compress_host: output buffer too small"; return -2; }
-  HIPCHK(hipMemcpy(out, c->d_out, n, hipMemcpyDeviceToHost));
+  if (!direct) HIPCHK(hipMemcpy(out, c->d_out, n, hipMemcpyDeviceToHost));
   *out_len = n;
   return 0;
 }
@@ -1155,7 +1272,8 @@ static int collect_again(encoder_state *e, const uint8_t *buf, size_t *buf_sz)
   HIPDIE(hipMemsetAsync(p->seq_out, 0, sizeof(lbz_seq_out), p->seq_q), "collect");
   HIPDIE(hipMemcpyAsync(p->seq_starts, &start0, sizeof start0, hipMemcpyHostToDevice, p->seq_q), "collect");
   hipLaunchKernelGGL(k_collect_seq, dim3(1), dim3(LBZ_COLLECT_WG), 0, p->seq_q, (const u8 *)e->seq_dev, (u64)(have + len), c->L, c->T, c->meta,
-                     1u, p->seq_starts, p->seq_ticket, p->seq_out, e->slab);
+                     1u, p->seq_starts, p->seq_ticket, p->seq_out, e->slab,
+                     (const unsigned long long *)nullptr, (const unsigned long long *)nullptr, 0u);
   lbz_seq_out so{};
   HIPDIE(hipMemcpyAsync(&so, p->seq_out, sizeof so, hipMemcpyDeviceToHost, p->seq_q), "collect");
   HIPDIE(hipStreamSynchronize(p->seq_q), "collect");

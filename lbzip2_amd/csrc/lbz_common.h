@@ -31,14 +31,19 @@
 #ifndef LBZ_COLLECT_WG
 #define LBZ_COLLECT_WG 512  /* k_collect's own geometry: scans and barriers, two workgroups per CU wait less on each other (-13 %) */
 #endif
+#define LBZ_HEAD_SLABS 96u  /* host-buffer calls: slabs of the short first round (the device starts after 1.5 ms of PCIe traffic) */
+#define LBZ_FINISH_WG 256   /* k_offsets / k_gather: small workgroups -- a sixteen-wave workgroup that needs a whole CU's wave slots
+                               at once waits tens of milliseconds behind the sorters' small workgroups (profiles/r03_h_host_timeline.txt) */
 #ifndef LBZ_BWT_WG
-#define LBZ_BWT_WG 512      /* the BWT kernels' own geometry: 8 waves, 2048-row batches (75 KB of LDS), two workgroups per CU --
-                               two blocks at different phases share a CU, one in its scattered-HBM phase while the other sorts in
-                               LDS: +10 % on byte-alphabet text over 1024 threads / 4096 rows (equal on the word soup) */
+#define LBZ_BWT_WG 256      /* the BWT kernels' own geometry: 4 waves, 1024-row batches (37 KB of LDS), four workgroups per CU.
+                               The sorting kernels spend 70-80 % of their wave cycles waiting (LDS round trips, workgroup
+                               barriers, gathers: profiles/r03_b_pmc_summary.json); more, smaller barrier domains per CU wait
+                               less on each other: 1024 threads -> 512: +10 % (round 2), 512 -> 256: +7 % (round 3, with a
+                               32-bit partition so that fewer groups outgrow the smaller batch) */
 #endif
 
 #ifndef LBZ_BWT_SEGS
-#define LBZ_BWT_SEGS 8u     /* segments of a block's sorted rows = workgroups per block in k_bwt_batch / k_bwt_fix* */
+#define LBZ_BWT_SEGS 16u    /* segments of a block's sorted rows = workgroups per block in k_bwt_batch / k_bwt_fix* (8: -5 %, 32: equal) */
 #endif
 
 /* Per-block record in HBM.  Blocks are numbered 2*slab (primary) and 2*slab+1 (spill). */

@@ -44,13 +44,25 @@ struct lbz_seq_out {
   u64 next;          /* input position behind the last block of this launch */
   u32 nblocks;       /* blocks that took input */
   u32 err;
+  u32 nfast;         /* blocks whose cut was found through the step tables */
 };
 __global__ void k_collect_seq(const u8 *in, u64 in_len, lbz_layout L, u8 *Tbase, lbz_block_meta *meta, u32 nblk,
-                              unsigned long long *starts, u32 *ticket, lbz_seq_out *so, u32 slot0);
+                              unsigned long long *starts, u32 *ticket, lbz_seq_out *so, u32 slot0,
+                              const unsigned long long *carry, const unsigned long long *gpre, u32 ntiles);
+/* tables of the sequential mode (k_collect.hip): per 32 KB step of the input */
+#define LBZ_SEQ_STEP (LBZ_COLLECT_WG * 64u)
+__global__ void k_seq_tiles(const u8 *in, u64 in_len, u32 *last_head, u32 *first_head, u32 *emits);
+__global__ void k_seq_prefix(const u32 *last_head, const u32 *first_head, const u32 *emits, u32 ntiles, u32 a0,
+                             unsigned long long *carry, unsigned long long *gpre);
 __global__ void k_bwt_part(const u8 *Tbase, lbz_block_meta *meta, lbz_layout L, u32 first, u32 count,
                            u8 *ws, u64 slot_bytes, u8 *ws_spill, u64 spill_bytes, const u32 *slabs);
 __global__ void k_bwt_part2(const u8 *Tbase, lbz_block_meta *meta, lbz_layout L, u32 first, u32 count,
                             u8 *ws, u64 slot_bytes, u8 *ws_spill, u64 spill_bytes, const u32 *slabs);
+/* the same kernels with 1024-thread workgroups (k_bwt.hip built a second time with LBZ_BWT_WIDE): rounds of few blocks */
+__global__ void k_bwt_part_w(const u8 *Tbase, lbz_block_meta *meta, lbz_layout L, u32 first, u32 count,
+                             u8 *ws, u64 slot_bytes, u8 *ws_spill, u64 spill_bytes, const u32 *slabs);
+__global__ void k_bwt_part2_w(const u8 *Tbase, lbz_block_meta *meta, lbz_layout L, u32 first, u32 count,
+                              u8 *ws, u64 slot_bytes, u8 *ws_spill, u64 spill_bytes, const u32 *slabs);
 /* from here on a block's sorted rows are dealt over LBZ_BWT_SEGS segment workgroups (k_bwt.hip, "segments"):
  * grid = lbz_seg_grid(nblk), nblk = blocks of the round (2 * count, or count when only primaries are listed) */
 __global__ void k_bwt_batch(const u8 *Tbase, u8 *Bbase, lbz_block_meta *meta, lbz_layout L, u32 first,

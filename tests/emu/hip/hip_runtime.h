@@ -163,6 +163,8 @@ static inline hipError_t hipFree(void *p) { free(p); return hipSuccess; }
 static inline hipError_t hipHostMalloc(void **p, size_t n, unsigned = 0) { return hipMalloc(p, n); }
 template <class T> static inline hipError_t hipHostMalloc(T **p, size_t n, unsigned f = 0) { return hipHostMalloc((void **)p, n, f); }
 static inline hipError_t hipHostFree(void *p) { free(p); return hipSuccess; }
+/* every emulated allocation is host memory; LBZ_EMU_NO_HOSTPTR makes the runtime take its staging path instead */
+static inline hipError_t hipHostGetDevicePointer(void **d, void *h, unsigned) { if (getenv("LBZ_EMU_NO_HOSTPTR")) return hipErrorInvalidValue; *d = h; return hipSuccess; }
 static inline hipError_t hipMemcpy(void *d, const void *s, size_t n, hipMemcpyKind) { memcpy(d, s, n); return hipSuccess; }
 static inline hipError_t hipMemcpyAsync(void *d, const void *s, size_t n, hipMemcpyKind, hipStream_t = nullptr) { memcpy(d, s, n); return hipSuccess; }
 static inline hipError_t hipMemset(void *d, int v, size_t n) { memset(d, v, n); return hipSuccess; }

@@ -68,6 +68,27 @@ def test_round_schedule(emu, monkeypatch):
             assert ctx.compress(data) == want, (streams, nslots, max_slabs)
 
 
+def test_host_output_paths(emu, monkeypatch):
+    """lbzamd_compress_host: a page-locked output buffer is written by the device round by round (k_gather straight into
+    host memory); any other buffer goes through the device staging copy.  Same stream either way, also when the call is
+    chunked and when the buffer is too small."""
+    data = bytes(gen("wiki", 430000, 9) + gen("runs", 60000, 2))
+    want = L.orc_compress(data, 1)
+    for no_direct in ("", "1"):
+        if no_direct:
+            monkeypatch.setenv("LBZ_EMU_NO_HOSTPTR", "1")
+        for max_slabs, nslots in ((5, 2), (2, 1)):
+            with emu.context(1, max_slabs, nslots) as ctx:
+                assert ctx.compress(data) == want, (no_direct, max_slabs, nslots)
+    monkeypatch.delenv("LBZ_EMU_NO_HOSTPTR")
+    import ctypes as C
+    with emu.context(1, 5, 2) as ctx:
+        small = C.create_string_buffer(len(want) - 7)
+        n = C.c_size_t()
+        rc = emu.lib.lbzamd_compress_host(ctx.h, C.cast(C.c_char_p(data), C.c_void_p), len(data), small, len(want) - 7, C.byref(n))
+        assert rc == -2 and b"too small" in emu.lib.lbzamd_last_error()
+
+
 def test_fuzz_slice(emu):
     """A slice of tests/fuzz_gpu.py small enough for the emulator (blocks of <= 9000 bytes)."""
     import fuzz_gpu

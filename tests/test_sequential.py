@@ -64,6 +64,36 @@ def test_edges_under_the_emulator(emu):
         assert ctx.compress(b"x" * 1000) == L.orc_compress(b"x" * 1000, 1)
 
 
+def test_step_tables_of_the_block_chain(emu, monkeypatch):
+    """The chain link through the step tables (k_seq_tiles / k_seq_prefix: what every 32 KB step of the input emits) and
+    the walk it replaces give the same cuts: text (table path), runs that cross step boundaries and block starts inside
+    long runs (the walk), a run head exactly on a step boundary, inputs shorter than a step."""
+    import random
+    rng = random.Random(7)
+    cases = [("wiki", bytes(gen("wiki", 500000, 3))), ("runs", bytes(gen("runs", 300000, 4))), ("mixed", bytes(gen("mixed", 400000, 5))),
+             ("zeros", bytes(350000)),
+             ("longruns", b"".join(bytes([rng.randrange(3)]) * rng.randrange(1, 70000) for _ in range(20))),
+             ("text+run", bytes(gen("text", 99990, 2)) + b"x" * 40000 + bytes(gen("text", 150000, 3))),
+             ("boundary", bytes(gen("text", 32768, 4)) + b"q" * 32768 + bytes(gen("text", 131072 + 5, 5))),
+             ("rand", bytes(gen("rand", 250000, 6))), ("short", b"abc" * 1000)]
+    for name, data in cases:
+        want = L.orc_compress_seq(data, 1)
+        for slabs in (2, 64):
+            with emu.context(1, slabs, 2) as ctx:
+                ctx.set_sequential(True)
+                assert ctx.compress(data) == want, (name, slabs)
+                st = ctx.stats()
+            if name in ("wiki", "mixed", "rand"):
+                assert st.seq_fast_links >= st.nblocks - 2, (name, st.seq_fast_links, st.nblocks)     # ordinary data takes the tables
+            if name == "zeros":
+                assert st.seq_fast_links <= 1          # only a block that starts exactly where the run does
+    monkeypatch.setenv("LBZAMD_SEQ_NO_TABLES", "1")
+    with emu.context(1, 8, 2) as ctx:
+        ctx.set_sequential(True)
+        assert ctx.compress(cases[0][1]) == L.orc_compress_seq(cases[0][1], 1)
+        assert ctx.stats().seq_fast_links == 0
+
+
 def test_drop_in_symbols_called_as_the_u_mode_calls_them(emu):
     """collect() re-entered on one state until the block is full (compress.c:160-170), then encode / transmit"""
     from lbzip2_amd._binding import compress_workunits_seq
