@@ -427,7 +427,8 @@ def main():
             "scaling": args.scaling, "vs_baseline": None, "dtype": "u8",
             "data": "synthetic" if "synthetic" in source else "enwik9",
             "config": {"workload": f"{source}, level -{args.level}, {nslabs} slabs of {M} B per GPU, "
-                                   f"{slabs} resident per chunk, one bzip2 block per workgroup, rounds of {nslots} slabs on two streams"
+                                   f"{slabs} resident per chunk, rounds of <= {nslots} slabs on {os.environ.get('LBZAMD_STREAMS', '3')} streams; one workgroup per block "
+                                   f"(collect, partition, MTF, coding), 16 segment workgroups per block in the sorting kernels"
                                    + ("; ONE stream gathered on rank 0 (RCCL send/recv of block bytes + 12-byte CRC partials)" if strong else ""),
                        "bytes_per_gpu": n, "level": args.level,
                        "parallelism": f"{world} slab range(s) of one input -> one stream" if strong else f"{world} independent shard(s)"},

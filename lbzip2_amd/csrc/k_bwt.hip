@@ -1334,7 +1334,7 @@ __device__ __forceinline__ void part_block(bwt_lds &S, const u8 *Tbase, lbz_bloc
     M->periodic = 0; M->rounds = 0; M->sort_elems = 0; M->isa_from = 0; M->nseg = 0;
     for (u32 i = 0; i < 8u; i++) M->ticks[i] = 0;
     for (u32 i = 0; i < 16u; i++) M->fticks[i] = 0;
-    for (u32 i = 0; i < LBZ_BWT_SEGS; i++) M->seg_m[i] = 0;
+    for (u32 i = 0; i < LBZ_BWT_MAXSEGS; i++) M->seg_m[i] = 0;
   }
   if (n <= SMALL_BLOCK) return;               /* small blocks are sorted whole by k_bwt_batch */
   const bwt_slot s = round_slot(ws, slot_bytes, ws_spill, spill_bytes, count, L, blockIdx.x);
@@ -1389,20 +1389,20 @@ k_bwt_part2(const u8 *Tbase, lbz_block_meta *meta, lbz_layout L, u32 first, u32 
  * waves of workgroups, the last one 17 % full), an input of a hundred blocks fills the chip, and a block's
  * chain of stages is short enough for the work-unit interface.  The segment workgroups of a block share its
  * workspace slot; what they share beyond that is isa[]: see k_bwt_fixr.                                       */
-__device__ __forceinline__ u32 bwt_nseg(u32 n)
+__device__ __forceinline__ u32 bwt_nseg(u32 n, u32 segs)          /* segs: the launch's workgroups per block (<= LBZ_BWT_MAXSEGS) */
 {
   const u32 p = n / (4u * BATCH_CAP);
-  return p < 1u ? 1u : (p > LBZ_BWT_SEGS ? LBZ_BWT_SEGS : p);
+  return p < 1u ? 1u : (p > segs ? segs : p);
 }
 
 /* (block of the round, segment) of this workgroup.  Hardware deals workgroup j to XCD j mod 8: the segment
  * workgroups of one block sit on ONE XCD (they share the block's text and ranks in that L2) and within 64
- * positions of each other in dispatch order.  Grid = ceil(nblk / 8) * 8 * LBZ_BWT_SEGS.                       */
-__device__ __forceinline__ bool seg_item(u32 nblk, u32 *i, u32 *seg)
+ * positions of each other in dispatch order.  Grid = ceil(nblk / 8) * 8 * segs.                                 */
+__device__ __forceinline__ bool seg_item(u32 nblk, u32 segs, u32 *i, u32 *seg)
 {
   const u32 j = blockIdx.x, k = j >> 3;
-  *i = (k / LBZ_BWT_SEGS) * 8u + (j & 7u);
-  *seg = k % LBZ_BWT_SEGS;
+  *i = (k / segs) * 8u + (j & 7u);
+  *seg = k % segs;
   return *i < nblk;
 }
 
@@ -1416,18 +1416,18 @@ __device__ u32 seg_cut(const u64 *k0, u32 x, u32 n, bwt_lds *S)
 
 /* ---- kernel 2: LDS batches of whole groups; emits BWT bytes + rows; flags deep ties ---- */
 __global__ void __launch_bounds__(LBZ_WG, 4)
-k_bwt_batch(const u8 *Tbase, u8 *Bbase, lbz_block_meta *meta, lbz_layout L, u32 first, u32 count, u32 nblk,
+k_bwt_batch(const u8 *Tbase, u8 *Bbase, lbz_block_meta *meta, lbz_layout L, u32 first, u32 count, u32 nblk, u32 segs,
             u8 *ws, u64 slot_bytes, u8 *ws_spill, u64 spill_bytes, const u32 *slabs)
 {
   __shared__ bwt_lds S;
   const u32 tid = threadIdx.x;
   u32 bi, seg;
-  if (!seg_item(nblk, &bi, &seg)) return;
+  if (!seg_item(nblk, segs, &bi, &seg)) return;
   const u32 blk = lbz_round_block(first, count, bi, slabs);
   lbz_block_meta *M = &meta[blk];
   const u32 n = M->n;
   if (n == 0u) return;
-  const u32 nseg = n <= BATCH_CAP ? 1u : bwt_nseg(n);
+  const u32 nseg = n <= BATCH_CAP ? 1u : bwt_nseg(n, segs);
   if (seg >= nseg) return;
   const bwt_slot s = round_slot(ws, slot_bytes, ws_spill, spill_bytes, count, L, bi);
   const size_t off = lbz_elem_off(L, blk);
@@ -1528,12 +1528,12 @@ __device__ __forceinline__ bwt_slot seg_view(bwt_slot s, u32 lo)
 }
 
 __global__ void __launch_bounds__(LBZ_WG, 4)
-k_bwt_fix0(const u8 *Tbase, u8 *Bbase, lbz_block_meta *meta, lbz_layout L, u32 first, u32 count, u32 nblk,
+k_bwt_fix0(const u8 *Tbase, u8 *Bbase, lbz_block_meta *meta, lbz_layout L, u32 first, u32 count, u32 nblk, u32 segs,
            u8 *ws, u64 slot_bytes, u8 *ws_spill, u64 spill_bytes, const u32 *slabs)
 {
   __shared__ bwt_lds S;
   u32 bi, seg;
-  if (!seg_item(nblk, &bi, &seg)) return;
+  if (!seg_item(nblk, segs, &bi, &seg)) return;
   const u32 blk = lbz_round_block(first, count, bi, slabs);
   lbz_block_meta *M = &meta[blk];
   const u32 n = M->n;
@@ -1553,12 +1553,12 @@ k_bwt_fix0(const u8 *Tbase, u8 *Bbase, lbz_block_meta *meta, lbz_layout L, u32 f
 }
 
 __global__ void __launch_bounds__(LBZ_WG, 4)
-k_bwt_fixr(const u8 *Tbase, u8 *Bbase, lbz_block_meta *meta, lbz_layout L, u32 first, u32 count, u32 nblk,
+k_bwt_fixr(const u8 *Tbase, u8 *Bbase, lbz_block_meta *meta, lbz_layout L, u32 first, u32 count, u32 nblk, u32 segs,
            u8 *ws, u64 slot_bytes, u8 *ws_spill, u64 spill_bytes, const u32 *slabs, u32 round)
 {
   __shared__ bwt_lds S;
   u32 bi, seg;
-  if (!seg_item(nblk, &bi, &seg)) return;
+  if (!seg_item(nblk, segs, &bi, &seg)) return;
   const u32 blk = lbz_round_block(first, count, bi, slabs);
   lbz_block_meta *M = &meta[blk];
   const u32 n = M->n;

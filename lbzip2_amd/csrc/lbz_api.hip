@@ -151,10 +151,12 @@ static int ctx_create(lbzamd_ctx **out, int device, unsigned bs100k, unsigned ma
   if (nslots == 0) {
     /* Slabs per round: the chunk's slabs dealt evenly over the streams (rounds of equal size overlap best), as far as
        half of the free device memory allows (a slot is 48 B per block byte, + 1/4 for the spill).  A round of a few
-       dozen blocks already fills the device -- from k_bwt_batch on a block is LBZ_BWT_SEGS workgroups -- so there is
-       no floor beyond that.                                                                                         */
+       dozen blocks already fills the sorting kernels -- from k_bwt_batch on a block is LBZ_BWT_SEGS workgroups. */
     const char *env = getenv("LBZAMD_SLOTS");
-    const unsigned floor_slots = 64u;
+    const unsigned floor_slots = (unsigned)prop.multiProcessorCount;    /* up to one block per CU goes as ONE round: the partition, MTF and
+                                                                           coding kernels are a workgroup per block, and a block's chain of
+                                                                           launches is what a small input waits for (two rounds of 56 blocks
+                                                                           on two streams: 26.5 ms for 10^8 bytes, one round: see DESIGN.md 6) */
     if (env) {
       nslots = (unsigned)atoi(env);
     } else {
@@ -247,6 +249,9 @@ static int timed_end(lbzamd_ctx *c, size_t *nbev, hipStream_t s)
 static void launch_sort(lbzamd_ctx *c, hipStream_t q, u32 first, u32 count, u32 nblk, u8 *ws, u8 *wsp, const u32 *lst,
                         int phase /* 0 = partition, 1 = batches, 2 = deep ties */)
 {
+  /* workgroups per block in the sorting kernels: more of them when the round has fewer blocks than the device has CUs -- the
+     caller then waits for a block's chain of launches, and every launch is as long as its longest segment */
+  const u32 segs = count <= c->ncus ? LBZ_BWT_MAXSEGS : LBZ_BWT_SEGS;
   if (phase == 0) {
     if (count <= c->ncus)      /* fewer blocks than CUs: sixteen waves per block instead of four (k_bwt_wide.o) */
       hipLaunchKernelGGL(k_bwt_part_w, dim3(nblk), dim3(1024), 0, q, (const u8 *)c->T, c->meta, c->L,
@@ -255,15 +260,15 @@ static void launch_sort(lbzamd_ctx *c, hipStream_t q, u32 first, u32 count, u32 
       hipLaunchKernelGGL(k_bwt_part, dim3(nblk), dim3(LBZ_BWT_WG), 0, q, (const u8 *)c->T, c->meta, c->L,
                          first, count, ws, (u64)c->slot_bytes, wsp, (u64)c->spill_bytes, lst);
   } else if (phase == 1) {
-    hipLaunchKernelGGL(k_bwt_batch, dim3(lbz_seg_grid(nblk)), dim3(LBZ_BWT_WG), 0, q, (const u8 *)c->T, c->B, c->meta, c->L,
-                       first, count, nblk, ws, (u64)c->slot_bytes, wsp, (u64)c->spill_bytes, lst);
+    hipLaunchKernelGGL(k_bwt_batch, dim3(lbz_seg_grid(nblk, segs)), dim3(LBZ_BWT_WG), 0, q, (const u8 *)c->T, c->B, c->meta, c->L,
+                       first, count, nblk, segs, ws, (u64)c->slot_bytes, wsp, (u64)c->spill_bytes, lst);
   } else {
-    hipLaunchKernelGGL(k_bwt_fix0, dim3(lbz_seg_grid(nblk)), dim3(LBZ_BWT_WG), 0, q, (const u8 *)c->T, c->B, c->meta, c->L,
-                       first, count, nblk, ws, (u64)c->slot_bytes, wsp, (u64)c->spill_bytes, lst);
+    hipLaunchKernelGGL(k_bwt_fix0, dim3(lbz_seg_grid(nblk, segs)), dim3(LBZ_BWT_WG), 0, q, (const u8 *)c->T, c->B, c->meta, c->L,
+                       first, count, nblk, segs, ws, (u64)c->slot_bytes, wsp, (u64)c->spill_bytes, lst);
     const u32 R = lbz_fix_rounds(c->L.M);
     for (u32 r = 0; r < R; r++)
-      hipLaunchKernelGGL(k_bwt_fixr, dim3(lbz_seg_grid(nblk)), dim3(LBZ_BWT_WG), 0, q, (const u8 *)c->T, c->B, c->meta, c->L,
-                         first, count, nblk, ws, (u64)c->slot_bytes, wsp, (u64)c->spill_bytes, lst, r);
+      hipLaunchKernelGGL(k_bwt_fixr, dim3(lbz_seg_grid(nblk, segs)), dim3(LBZ_BWT_WG), 0, q, (const u8 *)c->T, c->B, c->meta, c->L,
+                         first, count, nblk, segs, ws, (u64)c->slot_bytes, wsp, (u64)c->spill_bytes, lst, r);
     hipLaunchKernelGGL(k_bwt_fixend, dim3(nblk), dim3(LBZ_BWT_WG), 0, q, c->B, c->meta, c->L,
                        first, count, ws, (u64)c->slot_bytes, wsp, (u64)c->spill_bytes, lst);
   }

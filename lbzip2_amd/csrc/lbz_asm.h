@@ -92,8 +92,9 @@ __device__ __forceinline__ void huff_fast(unsigned long long &buf, unsigned &liv
     "s_cmp_gt_u32 %[t0], %[maxn]\n\t"
     "s_cbranch_scc1 HF_EXIT_%=\n\t"
     "v_readlane_b32 %[t1], %[L0], 0\n\t"
-    "v_mov_b32 %[vb], %[t1]\n\t"
     "v_add_u32 %[va], %[n], %[lane]\n\t"
+    "s_nop 0\n\t"                                /* 2 wait states before a VALU reads the SGPR a VALU wrote */
+    "v_mov_b32 %[vb], %[t1]\n\t"
     "v_cmp_gt_u32 vcc, %[es], %[lane]\n\t"
     "s_and_saveexec_b64 s[44:45], vcc\n\t"
     "global_store_byte %[va], %[vb], %[tt8]\n\t"
@@ -109,6 +110,7 @@ __device__ __forceinline__ void huff_fast(unsigned long long &buf, unsigned &liv
     "v_readlane_b32 %[t1], %[L0], %[sym]\n\t"
     "v_mov_b32_dpp %[vsh], %[L0] wave_shr:1 row_mask:0xf bank_mask:0xf\n\t"
     "v_cmp_ge_u32 vcc, %[sym], %[lane]\n\t"
+    "s_nop 1\n\t"                                /* VCC is an SGPR pair: the same 2 wait states */
     "v_cndmask_b32 %[L0], %[L0], %[vsh], vcc\n\t"
     "v_writelane_b32 %[L0], %[t1], 0\n\t"
     "HF_OUT_%=:\n\t"

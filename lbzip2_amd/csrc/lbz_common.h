@@ -43,8 +43,9 @@
 #endif
 
 #ifndef LBZ_BWT_SEGS
-#define LBZ_BWT_SEGS 16u    /* segments of a block's sorted rows = workgroups per block in k_bwt_batch / k_bwt_fix* (8: -5 %, 32: equal) */
+#define LBZ_BWT_SEGS 16u    /* segments of a block's sorted rows = workgroups per block in k_bwt_batch / k_bwt_fix* (8: -5 %, 32: -2 %) */
 #endif
+#define LBZ_BWT_MAXSEGS 32u /* ... and in rounds of fewer blocks than CUs, where a block's chain of launches is what the caller waits for */
 
 /* Per-block record in HBM.  Blocks are numbered 2*slab (primary) and 2*slab+1 (spill). */
 typedef struct lbz_block_meta {
@@ -65,9 +66,9 @@ typedef struct lbz_block_meta {
   /* The sorted rows of a block are cut into up to LBZ_BWT_SEGS segments at boundaries of the partition's groups; from
      k_bwt_batch on every (block, segment) is a workgroup of its own (k_bwt.hip).  Rows [seg_lo[s], seg_lo[s+1]).    */
   uint32_t nseg;
-  uint32_t seg_lo[LBZ_BWT_SEGS + 1];
-  uint32_t seg_isa_from[LBZ_BWT_SEGS];  /* k_bwt_batch wrote the ranks (isa) of the segment's rows >= this; k_bwt_fix0 fills in the rest */
-  uint32_t seg_m[LBZ_BWT_SEGS];         /* rows of the segment that are still tied (length of its list, k_bwt_fix*) */
+  uint32_t seg_lo[LBZ_BWT_MAXSEGS + 1];
+  uint32_t seg_isa_from[LBZ_BWT_MAXSEGS];  /* k_bwt_batch wrote the ranks (isa) of the segment's rows >= this; k_bwt_fix0 fills in the rest */
+  uint32_t seg_m[LBZ_BWT_MAXSEGS];         /* rows of the segment that are still tied (length of its list, k_bwt_fix*) */
   uint32_t ticks[8];   /* wall_clock64 ticks of k_bwt_part / k_bwt_batch phases (diagnostic) */
   uint32_t fticks[16];  /* wall_clock64 ticks of k_bwt_fix phases (diagnostic) */
   uint8_t  inuse[256]; /* used-byte map (encode.c:63) */

@@ -66,14 +66,14 @@ __global__ void k_bwt_part2_w(const u8 *Tbase, lbz_block_meta *meta, lbz_layout 
 /* from here on a block's sorted rows are dealt over LBZ_BWT_SEGS segment workgroups (k_bwt.hip, "segments"):
  * grid = lbz_seg_grid(nblk), nblk = blocks of the round (2 * count, or count when only primaries are listed) */
 __global__ void k_bwt_batch(const u8 *Tbase, u8 *Bbase, lbz_block_meta *meta, lbz_layout L, u32 first,
-                            u32 count, u32 nblk, u8 *ws, u64 slot_bytes, u8 *ws_spill, u64 spill_bytes, const u32 *slabs);
+                            u32 count, u32 nblk, u32 segs, u8 *ws, u64 slot_bytes, u8 *ws_spill, u64 spill_bytes, const u32 *slabs);
 __global__ void k_bwt_fix0(const u8 *Tbase, u8 *Bbase, lbz_block_meta *meta, lbz_layout L, u32 first,
-                           u32 count, u32 nblk, u8 *ws, u64 slot_bytes, u8 *ws_spill, u64 spill_bytes, const u32 *slabs);
+                           u32 count, u32 nblk, u32 segs, u8 *ws, u64 slot_bytes, u8 *ws_spill, u64 spill_bytes, const u32 *slabs);
 __global__ void k_bwt_fixr(const u8 *Tbase, u8 *Bbase, lbz_block_meta *meta, lbz_layout L, u32 first,
-                           u32 count, u32 nblk, u8 *ws, u64 slot_bytes, u8 *ws_spill, u64 spill_bytes, const u32 *slabs, u32 round);
+                           u32 count, u32 nblk, u32 segs, u8 *ws, u64 slot_bytes, u8 *ws_spill, u64 spill_bytes, const u32 *slabs, u32 round);
 __global__ void k_bwt_fixend(u8 *Bbase, lbz_block_meta *meta, lbz_layout L, u32 first, u32 count,
                              u8 *ws, u64 slot_bytes, u8 *ws_spill, u64 spill_bytes, const u32 *slabs);
-static inline u32 lbz_seg_grid(u32 nblk) { return (nblk + 7u) / 8u * 8u * LBZ_BWT_SEGS; }
+static inline u32 lbz_seg_grid(u32 nblk, u32 segs) { return (nblk + 7u) / 8u * 8u * segs; }
 /* deep-tie rounds a block of up to M rows can need: depths 8 << r < M (keys hold at least 8 symbols) */
 static inline u32 lbz_fix_rounds(u32 M) { u32 r = 0; while ((8ull << r) < M) r++; return r; }
 __global__ void k_mtf(const u8 *Bbase, u8 *Rbase, u16 *Vbase, u32 *freq_out, lbz_block_meta *meta, lbz_layout L, u32 first, u32 count, const u32 *slabs);

@@ -57,6 +57,16 @@ def test_streams_multi_slab_spill_chunked(emu):
     assert emu.compress(b"", 9) == L.orc_compress(b"", 9)
 
 
+def test_rounds_of_many_and_of_few_blocks(emu):
+    """Rounds with more blocks than the (emulated, 8-CU) device has CUs take 16 segment workgroups per block and the
+    256-thread partition; smaller rounds 32 and the 1024-thread partition (lbz_api.hip: launch_sort).  Same stream."""
+    data = bytes(gen("wiki", 1_130_000, 6))                       # 12 slabs at -1
+    want = L.orc_compress(data, 1)
+    for max_slabs, nslots in ((12, 12), (12, 4)):
+        with emu.context(1, max_slabs, nslots) as ctx:
+            assert ctx.compress(data) == want, (max_slabs, nslots)
+
+
 def test_round_schedule(emu, monkeypatch):
     """Rounds of nslots slabs (short last round issued first, slot sets per stream, spill blocks
     riding with their primaries): the stream must not depend on the schedule."""
