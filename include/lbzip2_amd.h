@@ -175,6 +175,11 @@ void lbzamd_ddestroy(lbzamd_dctx *ctx);
 /* 0 ok; -1 bad argument / HIP error; -2 output buffer too small (*out_len = bytes needed);
  * -3 malformed stream or CRC mismatch (lbzamd_last_error() says which block).                        */
 int  lbzamd_decompress_device(lbzamd_dctx *ctx, const void *d_in, size_t len, void *d_out, size_t out_cap, size_t *out_len);
+/* For callers that do not know the decoded size: ONE pass, the result in a malloc'ed buffer (*out, release with
+ * lbzamd_free).  (lbzamd_decompress_host with out_cap too small returns -2 and the size AFTER decoding every block;
+ * calling it again decodes them again.)  Same return codes otherwise.                                             */
+int  lbzamd_decompress_alloc(lbzamd_dctx *ctx, const uint8_t *in, size_t len, uint8_t **out, size_t *out_len);
+void lbzamd_free(void *p);
 int  lbzamd_decompress_host(lbzamd_dctx *ctx, const uint8_t *in, size_t len, uint8_t *out, size_t out_cap, size_t *out_len);
 int  lbzamd_dget_stats(lbzamd_dctx *ctx, lbzamd_dstats *st);
 

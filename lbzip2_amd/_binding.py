@@ -24,6 +24,7 @@ EXPORTS = [
     "lbzamd_compress_device_body", "lbzamd_compress_host_body", "lbzamd_fold_parts",
     "lbzamd_pinned_alloc", "lbzamd_pinned_free", "lbzamd_device_count",
     "lbzamd_dcreate", "lbzamd_ddestroy", "lbzamd_decompress_device", "lbzamd_decompress_host", "lbzamd_dget_stats",
+    "lbzamd_decompress_alloc", "lbzamd_free",
 ]
 
 
@@ -122,6 +123,10 @@ class Library:
         lib.lbzamd_decompress_device.restype = C.c_int
         lib.lbzamd_decompress_host.argtypes = [vp, vp, sz, vp, sz, szp]
         lib.lbzamd_decompress_host.restype = C.c_int
+        lib.lbzamd_decompress_alloc.argtypes = [vp, vp, sz, C.POINTER(C.POINTER(C.c_uint8)), szp]
+        lib.lbzamd_decompress_alloc.restype = C.c_int
+        lib.lbzamd_free.argtypes = [vp]
+        lib.lbzamd_free.restype = None
         lib.lbzamd_dget_stats.argtypes = [vp, C.POINTER(DStats)]
         lib.lbzamd_dget_stats.restype = C.c_int
         lib.lbzamd_bound.argtypes = [sz]
@@ -371,11 +376,15 @@ class Decoder:
     def decompress(self, data, out_cap=None):
         data = bytes(data)
         n = C.c_size_t()
-        if out_cap is None:                                   # size pass: everything but the output copy
-            rc = self.L.lib.lbzamd_decompress_host(self.h, data, len(data), None, 0, C.byref(n))
-            if rc not in (0, -2):
-                raise LbzError("lbzamd_decompress_host: " + self.L.error())
-            out_cap = n.value
+        if out_cap is None:                                   # size unknown: one pass, the library allocates
+            p = C.POINTER(C.c_uint8)()
+            rc = self.L.lib.lbzamd_decompress_alloc(self.h, data, len(data), C.byref(p), C.byref(n))
+            if rc:
+                raise LbzError("lbzamd_decompress_alloc: " + self.L.error())
+            try:
+                return C.string_at(p, n.value)
+            finally:
+                self.L.lib.lbzamd_free(p)
         out = C.create_string_buffer(max(1, out_cap))
         rc = self.L.lib.lbzamd_decompress_host(self.h, data, len(data), out, out_cap, C.byref(n))
         if rc:

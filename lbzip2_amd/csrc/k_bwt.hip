@@ -93,6 +93,14 @@
 #ifndef REFINE_ROUNDS
 #define REFINE_ROUNDS 12u                /* in-LDS refinements of a batch before rows are left to the doubling */
 #endif
+#ifndef DEEP_REFINE
+#define DEEP_REFINE 0u                   /* refinements every tied run gets in k_bwt_batch whatever the budget says (0 or 1): with 1 the
+                                            block leaves k_bwt_batch sorted to depth 2 S and the doubling starts at h = 2 S -- its first
+                                            round, the one over two thirds of the rows of a text block, is never run.  Measured (round 3,
+                                            same box, 10^9 bytes): wiki 6.57 GB/s with 1 against 6.75 with 0 (k_bwt_batch +71 ms of summed
+                                            launch time, the rounds -59), tar 6.78 against 6.61, mixed 6.79 against 6.74: a tied-row round
+                                            costs about the same on either side of the kernel boundary, so the default stays 0 */
+#endif
 #define TIE_FLAG 0x80000000u
 /* a suffix-array / tie-list entry: rotation index (n < 2^20) | dense code of the byte before it << 20 | TIE_FLAG.
    The byte rides along so that a row that becomes unique needs no look-up in the text.          */
@@ -140,7 +148,7 @@ struct bwt_lds {
   wg_scratch sc;
   u32 bc[16];
   u32 isa_from, tied0;                /* k_bwt_batch: rows from isa_from on get their rank written with them; tied0 = rows tied on their first key so far */
-  u32 budget, pad_;                   /* k_bwt_batch: tied-row rounds this segment may spend on in-LDS refinement */
+  u32 budget, shallow;                /* k_bwt_batch: tied-row rounds this segment may spend on in-LDS refinement; ties were left at depth S */
   u32 dbg[4];                         /* LDS_SORT_TICKS: whole-workgroup batch sorts (count, ticks), oversized groups (count, ticks) */
   u8 cmap[256];                       /* byte -> dense code */
   u8 inv[256];                        /* dense code -> byte */
@@ -884,11 +892,16 @@ __device__ void wave_finish_chunk(batch_lds *B, u32 cs, u32 ce, bool need_sort, 
   const u64 tw1 = wall_clock64();
   /* a block that keeps tying (isa != nullptr: batch_process has switched the rank emission on) goes through
      k_bwt_fix whatever is refined here, and a tied-row round costs the same on either side: skip it */
-  for (u32 r = 0; r < REFINE_ROUNDS && ntied && before && !isa; r++) {
-    /* block-wide budget of tied-row rounds: a block that has burnt n/8 of them is a repetitive
-       one that will need the doubling anyway -- stop refining its remaining chunks */
-    if ((u32)__builtin_amdgcn_readfirstlane((int)S->bc[9]) > S->budget) break;
-    if (lane == 0u) atomicAdd(&S->bc[9], ntied);
+  u32 rounds_done = 0;
+  for (u32 r = 0; r < REFINE_ROUNDS && ntied; r++) {
+    if (r >= DEEP_REFINE) {                     /* the first DEEP_REFINE rounds are unconditional: see DEEP_REFINE */
+      if (isa || !before) break;
+      /* block-wide budget of tied-row rounds: a block that has burnt n/8 of them is a repetitive
+         one that will need the doubling anyway -- stop refining its remaining chunks */
+      if ((u32)__builtin_amdgcn_readfirstlane((int)S->bc[9]) > S->budget) break;
+      if (lane == 0u) atomicAdd(&S->bc[9], ntied);
+    }
+    rounds_done++;
     /* every tied rotation trades its key for its next sy symbols; its run is re-sorted on them
        (counting for short runs, a per-run radix sort otherwise) and split where they differ */
     for (u32 j = cs + lane; j < ce; j += 64u)
@@ -919,7 +932,7 @@ __device__ void wave_finish_chunk(batch_lds *B, u32 cs, u32 ce, bool need_sort, 
 #endif
     if (idx == 0u) meta->bwt_idx = lo + j;
   }
-  if (ntied && lane == 0u) S->bc[8] = 1u;
+  if (ntied && lane == 0u) { S->bc[8] = 1u; if (rounds_done < DEEP_REFINE || DEEP_REFINE == 0u) S->shallow = 1u; }
   if (lane == 0u) {
     const u64 tw2 = wall_clock64();
     atomicAdd(&S->bc[13], (u32)(tw2 - tw0));
@@ -1088,7 +1101,7 @@ __device__ void emit_tied_rows(u8 *bwt, bwt_slot s, bwt_lds *S, u32 lo, u32 hi)
     s.sa[j] = SA_ENTRY(v & 0x00FFFFFFu, v >> 24) | (j > lo ? TIE_FLAG : 0u);
     s.isa[v & 0x00FFFFFFu] = ISA_ENTRY(lo, lo, 0u);
   }
-  if (threadIdx.x == 0) S->bc[8] = 1u;
+  if (threadIdx.x == 0) { S->bc[8] = 1u; S->shallow = 1u; }
   __syncthreads();
 }
 
@@ -1314,7 +1327,7 @@ struct part_lds {
   wg_scratch sc;
   u32 bc[16];
   u32 isa_from, tied0;
-  u32 budget, pad_;
+  u32 budget, shallow;
   u32 dbg[4];
   u8 cmap[256];
   u8 inv[256];
@@ -1331,7 +1344,7 @@ __device__ __forceinline__ void part_block(bwt_lds &S, const u8 *Tbase, lbz_bloc
   const u32 n = meta[blk].n;
   if (tid == 0) {                             /* the sorter's part of the block record: the segment workgroups add to it */
     lbz_block_meta *M = &meta[blk];
-    M->periodic = 0; M->rounds = 0; M->sort_elems = 0; M->isa_from = 0; M->nseg = 0;
+    M->periodic = 0; M->rounds = 0; M->sort_elems = 0; M->isa_from = 0; M->nseg = 0; M->deep_start = DEEP_REFINE ? 1u : 0u;
     for (u32 i = 0; i < 8u; i++) M->ticks[i] = 0;
     for (u32 i = 0; i < 16u; i++) M->fticks[i] = 0;
     for (u32 i = 0; i < LBZ_BWT_MAXSEGS; i++) M->seg_m[i] = 0;
@@ -1445,7 +1458,7 @@ k_bwt_batch(const u8 *Tbase, u8 *Bbase, lbz_block_meta *meta, lbz_layout L, u32 
     hi = seg + 1u == nseg ? n : seg_cut(s.k0, (u32)((u64)(seg + 1u) * n / nseg), n, &S);
   }
   if (tid == 0) {
-    S.isa_from = hi; S.tied0 = 0; S.budget = (hi - lo) / REFINE_BUDGET_DIV;
+    S.isa_from = hi; S.tied0 = 0; S.budget = (hi - lo) / REFINE_BUDGET_DIV; S.shallow = 0;
     for (u32 i = 0; i < 4; i++) S.dbg[i] = 0;
     M->seg_lo[seg] = lo;
     if (seg + 1u == nseg) M->seg_lo[nseg] = n;
@@ -1490,6 +1503,7 @@ k_bwt_batch(const u8 *Tbase, u8 *Bbase, lbz_block_meta *meta, lbz_layout L, u32 
   __syncthreads();
   if (tid == 0) {
     if (S.bc[8]) atomicMax(&M->periodic, 2u);  /* 2 = ties left for the deep-tie rounds */
+    if (S.shallow) M->deep_start = 0;          /* some of them only S symbols deep: the block needs the round at h = S too */
     M->seg_isa_from[seg] = S.isa_from;
     atomicAdd(&M->isa_from, hi - S.isa_from);
     atomicAdd(&M->sort_elems, hi - lo);
@@ -1564,7 +1578,7 @@ k_bwt_fixr(const u8 *Tbase, u8 *Bbase, lbz_block_meta *meta, lbz_layout L, u32 f
   const u32 n = M->n;
   if (n < 2u || M->periodic != 2u || seg >= M->nseg) return;
   const u32 m = M->seg_m[seg];
-  if (m == 0u) return;
+  if (m == 0u || round < M->deep_start) return;
   const u64 tk0 = wall_clock64();
   const u32 lo = M->seg_lo[seg];
   const bwt_slot s = seg_view(round_slot(ws, slot_bytes, ws_spill, spill_bytes, count, L, bi), lo);

@@ -759,6 +759,7 @@ struct lbzamd_dctx {
   u8 *d_in = nullptr, *d_out = nullptr;
   size_t d_in_cap = 0, d_out_cap = 0;
   uint32_t marks_cap = 0;
+  bool grow_out = false;                     /* lbzamd_decompress_alloc: the output buffer (d_out) grows with what the blocks turn out to hold */
   lbzamd_dstats stats{};
 };
 
@@ -951,6 +952,20 @@ extern "C" int lbzamd_decompress_device(lbzamd_dctx *c, const void *d_in_v, size
       nblocks++; stream_blocks++;
     }
     if (last_batch && in_stream) { g_err = "lbzamd_decompress: stream without end-of-stream marker (truncated?)"; return -3; }
+    if (c->grow_out && nb && total > out_cap) {
+      /* the size is known only now (the blocks of this pass are decoded, their bytes not yet in place): a larger buffer,
+         sized for the passes still to come as the blocks so far suggest, keeps what the earlier passes have written */
+      const uint64_t prev = hb[b0].out_off;
+      uint64_t want = total + total / 16u + 4096u;
+      if (b0 + nb < hb.size()) want = (uint64_t)((double)total * (double)hb.size() / (double)(b0 + nb) * 1.0625) + 4096u;
+      u8 *bigger = nullptr;
+      HIPCHK(hipMalloc((void **)&bigger, want + 256u));
+      if (prev) HIPCHK(hipMemcpyAsync(bigger, c->d_out, prev, hipMemcpyDeviceToDevice, q));
+      HIPCHK(hipStreamSynchronize(q));
+      (void)hipFree(c->d_out);
+      c->d_out = bigger; c->d_out_cap = want;
+      d_out = bigger; out_cap = want;
+    }
     if (nb && total <= out_cap && d_out) {
       HIPCHK(hipMemcpyAsync(c->blocks, hb.data() + b0, nb * sizeof(lbz_dblock), hipMemcpyHostToDevice, q));
       HIPCHK(hipEventRecord(c->ev[5], q));
@@ -1006,6 +1021,41 @@ extern "C" int lbzamd_decompress_host(lbzamd_dctx *c, const uint8_t *in, size_t 
   if (*out_len) HIPCHK(hipMemcpy(out, c->d_out, *out_len, hipMemcpyDeviceToHost));
   return 0;
 }
+
+/* One pass for callers that do not know the decoded size: the device output buffer grows between the block passes, the
+ * result comes back in a malloc'ed buffer (lbzamd_free).  lbzamd_decompress_host with a buffer that turns out too small
+ * has decoded every block by the time it knows, and the second call decodes them again.                              */
+extern "C" int lbzamd_decompress_alloc(lbzamd_dctx *c, const uint8_t *in, size_t len, uint8_t **out, size_t *out_len)
+{
+  if (!c || !out || !out_len || (len && !in)) { g_err = "lbzamd_decompress_alloc: bad argument"; return -1; }
+  HIPCHK(hipSetDevice(c->device));
+  *out = nullptr; *out_len = 0;
+  if (len + 16 > c->d_in_cap) {
+    (void)hipFree(c->d_in); c->d_in = nullptr; c->d_in_cap = 0;
+    HIPCHK(hipMalloc((void **)&c->d_in, len + 256));
+    c->d_in_cap = len + 16;
+  }
+  if (!c->d_out_cap) {
+    const size_t guess = 4u * len + 65536u;
+    HIPCHK(hipMalloc((void **)&c->d_out, guess + 256));
+    c->d_out_cap = guess;
+  }
+  HIPCHK(hipMemcpy(c->d_in, in, len, hipMemcpyHostToDevice));
+  c->grow_out = true;
+  size_t n = 0;
+  const int rc = lbzamd_decompress_device(c, c->d_in, len, c->d_out, c->d_out_cap, &n);
+  c->grow_out = false;
+  if (rc) return rc;
+  uint8_t *h = (uint8_t *)malloc(n ? n : 1);
+  if (!h) { g_err = "lbzamd_decompress_alloc: out of host memory"; return -1; }
+  if (n) {
+    const hipError_t e = hipMemcpy(h, c->d_out, n, hipMemcpyDeviceToHost);
+    if (e != hipSuccess) { free(h); return fail_msg("hipMemcpy", e); }
+  }
+  *out = h; *out_len = n;
+  return 0;
+}
+extern "C" void lbzamd_free(void *p) { free(p); }
 
 extern "C" int lbzamd_dget_stats(lbzamd_dctx *c, lbzamd_dstats *st)
 {

@@ -285,7 +285,7 @@ int main(int argc, char **argv)
     else { fprintf(stderr, "usage: %s [-1..-9] [-w N] [-t] [-r N] < in > out.bz2 | -f IN -o OUT [-c slabs] [-p pipelines] [-g devices] | -d [-f IN] [-o OUT]\n", argv[0]); return 2; }
   }
   if (decompress) {
-    /* whole file in, every block decoded at once (lbzamd_decompress_host), whole file out */
+    /* whole file in, every block decoded at once (lbzamd_decompress_alloc), whole file out */
     FILE *fi = in_path && strcmp(in_path, "-") ? fopen(in_path, "rb") : stdin;
     FILE *fo = out_path && strcmp(out_path, "-") ? fopen(out_path, "wb") : stdout;
     if (!fi || !fo) { perror("lbzamd_compress -d"); return 1; }
@@ -295,24 +295,21 @@ int main(int argc, char **argv)
     const double t0 = now_s();
     unsigned maxb = (unsigned)(zlen / 20000 + 8);
     if (lbzamd_dcreate(&d, -1, maxb > 2400 ? 2400 : maxb)) { fprintf(stderr, "lbzamd: %s\n", lbzamd_last_error()); return 1; }
-    size_t need = 0;
-    int rc = lbzamd_decompress_host(d, z, zlen, NULL, 0, &need);         /* size pass: everything but the output copy */
-    if (rc != 0 && rc != -2) { fprintf(stderr, "lbzamd: %s\n", lbzamd_last_error()); return 1; }
-    unsigned char *out = malloc(need ? need : 1);
+    unsigned char *out = NULL;
     size_t n = 0;
     const double t1 = now_s();
-    if (lbzamd_decompress_host(d, z, zlen, out, need, &n)) { fprintf(stderr, "lbzamd: %s\n", lbzamd_last_error()); return 1; }
+    if (lbzamd_decompress_alloc(d, z, zlen, &out, &n)) { fprintf(stderr, "lbzamd: %s\n", lbzamd_last_error()); return 1; }   /* one pass: the output buffer grows */
     const double t2 = now_s();
     if (timing) {
       lbzamd_dstats ds;
       lbzamd_dget_stats(d, &ds);
-      fprintf(stderr, "decode: %zu B -> %zu B, %u blocks in %u stream(s); context + size pass %.3f s, decode %.3f s = %.0f MB/s (device: scan %.1f blocks %.1f emit %.1f ms)\n",
+      fprintf(stderr, "decode: %zu B -> %zu B, %u blocks in %u stream(s); context %.3f s, decode %.3f s = %.0f MB/s (device: scan %.1f blocks %.1f emit %.1f ms)\n",
               zlen, n, ds.nblocks, ds.nstreams, t1 - t0, t2 - t1, (double)n / (t2 - t1) / 1e6, ds.ms_scan, ds.ms_blocks, ds.ms_emit);
     }
     if (fwrite(out, 1, n, fo) != n || fflush(fo)) { perror("lbzamd_compress -d: write"); return 1; }
     if (fo != stdout && fclose(fo)) { perror("lbzamd_compress -d: close"); return 1; }
     lbzamd_ddestroy(d);
-    free(out); free(z);
+    lbzamd_free(out); free(z);
     return 0;
   }
   if (in_path || out_path) {

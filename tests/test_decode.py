@@ -109,6 +109,20 @@ def test_more_blocks_than_the_context_holds(emu):
     assert st.nblocks == 7 and st.nstreams == 1 and st.n_out == len(d)
 
 
+def test_one_pass_when_the_size_is_unknown(emu):
+    """lbzamd_decompress_alloc (what Decoder.decompress(bytes) calls): the device output buffer grows between the block
+    passes -- also when the blocks come in several passes and the first guess (4 x the compressed size) is far too small"""
+    d = bytes(100_000) * 9 + bytes(gen("wiki", 120000, 4))              # ratio > 1000 on the zeros
+    z = L.orc_compress(d, 1)
+    for max_blocks in (64, 3):
+        with emu.decoder(max_blocks) as dec:
+            assert dec.decompress(z) == d
+            assert dec.decompress(L.orc_compress(b"", 9)) == b""
+            assert dec.decompress(z, out_cap=len(d)) == d                    # the caller's buffer, exact size
+            with pytest.raises(LbzError):
+                dec.decompress(z, out_cap=len(d) - 1)
+
+
 def test_damaged_streams_are_refused(emu):
     z = bytearray(L.orc_compress(bytes(gen("text", 120000, 6)), 1))
     for mutate in (lambda b: b.__setitem__(len(b) // 2, b[len(b) // 2] ^ 0x10),       # payload bit: block CRC or code error
