@@ -107,7 +107,12 @@ void lbzamd_destroy(lbzamd_ctx *ctx);
 const char *lbzamd_last_error(void);
 
 /* d_in/d_out are device pointers.  Writes a complete .bz2 stream; *out_len = its size.
- * Work is enqueued on the context's stream and waited for.  0 on success.              */
+ * Work is enqueued on the context's stream and waited for.  0 on success.
+ * Alignment: none required, but the kernels read whole 16-byte vectors (the decoder: 4-byte words) around the
+ * buffer's ends -- up to 15 bytes in front of d_in and up to 15 behind d_in + len may be READ (their values are
+ * masked out, nothing outside [d_out, d_out + out_cap) is written).  Base pointers of hipMalloc / torch allocations
+ * satisfy this by themselves; a pointer into the middle of an allocation does too; one that ends exactly at the last
+ * byte of an allocation next to an unmapped page does not -- leave 16 bytes of slack there.                          */
 /* The reference's -u / --sequential (main.c; compress.c:129-198 do_collect_seq): with on != 0 the context's
  * following calls cut blocks where they are FULL (a continuous RLE1 over the input, bzip2's own blocking) instead
  * of at every bs100k * 100000 input bytes; the stream is byte-identical to `lbzip2 -u`.  A block's start is known

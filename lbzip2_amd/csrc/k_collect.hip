@@ -116,6 +116,26 @@ __device__ u32 wg_crc32(const u8 *x, u32 a, u32 b, u32 xlen, collect_lds *S)
   return r;
 }
 
+/* The count byte of a run (encode.c:247-275): how many bytes equal to `byte` follow from position q on, at most 255 and
+ * not past `end`.  Byte by byte up to an 8-byte boundary, then eight at a time -- a byte-serial loop is 255 dependent
+ * loads (127 us on a zero-filled slab, measured: the tile's other threads wait at the next barrier), this one 32.     */
+__device__ __forceinline__ u32 run_count(const u8 *x, u32 q, u32 end, u8 byte, bool aligned_view)
+{
+  const u32 lim = end - q < 255u ? end - q : 255u;
+  u32 c = 0;
+  while (c < lim && ((q + c) & 7u) != 0u) { if (x[q + c] != byte) return c; c++; }
+  if (aligned_view) {                                  /* x is 16-byte aligned: q + c is an 8-byte boundary of the allocation */
+    const u64 pat = 0x0101010101010101ull * (u64)byte;
+    while (c + 8u <= lim) {
+      const u64 d = *reinterpret_cast<const u64 *>(x + q + c) ^ pat;
+      if (d) return c + (u32)(__ffsll((long long)d) - 1) / 8u;
+      c += 8u;
+    }
+  }
+  while (c < lim && x[q + c] == byte) c++;
+  return c;
+}
+
 /* Tokenise x[base..end) into out[] (capacity cap).  Returns via S->bc: [0] = bytes written,
  * [1] = first unconsumed position (== end if everything fitted).  EMIT = false: the same decisions without
  * the output (count bytes, staging, stores, used-byte map) -- where the block ends, nothing else.          */
@@ -174,11 +194,7 @@ __device__ void collect_pass(const u8 *x, u32 base, u32 end, u32 cap, u8 *out, c
       if (act) {
         const u32 kk = (p - (rs - 1u)) % LBZ_RUN_CAP;
         u32 e = kk < 3u ? 1u : (kk == 3u ? 2u : 0u);
-        if (EMIT && kk == 3u) {
-          u32 c = 0;
-          while (c < 255u && p + 1u + c < end && x[p + 1u + c] == b[i]) c++;
-          cnt[i] = (u8)c;
-        }
+        if (EMIT && kk == 3u) cnt[i] = (u8)run_count(x, p + 1u, end, b[i], vec_ok);
         emit2 |= e << (2u * i);
         nout += e;
       }

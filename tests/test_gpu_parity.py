@@ -315,6 +315,21 @@ def test_rccl_leg_of_the_stream_mux(tmp_path):
     assert res["n_gpus"] == 2 and res["scaling"] == "strong" and res["verified"] is True, line[:600]
 
 
+def test_repeated_passes_are_identical(lib):
+    """The segment workgroups of a block share its rank table while they refine it (k_bwt.hip, ISA_ENTRY): a race between
+    them would show up as a rare mismatch.  Eight passes over the 10^8-byte fixture, every stream hashed."""
+    import hashlib
+    import torch
+    rec = [r for r in bench_fixtures() if r["kind"] == "wiki" and r["n"] == 100_000_000][0]
+    data = gen(rec["kind"], rec["n"], rec["seed"])
+    src = torch.frombuffer(bytearray(data), dtype=torch.uint8).cuda()
+    dst = torch.empty(lib.bound(rec["n"]), dtype=torch.uint8, device="cuda")
+    with lib.context(9, 112) as ctx:
+        for p in range(8):
+            m = ctx.compress_device(src.data_ptr(), rec["n"], dst.data_ptr(), dst.numel())
+            assert m == rec["out_len"] and hashlib.md5(dst[:m].cpu().numpy().tobytes()).hexdigest() == rec["ref_md5"], p
+
+
 def test_full_size_property(lib):
     """BASELINE-sized behaviour by properties: 60 MB of text at -9 with chunked streaming
     (resident capacity smaller than the input) round-trips through an independent decoder,

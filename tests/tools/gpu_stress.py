@@ -1,0 +1,31 @@
+"""Ad-hoc: many passes over the full-size fixtures on the GPU, every stream checked (races between the segment
+workgroups of a block would show up as a rare mismatch).  usage: gpu_stress.py [passes]"""
+import hashlib, json, os, sys, time
+sys.path.insert(0, "/root/repo"); sys.path.insert(0, "/root/repo/tests")
+import torch, lbzip2_amd
+import bench
+lib = lbzip2_amd.library()
+passes = int(sys.argv[1]) if len(sys.argv) > 1 else 12
+recs = json.load(open("/root/repo/tests/golden/bench_fixtures.json"))
+want = [("wiki", 1_000_000_000, 2, 9), ("tar", 1_400_000_000, 5, 9), ("mixed", 211_938_580, 3, 1), ("mixed", 211_938_580, 3, 9),
+        ("wiki", 100_000_000, 1, 9), ("rand", 100_000_000, 4, 9)]
+bad = 0
+for kind, n, seed, level in want:
+    fx = [r for r in recs if (r["kind"], r["n"], r["seed"], r["level"]) == (kind, n, seed, level)][0]
+    data = bench.gen_input(kind, n, seed)
+    src = torch.frombuffer(data, dtype=torch.uint8).cuda()
+    dst = torch.empty(lib.bound(n), dtype=torch.uint8, device="cuda")
+    M = level * 100000
+    t0 = time.time()
+    with lib.context(level, (n + M - 1) // M) as ctx:
+        for p in range(passes):
+            m = ctx.compress_device(src.data_ptr(), n, dst.data_ptr(), dst.numel())
+            z = dst[:m].cpu().numpy().tobytes()
+            ok = m == fx["out_len"] and hashlib.md5(z).hexdigest() == fx["canon_md5"]
+            if not ok:
+                bad += 1
+                print("MISMATCH", kind, n, level, "pass", p, m, fx["out_len"], flush=True)
+    print("%s(%d) -%d: %d passes, %.1f s, mismatches so far %d" % (kind, n, level, passes, time.time() - t0, bad), flush=True)
+    del src, dst
+    torch.cuda.empty_cache()
+print("STRESS", "OK" if bad == 0 else "FAILED", bad)
