@@ -193,22 +193,6 @@ __device__ __forceinline__ bwt_slot round_slot(u8 *ws, u64 slot_bytes, u8 *ws_sp
                    : slot_carve(ws_spill + (u64)(i - count) * spill_bytes, L.cap_b);
 }
 
-/* Lanes of the wave holding the same 8-bit digit ("match any"): 8 ballots; each ballot is
- * folded in with an xnor against the lane's own sign-extended bit.                        */
-__device__ __forceinline__ u64 match_digit(u32 d, bool ok)
-{
-  const u64 act = __ballot(ok);
-  u32 lo = (u32)act, hi = (u32)(act >> 32);
-#pragma unroll
-  for (u32 b = 0; b < 8u; b++) {
-    const int bm = -(int)((d >> b) & 1u);               /* 0 or ~0 */
-    const u64 bal = __ballot(bm != 0);
-    lo &= ~((u32)bal ^ (u32)bm);
-    hi &= ~((u32)(bal >> 32) ^ (u32)bm);
-  }
-  return ((u64)hi << 32) | lo;
-}
-
 struct sort_lds;
 __device__ __forceinline__ void radix_tile_scatter_hbm(sort_lds *X, const unsigned long long (&key)[4], const unsigned int (&val)[4],
                                                        unsigned int okmask, unsigned int shift,

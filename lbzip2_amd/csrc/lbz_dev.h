@@ -107,6 +107,42 @@ __device__ __forceinline__ u32 wave_and(u32 v) { LBZ_DPP_SCAN(dpp_and, 0xFFFFFFF
 __device__ __forceinline__ u32 wave_or(u32 v) { for (u32 d = 32; d >= 1; d >>= 1) v |= __shfl_xor(v, (int)d); return v; }
 __device__ __forceinline__ u32 wave_and(u32 v) { for (u32 d = 32; d >= 1; d >>= 1) v &= __shfl_xor(v, (int)d); return v; }
 #endif
+/* Lanes of the wave holding the same 8-bit digit ("match any"): 8 ballots; each ballot is
+ * folded in with an xnor against the lane's own sign-extended bit.                        */
+__device__ __forceinline__ u64 match_digit(u32 d, bool ok)
+{
+  const u64 act = __ballot(ok);
+  u32 lo = (u32)act, hi = (u32)(act >> 32);
+#pragma unroll
+  for (u32 b = 0; b < 8u; b++) {
+    const int bm = -(int)((d >> b) & 1u);               /* 0 or ~0 */
+    const u64 bal = __ballot(bm != 0);
+    lo &= ~((u32)bal ^ (u32)bm);
+    hi &= ~((u32)(bal >> 32) ^ (u32)bm);
+  }
+  return ((u64)hi << 32) | lo;
+}
+
+/* inclusive OR-scan over the lanes of a wave (DPP on the device) and its 64-bit exclusive form: lane l gets the OR of
+   the values of lanes < l */
+#ifndef LBZ_EMULATED
+__device__ __forceinline__ u32 wave_incl_or(u32 v) { LBZ_DPP_SCAN(dpp_or, 0u) return v; }
+#else
+__device__ __forceinline__ u32 wave_incl_or(u32 v)
+{
+  const u32 l = lane_id();
+  for (u32 d = 1; d < 64; d <<= 1) { const u32 o = __shfl_up(v, d); if (l >= d) v |= o; }
+  return v;
+}
+#endif
+__device__ __forceinline__ u64 wave_excl_or64(u64 v, u64 *total = nullptr)
+{
+  const u32 lo = wave_incl_or((u32)v), hi = wave_incl_or((u32)(v >> 32));
+  if (total) *total = (u64)(u32)__builtin_amdgcn_readlane((int)lo, 63) | ((u64)(u32)__builtin_amdgcn_readlane((int)hi, 63) << 32);
+  const u32 elo = (u32)wave_shr1((int)lo), ehi = (u32)wave_shr1((int)hi);       /* lane 0 keeps its own value: cleared below */
+  return lane_id() == 0u ? 0ull : ((u64)elo | ((u64)ehi << 32));
+}
+
 /* OR and AND of a 64-bit value over the wave, in every lane */
 __device__ __forceinline__ void wave_or_and64(u64 *vo, u64 *va)
 {

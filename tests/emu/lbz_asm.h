@@ -70,20 +70,4 @@ static inline unsigned wave_claim(unsigned *tickets)
   if ((threadIdx.x & 63) == 0) r = atomicAdd(tickets, 64u);
   return (unsigned)__builtin_amdgcn_readfirstlane((int)r) >> 6;
 }
-/* C statement of lbz_asm.h's mtf_fast_heads (same contract): every head in f has a slot < 64 */
-template <int NQ>
-static inline void mtf_fast_heads(unsigned long long f, int &rank, int (&L)[NQ], int c, int sb0)
-{
-  if (NQ == 1) return;
-  while (f) {
-    const int l = __builtin_ctzll(f);
-    f &= f - 1ull;
-    const int s = __builtin_amdgcn_readlane(c, l);
-    const int pv = __builtin_amdgcn_readlane(L[0], s);
-    int cnt = 0;
-    for (int j = 0; j < NQ; j++) cnt += (int)__popcll(__ballot(L[j] > pv));
-    rank = lane_write(rank, cnt, l);
-    L[0] = lane_write(L[0], sb0 + l, s);
-  }
-}
 #endif
