@@ -44,7 +44,6 @@
    (small inputs, the work-unit interface) a block is better served by sixteen waves than by four.                  */
 #define LBZ_WIDE_WG 1024
 #define k_bwt_part k_bwt_part_w
-#define k_bwt_part2 k_bwt_part2_w
 #endif
 #include "lbz_common.h"
 #undef LBZ_WG
@@ -69,8 +68,11 @@
                                            pass pays: groups of more than a batch (HBM sorter) and of more than 256 rows (one wave's
                                            job) become rare: k_bwt_part +6.5 ms, k_bwt_batch -11 ms per 10^9 bytes of text */
 #endif
-#define MSD_PASSES (MSD_BITS / 8u)
-#define MSD_SHIFT (64u - MSD_BITS)
+/* ... per block: a block whose two leading key bytes are spread evenly (incompressible data: no byte value holds more
+   than 1/128 of the rotations in either position) is partitioned on 16 bits only -- its groups are a dozen rows then, and
+   two HBM passes over 12-byte rows are saved (k_bwt_part on random bytes: 46 -> 24 ms per 10^9 bytes).  The depth is in
+   the block record (msd_bits) and, as a shift, in every sorting kernel's LDS header (msd_shift).                      */
+#define MSD_BITS_FLAT 16u
 #define PART_HALO 48u
 #define BATCH_CAP (LBZ_WG * 4u)
 #define SMALL_BLOCK (LBZ_BWT_WG * 4u)    /* blocks of at most one batch of k_bwt_batch are sorted whole in LDS, without a partition */
@@ -149,6 +151,7 @@ struct bwt_lds {
   u32 bc[16];
   u32 isa_from, tied0;                /* k_bwt_batch: rows from isa_from on get their rank written with them; tied0 = rows tied on their first key so far */
   u32 budget, shallow;                /* k_bwt_batch: tied-row rounds this segment may spend on in-LDS refinement; ties were left at depth S */
+  u32 msd_shift, pad2_;               /* 64 - the block's partition depth: rows with equal key >> msd_shift form a group */
   u32 dbg[4];                         /* LDS_SORT_TICKS: whole-workgroup batch sorts (count, ticks), oversized groups (count, ticks) */
   u8 cmap[256];                       /* byte -> dense code */
   u8 inv[256];                        /* dense code -> byte */
@@ -494,12 +497,11 @@ __device__ __forceinline__ void radix_tile_scatter_hbm(sort_lds *X, const u64 (&
 /* A pass over the block text through the LDS tile, keys built on the fly.  The tile holds
  * dense symbol CODES (one table lookup per text byte); a thread owns 4 consecutive rotations,
  * reads their 4+sy-1 codes as five dwords and slides a window over them.
- * SCATTER = false: histogram the first partition digit of every rotation;
- * SCATTER = true : first partition pass (digit at MSD_SHIFT) straight from the text, counting
- *                  the other two digits on the way.  Values carry the CODE of the preceding
- *                  byte; the emitters map it back.                                          */
+ * SCATTER = false: histograms of the four partition digits (key bits 32.., 40.., 48.., 56..) of every rotation;
+ * SCATTER = true : first partition pass (digit at `shift`) straight from the text.  Values carry the CODE of the
+ *                  preceding byte; the emitters map it back.                                 */
 template <bool SCATTER>
-__device__ void msd_text_pass(const u8 *T, u32 n, keycfg c, u64 *kout, u32 *vout, bwt_lds *S)
+__device__ void msd_text_pass(const u8 *T, u32 n, keycfg c, u64 *kout, u32 *vout, bwt_lds *S, u32 shift = 0u)
 {
   sort_lds *P = &S->u.X;
   const u32 tid = threadIdx.x;
@@ -554,18 +556,14 @@ __device__ void msd_text_pass(const u8 *T, u32 n, keycfg c, u64 *kout, u32 *vout
       }
     }
     if (SCATTER) {
+      radix_tile_scatter_hbm(P, key, val, okmask, shift, kout, vout);
+    } else {
 #pragma unroll
       for (u32 k = 0; k < SORT_IPT; k++)
         if ((okmask >> k) & 1u) {
 #pragma unroll
-          for (u32 p = 1; p < MSD_PASSES; p++)
-            atomicAdd(&P->hist[p][(u32)(key[k] >> ((MSD_SHIFT + 8u * p) & 63u)) & 255u], 1u);
+          for (u32 p = 0; p < 4u; p++) atomicAdd(&P->hist[p][(u32)(key[k] >> (32u + 8u * p)) & 255u], 1u);
         }
-      radix_tile_scatter_hbm(P, key, val, okmask, MSD_SHIFT, kout, vout);
-    } else {
-#pragma unroll
-      for (u32 k = 0; k < SORT_IPT; k++)
-        if ((okmask >> k) & 1u) atomicAdd(&P->hist[0][(u32)(key[k] >> MSD_SHIFT) & 255u], 1u);
       __syncthreads();
     }
   }
@@ -1003,7 +1001,7 @@ __device__ u32 batch_process(const u8 *T, u32 n, u8 *bwt, lbz_block_meta *meta, 
   const u64 tb0 = wall_clock64();
   if (tid == 0) {
     S->bc[7] = 0; S->bc[5] = 0; S->bc[6] = 0;        /* window claim counter; the barriers below publish it */
-    if (trim) S->bc[1] = lo + cnt < n ? (u32)(s.k0[lo + cnt] >> MSD_SHIFT) : 0xFFFFFFFFu;   /* MSD_BITS <= 32 */
+    if (trim) S->bc[1] = lo + cnt < n ? (u32)(s.k0[lo + cnt] >> S->msd_shift) : 0xFFFFFFFFu;   /* partition depth <= 32 bits */
   }
   if (!preloaded) {
     for (u32 i = tid; i < cnt; i += LBZ_WG) { B->kA[i] = s.k0[lo + i]; B->vA[i] = s.v0[lo + i]; }
@@ -1019,8 +1017,8 @@ __device__ u32 batch_process(const u8 *T, u32 n, u8 *bwt, lbz_block_meta *meta, 
     }
     need_sort = false;
   }
-  batch_runs(B, B->kA, cnt, need_sort ? MSD_SHIFT : 0u, &maxrun, S);
-  if (trim && lo + cnt < n && (u32)(B->kA[cnt - 1u] >> MSD_SHIFT) == S->bc[1]) {
+  batch_runs(B, B->kA, cnt, need_sort ? S->msd_shift : 0u, &maxrun, S);
+  if (trim && lo + cnt < n && (u32)(B->kA[cnt - 1u] >> S->msd_shift) == S->bc[1]) {
     cnt = B->gh[cnt - 1u];                       /* the last group goes on: it waits for the next batch */
     if (cnt == 0u) { __syncthreads(); return 0u; }
   }
@@ -1140,7 +1138,7 @@ __device__ void big_group(const u8 *T, u32 n, u8 *bwt, lbz_block_meta *meta, bwt
 {
   const u32 tid = threadIdx.x;
   const u32 m = hi - lo;
-  const u32 which = wg_radix_sort(s.k0 + lo, s.v0 + lo, s.k1 + lo, s.v1 + lo, m, MSD_SHIFT, S);
+  const u32 which = wg_radix_sort(s.k0 + lo, s.v0 + lo, s.k1 + lo, s.v1 + lo, m, S->msd_shift, S);
   if (which) {
     for (u32 i = tid; i < m; i += LBZ_WG) { s.k0[lo + i] = s.k1[lo + i]; s.v0[lo + i] = s.v1[lo + i]; }
     __syncthreads();
@@ -1299,7 +1297,10 @@ __device__ keycfg bwt_setup(const lbz_block_meta *meta, bwt_lds *S)
   c.sy = 64u / c.b;
   if (c.sy > MAX_SYMS) c.sy = MAX_SYMS;
   c.pad = 64u - c.b * c.sy;
-  if (tid == 0) for (u32 i = 1; i < 16; i++) S->bc[i] = 0;
+  if (tid == 0) {
+    for (u32 i = 1; i < 16; i++) S->bc[i] = 0;
+    S->msd_shift = 64u - (meta->msd_bits ? meta->msd_bits : MSD_BITS);
+  }
   __syncthreads();
   return c;
 }
@@ -1312,6 +1313,7 @@ struct part_lds {
   u32 bc[16];
   u32 isa_from, tied0;
   u32 budget, shallow;
+  u32 msd_shift, pad2_;
   u32 dbg[4];
   u8 cmap[256];
   u8 inv[256];
@@ -1329,6 +1331,7 @@ __device__ __forceinline__ void part_block(bwt_lds &S, const u8 *Tbase, lbz_bloc
   if (tid == 0) {                             /* the sorter's part of the block record: the segment workgroups add to it */
     lbz_block_meta *M = &meta[blk];
     M->periodic = 0; M->rounds = 0; M->sort_elems = 0; M->isa_from = 0; M->nseg = 0; M->deep_start = DEEP_REFINE ? 1u : 0u;
+    M->msd_bits = MSD_BITS;
     for (u32 i = 0; i < 8u; i++) M->ticks[i] = 0;
     for (u32 i = 0; i < 16u; i++) M->fticks[i] = 0;
     for (u32 i = 0; i < LBZ_BWT_MAXSEGS; i++) M->seg_m[i] = 0;
@@ -1339,38 +1342,36 @@ __device__ __forceinline__ void part_block(bwt_lds &S, const u8 *Tbase, lbz_bloc
   const u64 tk0 = wall_clock64();
   const keycfg c = bwt_setup(&meta[blk], &S);
   sort_lds *P = &S.u.X;
-  for (u32 i = tid; i < MSD_PASSES * 256u; i += LBZ_WG) (&P->hist[0][0])[i] = 0;
+  for (u32 i = tid; i < 4u * 256u; i += LBZ_WG) (&P->hist[0][0])[i] = 0;
   __syncthreads();
-  msd_text_pass<false>(T, n, c, nullptr, nullptr, &S);
-  load_digit_offsets(P->hist[0], P->dbase, &S);
-  /* least significant of the MSD digits first; buffers alternate so that the last pass lands in (k0,v0) */
+  msd_text_pass<false>(T, n, c, nullptr, nullptr, &S);         /* hist[j]: the key byte at bit 32 + 8 j */
+  /* how deep to partition: both leading bytes flat -> 16 bits, else MSD_BITS */
+  u32 bits = MSD_BITS;
+  if (MSD_BITS > MSD_BITS_FLAT) {
+    const u32 h3 = tid < 256u ? P->hist[3][tid] : 0u, h2 = tid < 256u ? P->hist[2][tid] : 0u;
+    const u32 top = wg_max(h3 > h2 ? h3 : h2, &S.sc);
+    if (top <= n / 128u) bits = MSD_BITS_FLAT;
+  }
+  if (tid == 0) meta[blk].msd_bits = bits;
+  const u32 passes = bits / 8u, j0 = 4u - passes;             /* digits j0 .. 3, least significant first */
+  load_digit_offsets(P->hist[j0], P->dbase, &S);
+  /* buffers alternate so that the last pass lands in (k0,v0) */
   u64 *kb[2] = { s.k0, s.k1 };
   u32 *vb[2] = { s.v0, s.v1 };
-  u32 cur = (MSD_PASSES - 1u) & 1u;
-  msd_text_pass<true>(T, n, c, kb[cur], vb[cur], &S);
-#pragma unroll
-  for (u32 p = 1; p < MSD_PASSES; p++) {
-    load_digit_offsets(P->hist[p], P->dbase, &S);
-    msd_array_pass(kb[cur], vb[cur], n, (MSD_SHIFT + 8u * p) & 63u, kb[cur ^ 1u], vb[cur ^ 1u], &S);
+  u32 cur = (passes - 1u) & 1u;
+  msd_text_pass<true>(T, n, c, kb[cur], vb[cur], &S, 32u + 8u * j0);
+  for (u32 j = j0 + 1u; j < 4u; j++) {
+    load_digit_offsets(P->hist[j], P->dbase, &S);
+    msd_array_pass(kb[cur], vb[cur], n, 32u + 8u * j, kb[cur ^ 1u], vb[cur ^ 1u], &S);
     cur ^= 1u;
   }
   if (tid == 0) meta[blk].ticks[2] = (u32)(wall_clock64() - tk0);
 }
 
-/* One body, two register budgets.  k_bwt_part: 128 VGPRs, one workgroup per CU -- for rounds of
- * at most one full-size block per CU.  k_bwt_part2: 64 VGPRs (12 spill) and 80 SGPRs, so that
- * two workgroups share a CU (the LDS layout is 80 KB either way): twice the loads in flight,
- * -10 % on rounds that have the blocks for it, +12 % on those that do not.                    */
+/* 256 threads in the main build (four workgroups per CU beside the sorting kernels' own), 1024 in the wide one */
 __global__ void __launch_bounds__(LBZ_WG, 4)
 k_bwt_part(const u8 *Tbase, lbz_block_meta *meta, lbz_layout L, u32 first, u32 count,
            u8 *ws, u64 slot_bytes, u8 *ws_spill, u64 spill_bytes, const u32 *slabs)
-{
-  __shared__ part_lds S_;
-  part_block(*reinterpret_cast<bwt_lds *>(&S_), Tbase, meta, L, first, count, ws, slot_bytes, ws_spill, spill_bytes, slabs);
-}
-__global__ void __launch_bounds__(LBZ_WG, 8) __attribute__((amdgpu_num_sgpr(80)))
-k_bwt_part2(const u8 *Tbase, lbz_block_meta *meta, lbz_layout L, u32 first, u32 count,
-            u8 *ws, u64 slot_bytes, u8 *ws_spill, u64 spill_bytes, const u32 *slabs)
 {
   __shared__ part_lds S_;
   part_block(*reinterpret_cast<bwt_lds *>(&S_), Tbase, meta, L, first, count, ws, slot_bytes, ws_spill, spill_bytes, slabs);
@@ -1408,7 +1409,7 @@ __device__ u32 seg_cut(const u64 *k0, u32 x, u32 n, bwt_lds *S)
 {
   if (x == 0u) return 0u;
   if (x >= n) return n;
-  return find_run_end(k0, x - 1u, x, n, MSD_SHIFT, S);
+  return find_run_end(k0, x - 1u, x, n, S->msd_shift, S);
 }
 
 /* ---- kernel 2: LDS batches of whole groups; emits BWT bytes + rows; flags deep ties ---- */
@@ -1473,7 +1474,7 @@ k_bwt_batch(const u8 *Tbase, u8 *Bbase, lbz_block_meta *meta, lbz_layout L, u32 
 #ifdef LDS_SORT_TICKS
         const u64 tg0 = wall_clock64();
 #endif
-        const u32 end = find_run_end(s.k0, pos, pos + want, n, MSD_SHIFT, &S);
+        const u32 end = find_run_end(s.k0, pos, pos + want, n, S.msd_shift, &S);
         big_group(T, n, bwt, M, s, &S, c, pos, end);
 #ifdef LDS_SORT_TICKS
         if (tid == 0) { S.dbg[3] += (u32)(wall_clock64() - tg0); S.dbg[2] += end - pos; }

@@ -66,6 +66,7 @@ typedef struct lbz_block_meta {
   /* The sorted rows of a block are cut into up to LBZ_BWT_SEGS segments at boundaries of the partition's groups; from
      k_bwt_batch on every (block, segment) is a workgroup of its own (k_bwt.hip).  Rows [seg_lo[s], seg_lo[s+1]).    */
   uint32_t nseg;
+  uint32_t msd_bits;    /* key bits the block was partitioned on in HBM (k_bwt_part decides: 32, or 16 for incompressible data) */
   uint32_t deep_start;  /* first doubling round the block needs: 1 if every tie k_bwt_batch left over has been through one
                            refinement in LDS (the block is sorted to depth 2 S), 0 otherwise */
   uint32_t seg_lo[LBZ_BWT_MAXSEGS + 1];
