@@ -497,11 +497,12 @@ __device__ __forceinline__ void radix_tile_scatter_hbm(sort_lds *X, const u64 (&
 /* A pass over the block text through the LDS tile, keys built on the fly.  The tile holds
  * dense symbol CODES (one table lookup per text byte); a thread owns 4 consecutive rotations,
  * reads their 4+sy-1 codes as five dwords and slides a window over them.
- * SCATTER = false: histograms of the four partition digits (key bits 32.., 40.., 48.., 56..) of every rotation;
- * SCATTER = true : first partition pass (digit at `shift`) straight from the text.  Values carry the CODE of the
+ * SCATTER = false: histogram of the partition digit at key bit 32 of every rotation (hist[0]);
+ * SCATTER = true : first partition pass (digit at `shift`) straight from the text, counting the digits above it on
+ *                  the way if `count_above` (hist[j]: the digit at bit 32 + 8 j).  Values carry the CODE of the
  *                  preceding byte; the emitters map it back.                                 */
 template <bool SCATTER>
-__device__ void msd_text_pass(const u8 *T, u32 n, keycfg c, u64 *kout, u32 *vout, bwt_lds *S, u32 shift = 0u)
+__device__ void msd_text_pass(const u8 *T, u32 n, keycfg c, u64 *kout, u32 *vout, bwt_lds *S, u32 shift = 0u, bool count_above = false)
 {
   sort_lds *P = &S->u.X;
   const u32 tid = threadIdx.x;
@@ -556,14 +557,19 @@ __device__ void msd_text_pass(const u8 *T, u32 n, keycfg c, u64 *kout, u32 *vout
       }
     }
     if (SCATTER) {
+      if (count_above) {
+#pragma unroll
+        for (u32 k = 0; k < SORT_IPT; k++)
+          if ((okmask >> k) & 1u) {
+#pragma unroll
+            for (u32 p = 1; p < 4u; p++) atomicAdd(&P->hist[p][(u32)(key[k] >> (32u + 8u * p)) & 255u], 1u);
+          }
+      }
       radix_tile_scatter_hbm(P, key, val, okmask, shift, kout, vout);
     } else {
 #pragma unroll
       for (u32 k = 0; k < SORT_IPT; k++)
-        if ((okmask >> k) & 1u) {
-#pragma unroll
-          for (u32 p = 0; p < 4u; p++) atomicAdd(&P->hist[p][(u32)(key[k] >> (32u + 8u * p)) & 255u], 1u);
-        }
+        if ((okmask >> k) & 1u) atomicAdd(&P->hist[0][(u32)(key[k] >> 32u) & 255u], 1u);
       __syncthreads();
     }
   }
@@ -1344,13 +1350,19 @@ __device__ __forceinline__ void part_block(bwt_lds &S, const u8 *Tbase, lbz_bloc
   sort_lds *P = &S.u.X;
   for (u32 i = tid; i < 4u * 256u; i += LBZ_WG) (&P->hist[0][0])[i] = 0;
   __syncthreads();
-  msd_text_pass<false>(T, n, c, nullptr, nullptr, &S);         /* hist[j]: the key byte at bit 32 + 8 j */
-  /* how deep to partition: both leading bytes flat -> 16 bits, else MSD_BITS */
+  msd_text_pass<false>(T, n, c, nullptr, nullptr, &S);         /* hist[0]: the key byte at bit 32 */
+  /* With 8-bit symbols a key byte is one symbol of the rotation, and every position of the text is the k-th symbol of
+     exactly one rotation: the four digit histograms are the SAME histogram (the text's), so the other three need not be
+     counted -- and it tells how deep to partition: no byte value in more than 1/128 of the positions (incompressible
+     data) -> 16 bits, else MSD_BITS.  Narrower symbols straddle the key bytes: their digits are counted during the
+     first scatter pass, as before, and the depth stays MSD_BITS.                                                    */
+  const bool bytes = c.b == 8u;
   u32 bits = MSD_BITS;
-  if (MSD_BITS > MSD_BITS_FLAT) {
-    const u32 h3 = tid < 256u ? P->hist[3][tid] : 0u, h2 = tid < 256u ? P->hist[2][tid] : 0u;
-    const u32 top = wg_max(h3 > h2 ? h3 : h2, &S.sc);
-    if (top <= n / 128u) bits = MSD_BITS_FLAT;
+  if (bytes) {
+    const u32 h0 = tid < 256u ? P->hist[0][tid] : 0u;
+    if (tid < 256u) { P->hist[1][tid] = h0; P->hist[2][tid] = h0; P->hist[3][tid] = h0; }
+    const u32 top = wg_max(h0, &S.sc);
+    if (MSD_BITS > MSD_BITS_FLAT && top <= n / 128u) bits = MSD_BITS_FLAT;
   }
   if (tid == 0) meta[blk].msd_bits = bits;
   const u32 passes = bits / 8u, j0 = 4u - passes;             /* digits j0 .. 3, least significant first */
@@ -1359,7 +1371,7 @@ __device__ __forceinline__ void part_block(bwt_lds &S, const u8 *Tbase, lbz_bloc
   u64 *kb[2] = { s.k0, s.k1 };
   u32 *vb[2] = { s.v0, s.v1 };
   u32 cur = (passes - 1u) & 1u;
-  msd_text_pass<true>(T, n, c, kb[cur], vb[cur], &S, 32u + 8u * j0);
+  msd_text_pass<true>(T, n, c, kb[cur], vb[cur], &S, 32u + 8u * j0, !bytes);
   for (u32 j = j0 + 1u; j < 4u; j++) {
     load_digit_offsets(P->hist[j], P->dbase, &S);
     msd_array_pass(kb[cur], vb[cur], n, 32u + 8u * j, kb[cur ^ 1u], vb[cur ^ 1u], &S);
