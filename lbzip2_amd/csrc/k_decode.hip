@@ -22,6 +22,9 @@
 
 #define DEC_MAX_SEL 18002u
 #define DEC_LUT_BITS 10u
+#define DW_T 256u                     /* threads of a k_dblock workgroup */
+#define DM_CHUNK 1024u                /* symbols per move-to-front chunk */
+#define DM_EOB 0xFFFFu                /* the end-of-block symbol as stored in the symbol array */
 
 struct dec_lds {
   u16 lut[LBZ_MAX_TREES][1u << DEC_LUT_BITS];   /* next 10 bits -> symbol << 5 | code length; 0: a longer code (or none) */
@@ -32,6 +35,11 @@ struct dec_lds {
   u8 len[LBZ_MAX_TREES][LBZ_MAX_ALPHA + 2];
   u32 sel[(DEC_MAX_SEL + 7u) / 8u + 1u];        /* tree of every 50-symbol group, 4 bits each */
   u8 seq2unseq[256];
+  u8 wl[DW_T / 64u][256];             /* dmtf_expand: the list a wave's chunk starts with */
+  u32 nsym, nout, err2;
+  u32 prod, fin;                      /* symbols the bit chain has handed over (a multiple of DM_CHUNK); 1 once it is done and nsym stands */
+  u32 ring[260];                      /* dhuff_block: 256 dwords of the stream around the cursor (+ ring[0] again) */
+  u32 ctr[2];                         /* chunk tickets of dmtf_chunks / dmtf_expand */
 };
 
 /* MSB-first bit cursor, the same in every lane of the wave (all its state is wave-uniform and lives in
@@ -53,11 +61,13 @@ __device__ __forceinline__ u64 rfl64(u64 v) { return (u64)rfl((u32)v) | (u64)rfl
 __device__ __forceinline__ u32 ub_chunk(const ubit *b, u64 chunk)          /* the raw dwords: nothing here waits for the load */
 {
   const u64 i = chunk * 64u + lane_id();
-  return i < b->ndw ? b->base[i] : 0u;
+  return b->base[i < b->ndw ? i : b->ndw - 1u];          /* no branch around the load: its result is first looked at a chunk later */
 }
 __device__ __forceinline__ u32 ub_cook(const ubit *b, u32 v, u64 chunk)    /* MSB first, once per dword instead of once per use */
 {
-  if (chunk * 64u + lane_id() + 1u == b->ndw) v &= b->tailmask;
+  const u64 i = chunk * 64u + lane_id();
+  if (i + 1u == b->ndw) v &= b->tailmask;
+  if (i >= b->ndw) v = 0;
   return __builtin_bswap32(v);
 }
 __device__ __forceinline__ void ub_refill(ubit *b)
@@ -123,13 +133,13 @@ k_dscan(const u8 *in, u64 nbytes, u64 *marks, u32 *nmarks, u32 cap)
  * and for the wide parts: the input window (ubit), the move-to-front list (256 entries in four vector
  * registers: a front move is one wave_shr), the code tables (built 64 symbols at a time), zero-run fills.
  * Codes of up to 10 bits -- nearly all -- resolve with one LDS lookup.                                     */
-__device__ __forceinline__ void dhuff_block(const u8 *in, u64 nbytes, lbz_dblock *D, u8 *tt8, u32 cap, dec_lds &S)
+__device__ __forceinline__ void dhuff_block(const u8 *in, u64 nbytes, lbz_dblock *D, u16 *sym16, u32 cap, dec_lds &S)
 {
   const u32 lane = threadIdx.x;                  /* wave 0 of the workgroup */
   const u32 maxn = rfl(D->max_block < cap ? D->max_block : cap);
   ubit b;
   ub_init(&b, in, nbytes, rfl64(D->bit_start));
-  u32 err = 0, n = 0;
+  u32 err = 0;
   const u32 stored_crc = ub_get(&b, 32);
   const u32 randomised = ub_get(&b, 1);
   const u32 orig_ptr = ub_get(&b, 24);
@@ -226,89 +236,241 @@ __device__ __forceinline__ void dhuff_block(const u8 *in, u64 nbytes, lbz_dblock
     err = rfl(wave_max(err));
   }
   wave_sync();
-  /* symbols */
+  /* symbols: the bit chain alone.  From here on the stream is read through a ring of 256 cooked dwords in LDS (four
+     chunks of 64, filled a chunk ahead of the cursor; ring[256] repeats ring[0] so that a pair of dwords never wraps).
+     A strip at a time: lane j looks up the 10 bits that start at bit j and at bit 64 + j behind the cursor G (one
+     window read + one table read each), turns the entry's length into the offset of the code behind it, and the codes
+     are then walked with one v_readlane per code (huff_walk) -- first the offsets 0..63, then 64..127; the lanes that
+     were hopped on store their symbols side by side.  Nothing else is on the chain: what the symbols MEAN (move-to-
+     front, zero runs) is worked out afterwards, by every wave of the workgroup (dmtf_*).                        */
+  u32 nsym = 0;
+  u64 G = ub_bitpos(&b) + b.lead;                                /* bit cursor in the dword stream that starts at b.base */
   if (!err) {
-    int L0 = (int)S.seq2unseq[lane], L1 = (int)S.seq2unseq[lane + 64u], L2 = (int)S.seq2unseq[lane + 128u], L3 = (int)S.seq2unseq[lane + 192u];
-    u32 groupno = 0, k = LBZ_GROUP, t = 0;
-    u32 es = 0, N = 0;
+    u64 whi = (G >> 5) >> 6;                                     /* next chunk to put into the ring */
+    for (u32 i = 0; i < 2u; i++, whi++) {
+      const u32 v = ub_cook(&b, ub_chunk(&b, whi), whi);
+      S.ring[((u32)whi & 3u) * 64u + lane] = v;
+      if (((u32)whi & 3u) == 0u && lane == 0u) S.ring[256] = v;
+    }
+    u32 pf = ub_chunk(&b, whi);
+    wave_sync();
+    u32 groupno = 0, k = LBZ_GROUP, t = 0, pub = 0;
     for (;;) {
-      /* The common cases run in huff_fast() (lbz_asm.h): a dependent instruction costs a lone wave ~2.5 ns
-         whatever its kind and the table lookup ~37 ns (tests/tools/micro/chain.hip), so that loop is written by
-         hand; it returns for anything else and one general step follows.                               */
-      if (k < LBZ_GROUP) {
-        u32 dwl = (u32)b.dw;
-        const u32 dwl0 = dwl;
-#ifdef LBZ_EMULATED
-        huff_fast(b.buf, b.live, dwl, b.cur, k, n, es, N, L0, L1, L2, L3, S.lut[t], tt8, maxn, lane);
-#else
-        huff_fast(b.buf, b.live, dwl, b.cur, k, n, es, N, L0, L1, L2, L3,
-                  (u32)(size_t)(const __attribute__((address_space(3))) void *)S.lut[t], tt8, maxn, lane);
-#endif
-        b.dw += dwl - dwl0;
-      }
       if (k == LBZ_GROUP) {                                      /* a group: LBZ_GROUP symbols of one tree */
         if (groupno >= nsel) { err = 5; break; }
         t = groupno < DEC_MAX_SEL ? (rfl(S.sel[groupno >> 3]) >> (4u * (groupno & 7u))) & 15u : 0u;
         groupno++;
-        if (n > maxn) { err = 8; break; }                        /* the array has room for a group beyond maxn */
+        if (nsym > maxn + 1u) { err = 8; break; }                /* every symbol but the last is at least one byte */
         k = 0;
+        if ((nsym ^ pub) >= DM_CHUNK) { pub = nsym & ~(DM_CHUNK - 1u); lds_publish(&S.prod, pub); }   /* whole chunks go to the waves that wait in dmtf_chunks */
       }
-      if (b.live < 20u) ub_refill(&b);
-      const u32 e = rfl(S.lut[t][(u32)(b.buf >> (64u - DEC_LUT_BITS))]);
-      u32 l = e & 31u, sym = e >> 5;
-      if (e == 0u) {                                             /* a long code or the end of the block */
-        const u32 code = (u32)(b.buf >> 44);
-        l = rfl(S.minlen[t]);
-        const u32 mx = rfl(S.maxlen[t]);
-        while (l <= mx && (int)code > (int)rfl((u32)S.limit[t][l])) l++;
-        if (l > mx) { err = 6; break; }
-        const int pi = (int)(code >> (20u - l)) - (int)rfl((u32)S.base[t][l]);
-        if (pi < 0 || pi >= (int)alpha) { err = 6; break; }
-        sym = rfl(S.perm[t][pi]);
+      const u32 gd = (u32)(G >> 5), g5 = (u32)G & 31u;
+      if ((u32)(whi * 64u - (G >> 5)) < 8u) {                    /* the cursor is within 8 dwords of the ring's end */
+        const u32 v = ub_cook(&b, pf, whi);
+        S.ring[((u32)whi & 3u) * 64u + lane] = v;
+        if (((u32)whi & 3u) == 0u && lane == 0u) S.ring[256] = v;
+        whi++;
+        pf = ub_chunk(&b, whi);
+        wave_sync();
       }
-      b.buf <<= l; b.live -= l;
+      u32 e0, e1, nx0, nx1;
+#define DH_HALF(e, nx, h) {                                                                                  \
+        const u32 pos = g5 + lane + 64u * (h), idx = (gd + (pos >> 5)) & 255u;                                \
+        const u64 w = (u64)S.ring[idx] << 32 | S.ring[idx + 1u];                                              \
+        e = S.lut[t][(u32)((w << (pos & 31u)) >> (64u - DEC_LUT_BITS))];                                       \
+        const u32 len = e & 31u;                                                                              \
+        nx = (len == 0u || lane + len >= 64u) ? lane : lane + len; }
+      DH_HALF(e0, nx0, 0u)
+      DH_HALF(e1, nx1, 1u)
+#undef DH_HALF
+      u32 off, used;
+      u64 M0, M1 = 0;
+      bool stop;                                                 /* the walk ended on an offset without a table entry */
+      huff_walk(nx0, 0u, off, M0);
+      u32 l = (u32)__builtin_amdgcn_readlane((int)e0, (int)off) & 31u;
+      if (l == 0u) { M0 &= ~(1ull << off); used = off; stop = true; }
+      else {
+        huff_walk(nx1, off + l - 64u, off, M1);
+        l = (u32)__builtin_amdgcn_readlane((int)e1, (int)off) & 31u;
+        if (l == 0u) { M1 &= ~(1ull << off); used = 64u + off; stop = true; }
+        else { used = 64u + off + l; stop = false; }
+      }
+      u32 c0 = (u32)__popcll(M0), cnt = c0 + (u32)__popcll(M1);
+      const u32 rem = LBZ_GROUP - k;
+      if (cnt >= rem) {                                          /* the group ends in this strip: behind it another tree reads the bits */
+        if (cnt > rem) {
+          const u32 r0 = (u32)__popcll(M0 & lanes_below()), r1 = c0 + (u32)__popcll(M1 & lanes_below());
+          const u64 q0 = __ballot(((M0 >> lane) & 1ull) && r0 == rem), q1 = __ballot(((M1 >> lane) & 1ull) && r1 == rem);
+          if (q0) { used = (u32)__builtin_ctzll(q0); M0 &= (1ull << used) - 1ull; M1 = 0; }
+          else { const u32 q = (u32)__builtin_ctzll(q1); used = 64u + q; M1 &= (1ull << q) - 1ull; }
+          c0 = (u32)__popcll(M0); cnt = rem;
+        }
+        stop = false;
+      }
+      if ((M0 >> lane) & 1ull) sym16[nsym + (u32)__popcll(M0 & lanes_below())] = (u16)(e0 >> 5);
+      if ((M1 >> lane) & 1ull) sym16[nsym + c0 + (u32)__popcll(M1 & lanes_below())] = (u16)(e1 >> 5);
+      nsym += cnt; k += cnt;
+      G += used;
+      if (!stop) continue;
+      /* a long code or the end of the block */
+      const u32 i0 = (u32)(G >> 5) & 255u;
+      const u64 w = (u64)rfl(S.ring[i0]) << 32 | rfl(S.ring[i0 + 1u]);
+      const u32 code = (u32)((w << ((u32)G & 31u)) >> 44);
+      l = rfl(S.minlen[t]);
+      const u32 mx = rfl(S.maxlen[t]);
+      while (l <= mx && (int)code > (int)rfl((u32)S.limit[t][l])) l++;
+      if (l > mx) { err = 6; break; }
+      const int pi = (int)(code >> (20u - l)) - (int)rfl((u32)S.base[t][l]);
+      if (pi < 0 || pi >= (int)alpha) { err = 6; break; }
+      const u32 sym = rfl(S.perm[t][pi]);
+      G += l;
       k++;
-      if (sym <= 1u) {                                           /* RUNA / RUNB: bijective base-2 digits of a zero run */
-        es += (sym + 1u) << N;
-        N++;
-        if (N > 21u) { err = 7; break; }
-        continue;
-      }
-      if (es) {
-        if (n + es > maxn) { err = 8; break; }
-        const u32 uc = (u32)__builtin_amdgcn_readlane(L0, 0);
-#pragma clang loop vectorize(disable) unroll(disable)
-        for (u32 i = lane; i < es; i += 64u) tt8[n + i] = (u8)uc;
-        n += es; es = 0; N = 0;
-      }
+      if (lane == 0u) sym16[nsym] = sym == eob ? (u16)DM_EOB : (u16)sym;
+      nsym++;
       if (sym == eob) break;
-      const u32 nn = sym - 1u;
-      u32 m;
-      if (nn < 64u) {
-        m = (u32)__builtin_amdgcn_readlane(L0, (int)nn);
-        const int sh = wave_shr1(L0);
-        L0 = lane == 0u ? (int)m : (lane <= nn ? sh : L0);
-      } else {
-        const u32 q = nn >> 6, r = nn & 63u;
-        const int c0 = __builtin_amdgcn_readlane(L0, 63), c1 = __builtin_amdgcn_readlane(L1, 63), c2 = __builtin_amdgcn_readlane(L2, 63);
-        m = (u32)__builtin_amdgcn_readlane(q == 1u ? L1 : (q == 2u ? L2 : L3), (int)r);
-        const int s0 = wave_shr1(L0), s1 = wave_shr1(L1), s2 = wave_shr1(L2), s3 = wave_shr1(L3);
-        L0 = lane == 0u ? (int)m : s0;
-        L1 = lane == 0u ? c0 : ((q > 1u || lane <= r) ? s1 : L1);
-        if (q >= 2u) L2 = lane == 0u ? c1 : ((q > 2u || lane <= r) ? s2 : L2);
-        if (q >= 3u) L3 = lane == 0u ? c2 : (lane <= r ? s3 : L3);
-      }
-      if (lane == 0u) tt8[n] = (u8)m;
-      n++;
     }
-    if (!err && n > maxn) err = 8;
   }
-  if (!err && (n == 0u || orig_ptr >= n)) err = 9;
   if (lane == 0u) {
     D->stored_crc = stored_crc; D->randomised = randomised; D->orig_ptr = orig_ptr;
-    D->nblock = err ? 0u : n;
+    D->nblock = 0;
     D->err = err;
-    D->bit_used = ub_bitpos(&b);
+    D->bit_used = G - b.lead;
+    S.nsym = err ? 0u : nsym;
+  }
+  lds_publish(&S.fin, 1u);
+}
+
+/* ------------------------------------------------------------------ what the symbols mean */
+/* The symbols of a block are RUNA/RUNB (0/1: a digit of a zero run), literals (2..: move list entry v - 1 to the
+ * front and output it) and the end-of-block mark.  decode.c:519-850 does all of it in one loop, one symbol after the
+ * other; here only what is serial by nature stays serial, and that part runs on every wave of the workgroup at once:
+ *
+ *   dmtf_chunks  a wave takes a chunk of DM_CHUNK symbols and runs the move-to-front chain over its literals
+ *                starting from the IDENTITY list (the list lives in four vector registers; a front move is a
+ *                wave_shr), so what it writes back for a literal is an index into the list the chunk starts with,
+ *                whatever that is; what the chunk leaves behind is a permutation.  The chunk's decoded length
+ *                needs no chain at all: digit k of a run is worth (d + 1) << k, and k is the number of digits
+ *                right in front of it.
+ *   dmtf_scan    one wave composes the permutations in order -- the real list at the start of every chunk -- and
+ *                sums the lengths -- where every chunk's bytes go.
+ *   dmtf_expand  every wave again, no chain: literal = list[index]; a run takes the value of the last literal in
+ *                front of it (the list's front); positions from a prefix sum of the lengths.               */
+__device__ __forceinline__ u32 run_digit_index(u64 R, u64 Rprev, u32 lane)
+{
+  u32 N = lane ? (u32)__clzll(~(R << (64u - lane))) : 0u;        /* digits right below this lane (the shifted-in zeros stop it) */
+  if (N == lane) N += Rprev == ~0ull ? 64u : (u32)__clzll(~Rprev);
+  return N;
+}
+__device__ __forceinline__ u64 run_mask_before(const u16 *sym16, u32 s0, u32 lane)
+{
+  const u32 v = s0 >= 64u ? sym16[s0 - 64u + lane] : 2u;
+  return __ballot(v <= 1u);
+}
+
+__device__ __forceinline__ void dmtf_chunks(u16 *sym16, u8 *lists, u32 *lens, dec_lds &S)
+{
+  const u32 lane = threadIdx.x & 63u;
+  for (;;) {
+    const u32 c = wave_claim(&S.ctr[0]);
+    const u32 s0 = c * DM_CHUNK;
+    u32 s1 = s0 + DM_CHUNK;
+    while (lds_observe(&S.prod) < s1) {                          /* the bit chain is still at it (wave 0 comes here when it is done) */
+      if (lds_observe(&S.fin)) { const u32 nsym = rfl(S.nsym); s1 = s1 < nsym ? s1 : nsym; break; }
+      wave_pause();
+    }
+    if (s0 >= s1) break;
+    int L0 = (int)lane, L1 = (int)lane + 64, L2 = (int)lane + 128, L3 = (int)lane + 192;
+    u32 clen = 0, bad = 0;
+    u64 Rprev = run_mask_before(sym16, s0, lane);
+    u32 vn = s0 + lane < s1 ? sym16[s0 + lane] : DM_EOB;
+    for (u32 base = s0; base < s1; base += 64u) {
+      const u32 v = vn;
+      if (base + 64u < s1) vn = base + 64u + lane < s1 ? sym16[base + 64u + lane] : DM_EOB;
+      const bool run = v <= 1u, lit = v >= 2u && v != DM_EOB;
+      const u64 R = __ballot(run);
+      if (run) {
+        const u32 N = run_digit_index(R, Rprev, lane);
+        if (N > 20u) bad = 7; else clen += (v + 1u) << N;
+      } else if (lit) clen++;
+      Rprev = R;
+      int outv = (int)v;
+      mtf_strip(L0, L1, L2, L3, v, __ballot(lit), outv, lane);
+      if (lit) sym16[base + lane] = (u16)outv;
+    }
+    u8 *P = lists + (size_t)c * 256u;
+    P[lane] = (u8)L0; P[lane + 64u] = (u8)L1; P[lane + 128u] = (u8)L2; P[lane + 192u] = (u8)L3;
+    const u32 tot = wave_sum(clen);
+    bad = wave_max(bad);
+    if (lane == 0u) { lens[c] = tot; if (bad) atomicMax(&S.err2, bad); }
+  }
+}
+
+__device__ __forceinline__ void dmtf_scan(u8 *lists, u32 *lens, u32 maxn, dec_lds &S)
+{
+  const u32 lane = threadIdx.x;                  /* wave 0 */
+  const u32 nchunks = (S.nsym + DM_CHUNK - 1u) / DM_CHUNK;
+  int c0 = (int)S.seq2unseq[lane], c1 = (int)S.seq2unseq[lane + 64u], c2 = (int)S.seq2unseq[lane + 128u], c3 = (int)S.seq2unseq[lane + 192u];
+  u32 off = 0, err = 0;
+  for (u32 c = 0; c < nchunks; c++) {
+    u8 *P = lists + (size_t)c * 256u;
+    const u32 p0 = P[lane], p1 = P[lane + 64u], p2 = P[lane + 128u], p3 = P[lane + 192u];
+    const u32 len = rfl(lens[c]);
+    P[lane] = (u8)c0; P[lane + 64u] = (u8)c1; P[lane + 128u] = (u8)c2; P[lane + 192u] = (u8)c3;
+    if (lane == 0u) lens[c] = off;
+    off += len;
+    if (off > maxn) { err = 8; break; }
+    int n0, n1, n2, n3;
+#define DM_PICK(dst, p) { const int g0 = __shfl(c0, (int)((p) & 63u)), g1 = __shfl(c1, (int)((p) & 63u)), g2 = __shfl(c2, (int)((p) & 63u)), g3 = __shfl(c3, (int)((p) & 63u)); \
+                          dst = (p) < 64u ? g0 : ((p) < 128u ? g1 : ((p) < 192u ? g2 : g3)); }
+    DM_PICK(n0, p0) DM_PICK(n1, p1) DM_PICK(n2, p2) DM_PICK(n3, p3)
+#undef DM_PICK
+    c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+  }
+  if (lane == 0u) { S.nout = off; if (err) atomicMax(&S.err2, err); }
+}
+
+__device__ __forceinline__ void dmtf_expand(const u16 *sym16, const u8 *lists, const u32 *lens, u8 *tt8, dec_lds &S)
+{
+  const u32 lane = threadIdx.x & 63u, w = threadIdx.x >> 6;
+  const u32 nsym = S.nsym;
+  const u32 nchunks = (nsym + DM_CHUNK - 1u) / DM_CHUNK;
+  u8 *wl = S.wl[w];
+  for (;;) {
+    const u32 c = wave_claim(&S.ctr[1]);
+    if (c >= nchunks) break;
+    const u32 s0 = c * DM_CHUNK, s1 = s0 + DM_CHUNK < nsym ? s0 + DM_CHUNK : nsym;
+    wave_sync();
+    reinterpret_cast<u32 *>(wl)[lane] = reinterpret_cast<const u32 *>(lists + (size_t)c * 256u)[lane];
+    wave_sync();
+    u32 pos = rfl(lens[c]);
+    u32 carry = wl[0];                                          /* the list's front: what a run in front of the chunk's first literal repeats */
+    u64 Rprev = run_mask_before(sym16, s0, lane);
+    for (u32 base = s0; base < s1; base += 64u) {
+      const u32 v = base + lane < s1 ? sym16[base + lane] : DM_EOB;
+      const bool run = v <= 1u, lit = v >= 2u && v != DM_EOB;
+      const u64 R = __ballot(run), Lm = __ballot(lit);
+      u32 len = lit ? 1u : 0u;
+      if (run) len = (v + 1u) << run_digit_index(R, Rprev, lane);     /* indices > 20 were refused by dmtf_chunks */
+      Rprev = R;
+      const u32 val = lit ? wl[v - 2u] : 0u;
+      const u64 lower = Lm & lanes_below();
+      const u32 g = (u32)__shfl((int)val, lower ? 63 - (int)__clzll(lower) : (int)lane);
+      const u32 fv = lower ? g : carry;
+      const u32 inc = wave_incl_add(len);
+      const u32 p = pos + inc - len;
+      if (lit) tt8[p] = (u8)val;
+      if (run && len <= 16u) for (u32 r = 0; r < len; r++) tt8[p + r] = (u8)fv;
+      u64 big = __ballot(run && len > 16u);
+      while (big) {
+        const u32 j = (u32)__builtin_ctzll(big);
+        big &= big - 1ull;
+        const u32 P = (u32)__builtin_amdgcn_readlane((int)p, (int)j), Ln = (u32)__builtin_amdgcn_readlane((int)len, (int)j);
+        const u32 F = (u32)__builtin_amdgcn_readlane((int)fv, (int)j);
+        for (u32 r = lane; r < Ln; r += 64u) tt8[P + r] = (u8)F;
+      }
+      pos += (u32)__builtin_amdgcn_readlane((int)inc, 63);
+      if (Lm) carry = (u32)__builtin_amdgcn_readlane((int)val, 63 - (int)__clzll(Lm));
+    }
   }
 }
 
@@ -401,7 +563,6 @@ __device__ __forceinline__ void dsort_block(const lbz_dblock *D, const u8 *tt8, 
  *      CRC (from 0) and, per 16 bytes of W, the output offset + state that k_demit starts from;
  *   5. CRC-32 is linear: crc(A|B) = crc(A) * x^(8|B|) + crc(B) over GF(2)[x]/P -- the chunk CRCs are
  *      shifted by the decoded length behind them (square-and-multiply with x^(8 * 2^k)) and xor-ed.      */
-#define DW_T 256u
 #define DW_LOG 9u
 #define DW_STRIDE (1u << DW_LOG)
 #define DW_MAXS ((LBZ_MAX_BLOCK >> DW_LOG) + 4u)
@@ -627,13 +788,42 @@ k_dblock(const u8 *in, u64 nbytes, lbz_dblock *blocks, u32 nblk, u8 *tt8_base, u
   lbz_dblock *D = &blocks[blk];
   u8 *tt8 = tt8_base + (size_t)blk * cap;
   u32 *tt = tt_base + (size_t)blk * cap;
+  /* scratch of the codes stage, in the block's (not yet used) list array: the symbols, then per chunk of DM_CHUNK
+     symbols 256 bytes (its permutation, later the list it starts with) and a word (its decoded length, later its offset) */
+  u16 *sym16 = reinterpret_cast<u16 *>(tt);
+  const u32 loff = (2u * (cap + 128u) + 255u) & ~255u;
+  u8 *lists = reinterpret_cast<u8 *>(tt) + loff;
+  u32 *lens = reinterpret_cast<u32 *>(lists + (size_t)((cap + 128u) / DM_CHUNK + 2u) * 256u);
   const u64 k0 = wall_clock64();
-  if (tid < 64u) dhuff_block(in, nbytes, D, tt8, cap, U.h);
+  if (tid == 0u) { U.h.ctr[0] = 0; U.h.ctr[1] = 0; U.h.err2 = 0; U.h.nout = 0; U.h.prod = 0; U.h.fin = 0; U.h.nsym = 0; }
+  __syncthreads();
+  /* wave 0 walks the codes; the others turn chunks of symbols into chunks of list indices as they come, and wave 0
+     joins them when it has reached the end of the block */
+  u64 ka = k0;
+  if (tid < 64u) { dhuff_block(in, nbytes, D, sym16, cap, U.h); ka = wall_clock64(); }
+  dmtf_chunks(sym16, lists, lens, U.h);
+  __threadfence_block();
+  __syncthreads();
+  u64 kb = wall_clock64();
+  if (U.h.nsym) {
+    if (tid < 64u && !U.h.err2) dmtf_scan(lists, lens, D->max_block < cap ? D->max_block : cap, U.h);
+    __threadfence_block();
+    __syncthreads();
+    if (!U.h.err2) dmtf_expand(sym16, lists, lens, tt8, U.h);
+    __syncthreads();
+    if (tid == 0u) {
+      u32 err = U.h.err2;
+      const u32 n = U.h.nout;
+      if (!err && (n == 0u || D->orig_ptr >= n)) err = 9;
+      D->nblock = err ? 0u : n;
+      D->err = err;
+    }
+  }
   __threadfence_block();
   __syncthreads();
   const u64 k1 = wall_clock64();
   if (D->err || D->nblock == 0u) {
-    if (tid == 0u) { D->out_len = 0; D->tk[0] = (u32)(k1 - k0); D->tk[1] = D->tk[2] = 0; }
+    if (tid == 0u) { D->out_len = 0; D->tk[0] = (u32)(k1 - k0); D->tk[1] = D->tk[2] = 0; D->tk[3] = (u32)(ka - k0); D->tk[4] = (u32)(kb - ka); D->tk[5] = (u32)(k1 - kb); }
     return;
   }
   dsort_block(D, tt8, tt, U.s);
@@ -641,7 +831,10 @@ k_dblock(const u8 *in, u64 nbytes, lbz_dblock *blocks, u32 nblk, u8 *tt8_base, u
   __syncthreads();
   const u64 k2 = wall_clock64();
   dwalk_block(D, tt, W_base + (size_t)blk * cap, pinfo_base + (size_t)blk * (cap / 16u), U.w);
-  if (tid == 0u) { D->tk[0] = (u32)(k1 - k0); D->tk[1] = (u32)(k2 - k1); D->tk[2] = (u32)(wall_clock64() - k2); }
+  if (tid == 0u) {
+    D->tk[0] = (u32)(k1 - k0); D->tk[1] = (u32)(k2 - k1); D->tk[2] = (u32)(wall_clock64() - k2);
+    D->tk[3] = (u32)(ka - k0); D->tk[4] = (u32)(kb - ka); D->tk[5] = (u32)(k1 - kb);
+  }
 }
 
 /* ------------------------------------------------------------------ k_demit */

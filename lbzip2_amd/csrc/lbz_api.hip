@@ -906,9 +906,12 @@ extern "C" int lbzamd_decompress_device(lbzamd_dctx *c, const void *d_in_v, size
          block's (100 MHz ticks), the pass as a whole is timed by events */
       float t = 0;
       HIPCHK(hipEventElapsedTime(&t, c->ev[1], c->ev[2])); ms[5] += t;
-      u32 tk[3] = { 0, 0, 0 };
-      for (u32 i = 0; i < nb; i++) for (int k = 0; k < 3; k++) tk[k] = std::max(tk[k], hb[b0 + i].tk[k]);
+      u32 tk[6] = { 0, 0, 0, 0, 0, 0 };
+      for (u32 i = 0; i < nb; i++) for (int k = 0; k < 6; k++) tk[k] = std::max(tk[k], hb[b0 + i].tk[k]);
       for (int k = 0; k < 3; k++) ms[1 + k] = std::max(ms[1 + k], tk[k] * 1e-5f);
+      if (getenv("LBZAMD_DTIMES"))
+        fprintf(stderr, "lbzamd: k_dblock %u blocks, slowest: codes %.2f ms (bit chain %.2f, move-to-front chunks %.2f, scan + expansion %.2f), sort %.2f, walk %.2f\n",
+                nb, tk[0] * 1e-5, tk[3] * 1e-5, tk[4] * 1e-5, tk[5] * 1e-5, tk[1] * 1e-5, tk[2] * 1e-5);
     }
     /* the walk: marks in stream order, up to the last candidate of this batch */
     const bool last_batch = b0 + nb >= hb.size();
