@@ -22,11 +22,14 @@
 
 #define DEC_MAX_SEL 18002u
 #define DEC_LUT_BITS 10u
-#define DW_T 256u                     /* threads of a k_dblock workgroup */
+#define DW_TMAX 1024u                 /* threads of a k_dblock workgroup: 256, or DW_TMAX when the file has few blocks */
+#ifndef DH_HALVES
+#define DH_HALVES 2                  /* a strip of the bit chain: 64 DH_HALVES bit offsets */
+#endif
 #define DM_CHUNK 1024u                /* symbols per move-to-front chunk */
 #define DM_EOB 0xFFFFu                /* the end-of-block symbol as stored in the symbol array */
 
-struct dec_lds {
+template <u32 T> struct dec_lds {
   u16 lut[LBZ_MAX_TREES][1u << DEC_LUT_BITS];   /* next 10 bits -> symbol << 5 | code length; 0: a longer code (or none) */
   int limit[LBZ_MAX_TREES][24];       /* per code length l: largest 20-bit window whose top l bits are a code of length <= l (-1: none) */
   int base[LBZ_MAX_TREES][24];        /* perm index = (window >> (20 - l)) - base */
@@ -35,7 +38,7 @@ struct dec_lds {
   u8 len[LBZ_MAX_TREES][LBZ_MAX_ALPHA + 2];
   u32 sel[(DEC_MAX_SEL + 7u) / 8u + 1u];        /* tree of every 50-symbol group, 4 bits each */
   u8 seq2unseq[256];
-  u8 wl[DW_T / 64u][256];             /* dmtf_expand: the list a wave's chunk starts with */
+  u8 wl[T / 64u][256];             /* dmtf_expand: the list a wave's chunk starts with */
   u32 nsym, nout, err2;
   u32 prod, fin;                      /* symbols the bit chain has handed over (a multiple of DM_CHUNK); 1 once it is done and nsym stands */
   u32 ring[260];                      /* dhuff_block: 256 dwords of the stream around the cursor (+ ring[0] again) */
@@ -133,7 +136,7 @@ k_dscan(const u8 *in, u64 nbytes, u64 *marks, u32 *nmarks, u32 cap)
  * and for the wide parts: the input window (ubit), the move-to-front list (256 entries in four vector
  * registers: a front move is one wave_shr), the code tables (built 64 symbols at a time), zero-run fills.
  * Codes of up to 10 bits -- nearly all -- resolve with one LDS lookup.                                     */
-__device__ __forceinline__ void dhuff_block(const u8 *in, u64 nbytes, lbz_dblock *D, u16 *sym16, u32 cap, dec_lds &S)
+template <u32 T> __device__ __forceinline__ void dhuff_block(const u8 *in, u64 nbytes, lbz_dblock *D, u16 *sym16, u32 cap, dec_lds<T> &S)
 {
   const u32 lane = threadIdx.x;                  /* wave 0 of the workgroup */
   const u32 maxn = rfl(D->max_block < cap ? D->max_block : cap);
@@ -255,6 +258,9 @@ __device__ __forceinline__ void dhuff_block(const u8 *in, u64 nbytes, lbz_dblock
     u32 pf = ub_chunk(&b, whi);
     wave_sync();
     u32 groupno = 0, k = LBZ_GROUP, t = 0, pub = 0;
+#ifdef DH_PROF
+    u64 prof[4] = { 0, 0, 0, 0 };
+#endif
     for (;;) {
       if (k == LBZ_GROUP) {                                      /* a group: LBZ_GROUP symbols of one tree */
         if (groupno >= nsel) { err = 5; break; }
@@ -265,7 +271,7 @@ __device__ __forceinline__ void dhuff_block(const u8 *in, u64 nbytes, lbz_dblock
         if ((nsym ^ pub) >= DM_CHUNK) { pub = nsym & ~(DM_CHUNK - 1u); lds_publish(&S.prod, pub); }   /* whole chunks go to the waves that wait in dmtf_chunks */
       }
       const u32 gd = (u32)(G >> 5), g5 = (u32)G & 31u;
-      if ((u32)(whi * 64u - (G >> 5)) < 8u) {                    /* the cursor is within 8 dwords of the ring's end */
+      if ((u32)(whi * 64u - (G >> 5)) < 4u + 2u * DH_HALVES) {   /* the cursor is within a strip (+ a long code) of the ring's end */
         const u32 v = ub_cook(&b, pf, whi);
         S.ring[((u32)whi & 3u) * 64u + lane] = v;
         if (((u32)whi & 3u) == 0u && lane == 0u) S.ring[256] = v;
@@ -273,50 +279,77 @@ __device__ __forceinline__ void dhuff_block(const u8 *in, u64 nbytes, lbz_dblock
         pf = ub_chunk(&b, whi);
         wave_sync();
       }
-      u32 e0, e1, nx0, nx1;
-#define DH_HALF(e, nx, h) {                                                                                  \
-        const u32 pos = g5 + lane + 64u * (h), idx = (gd + (pos >> 5)) & 255u;                                \
-        const u64 w = (u64)S.ring[idx] << 32 | S.ring[idx + 1u];                                              \
-        e = S.lut[t][(u32)((w << (pos & 31u)) >> (64u - DEC_LUT_BITS))];                                       \
-        const u32 len = e & 31u;                                                                              \
-        nx = (len == 0u || lane + len >= 64u) ? lane : lane + len; }
-      DH_HALF(e0, nx0, 0u)
-      DH_HALF(e1, nx1, 1u)
-#undef DH_HALF
-      u32 off, used;
-      u64 M0, M1 = 0;
-      bool stop;                                                 /* the walk ended on an offset without a table entry */
-      huff_walk(nx0, 0u, off, M0);
-      u32 l = (u32)__builtin_amdgcn_readlane((int)e0, (int)off) & 31u;
-      if (l == 0u) { M0 &= ~(1ull << off); used = off; stop = true; }
-      else {
-        huff_walk(nx1, off + l - 64u, off, M1);
-        l = (u32)__builtin_amdgcn_readlane((int)e1, (int)off) & 31u;
-        if (l == 0u) { M1 &= ~(1ull << off); used = 64u + off; stop = true; }
-        else { used = 64u + off + l; stop = false; }
-      }
-      u32 c0 = (u32)__popcll(M0), cnt = c0 + (u32)__popcll(M1);
+#ifdef DH_PROF
+      const u64 p0 = clock64();
+#endif
       const u32 rem = LBZ_GROUP - k;
-      if (cnt >= rem) {                                          /* the group ends in this strip: behind it another tree reads the bits */
-        if (cnt > rem) {
-          const u32 r0 = (u32)__popcll(M0 & lanes_below()), r1 = c0 + (u32)__popcll(M1 & lanes_below());
-          const u64 q0 = __ballot(((M0 >> lane) & 1ull) && r0 == rem), q1 = __ballot(((M1 >> lane) & 1ull) && r1 == rem);
-          if (q0) { used = (u32)__builtin_ctzll(q0); M0 &= (1ull << used) - 1ull; M1 = 0; }
-          else { const u32 q = (u32)__builtin_ctzll(q1); used = 64u + q; M1 &= (1ull << q) - 1ull; }
-          c0 = (u32)__popcll(M0); cnt = rem;
-        }
-        stop = false;
+      u32 cnt = 0, used = 0, start = 0;
+      bool stop = false;                                         /* the walk ended on an offset without a table entry */
+#define DH_HALF(h)                                                                                            \
+      u32 e##h, nx##h, c##h = 0; u64 M##h = 0, Z##h;                                                           \
+      {                                                                                                        \
+        const u32 pos = g5 + lane + 64u * (h), idx = (gd + (pos >> 5)) & 255u;                                 \
+        const u64 w = (u64)S.ring[idx] << 32 | S.ring[idx + 1u];                                               \
+        e##h = S.lut[t][(u32)((w << (pos & 31u)) >> (64u - DEC_LUT_BITS))];                                     \
+        const u32 len = e##h & 31u;                                                                            \
+        Z##h = __ballot(len == 0u);                                                                            \
+        nx##h = (len == 0u || lane + len >= 64u) ? lane | 64u : lane + len;                                    \
       }
-      if ((M0 >> lane) & 1ull) sym16[nsym + (u32)__popcll(M0 & lanes_below())] = (u16)(e0 >> 5);
-      if ((M1 >> lane) & 1ull) sym16[nsym + c0 + (u32)__popcll(M1 & lanes_below())] = (u16)(e1 >> 5);
+      /* walk the offsets 64 h .. 64 h + 63 from `start`; the group may end there (another tree reads the bits behind it) */
+#define DH_WALK(h)                                                                                            \
+      {                                                                                                        \
+        u32 off;                                                                                               \
+        huff_walk(nx##h, start, off, M##h);                                                                    \
+        if ((Z##h >> off) & 1ull) { M##h &= ~(1ull << off); used = 64u * (h) + off; stop = true; }             \
+        else { start = off + ((u32)__builtin_amdgcn_readlane((int)e##h, (int)off) & 31u) - 64u; used = 64u * (h + 1u) + start; } \
+        c##h = (u32)__popcll(M##h);                                                                            \
+        if (cnt + c##h >= rem) {                                                                               \
+          if (cnt + c##h > rem) {                                                                              \
+            const u64 q = __ballot(((M##h >> lane) & 1ull) && (u32)__popcll(M##h & lanes_below()) == rem - cnt); \
+            const u32 at = (u32)__builtin_ctzll(q);                                                            \
+            used = 64u * (h) + at; M##h &= (1ull << at) - 1ull; c##h = rem - cnt;                              \
+          }                                                                                                    \
+          cnt = rem; stop = false;                                                                             \
+          goto walked;                                                                                         \
+        }                                                                                                      \
+        cnt += c##h;                                                                                           \
+        if (stop) goto walked;                                                                                 \
+      }
+#if DH_HALVES == 4
+      DH_HALF(0) DH_HALF(1) DH_HALF(2) DH_HALF(3)
+      DH_WALK(0) DH_WALK(1) DH_WALK(2) DH_WALK(3)
+    walked:
+      huff_store(sym16, nsym, e0, M0);
+      huff_store(sym16, nsym + c0, e1, M1);
+      if (M2) huff_store(sym16, nsym + c0 + c1, e2, M2);
+      if (M3) huff_store(sym16, nsym + c0 + c1 + c2, e3, M3);
+#else
+      DH_HALF(0) DH_HALF(1)
+#ifdef DH_PROF
+      const u32 keep = rfl(nx0 + nx1);
+      const u64 p1 = clock64() + (keep & 0u);
+#endif
+      DH_WALK(0) DH_WALK(1)
+    walked:
+#ifdef DH_PROF
+      const u64 p2 = clock64();
+#endif
+      huff_store(sym16, nsym, e0, M0);
+      huff_store(sym16, nsym + c0, e1, M1);
+#endif
+#undef DH_HALF
+#undef DH_WALK
       nsym += cnt; k += cnt;
       G += used;
+#ifdef DH_PROF
+      { const u64 p3 = clock64(); prof[0] += p1 - p0; prof[1] += p2 - p1; prof[2] += p3 - p2; prof[3]++; }
+#endif
       if (!stop) continue;
       /* a long code or the end of the block */
       const u32 i0 = (u32)(G >> 5) & 255u;
       const u64 w = (u64)rfl(S.ring[i0]) << 32 | rfl(S.ring[i0 + 1u]);
       const u32 code = (u32)((w << ((u32)G & 31u)) >> 44);
-      l = rfl(S.minlen[t]);
+      u32 l = rfl(S.minlen[t]);
       const u32 mx = rfl(S.maxlen[t]);
       while (l <= mx && (int)code > (int)rfl((u32)S.limit[t][l])) l++;
       if (l > mx) { err = 6; break; }
@@ -329,6 +362,9 @@ __device__ __forceinline__ void dhuff_block(const u8 *in, u64 nbytes, lbz_dblock
       nsym++;
       if (sym == eob) break;
     }
+#ifdef DH_PROF
+    if (lane == 0u && !err && (blockIdx.x & 31u) == 0u) printf("blk %u strips %llu: fetch+lookup %llu walk %llu store+count %llu cycles per strip; symbols %u\n", blockIdx.x, prof[3], prof[0] / prof[3], prof[1] / prof[3], prof[2] / prof[3], nsym);
+#endif
   }
   if (lane == 0u) {
     D->stored_crc = stored_crc; D->randomised = randomised; D->orig_ptr = orig_ptr;
@@ -367,7 +403,7 @@ __device__ __forceinline__ u64 run_mask_before(const u16 *sym16, u32 s0, u32 lan
   return __ballot(v <= 1u);
 }
 
-__device__ __forceinline__ void dmtf_chunks(u16 *sym16, u8 *lists, u32 *lens, dec_lds &S)
+template <u32 T> __device__ __forceinline__ void dmtf_chunks(u16 *sym16, u8 *lists, u32 *lens, dec_lds<T> &S)
 {
   const u32 lane = threadIdx.x & 63u;
   for (;;) {
@@ -405,7 +441,7 @@ __device__ __forceinline__ void dmtf_chunks(u16 *sym16, u8 *lists, u32 *lens, de
   }
 }
 
-__device__ __forceinline__ void dmtf_scan(u8 *lists, u32 *lens, u32 maxn, dec_lds &S)
+template <u32 T> __device__ __forceinline__ void dmtf_scan(u8 *lists, u32 *lens, u32 maxn, dec_lds<T> &S)
 {
   const u32 lane = threadIdx.x;                  /* wave 0 */
   const u32 nchunks = (S.nsym + DM_CHUNK - 1u) / DM_CHUNK;
@@ -429,7 +465,7 @@ __device__ __forceinline__ void dmtf_scan(u8 *lists, u32 *lens, u32 maxn, dec_ld
   if (lane == 0u) { S.nout = off; if (err) atomicMax(&S.err2, err); }
 }
 
-__device__ __forceinline__ void dmtf_expand(const u16 *sym16, const u8 *lists, const u32 *lens, u8 *tt8, dec_lds &S)
+template <u32 T> __device__ __forceinline__ void dmtf_expand(const u16 *sym16, const u8 *lists, const u32 *lens, u8 *tt8, dec_lds<T> &S)
 {
   const u32 lane = threadIdx.x & 63u, w = threadIdx.x >> 6;
   const u32 nsym = S.nsym;
@@ -478,21 +514,22 @@ __device__ __forceinline__ void dmtf_expand(const u16 *sym16, const u8 *lists, c
 /* tt[k] = (position of the k-th byte in sorted order) << 8 | byte at position k  (decode.c:852-942).
  * Stable counting sort, 256 positions at a time: ranks inside a wave from match-any ballots, the four
  * waves of a tile in order through per-wave digit counts.                                          */
-struct sort_lds {
+template <u32 T> struct sort_lds {
   u32 cf[256];
-  u32 wcnt[4][256];
+  u32 wcnt[T / 64u][256];
   u32 wsum[4];
 };
-__device__ __forceinline__ void dsort_block(const lbz_dblock *D, const u8 *tt8, u32 *tt, sort_lds &S)
+template <u32 T> __device__ __forceinline__ void dsort_block(const lbz_dblock *D, const u8 *tt8, u32 *tt, sort_lds<T> &S)
 {
+  constexpr u32 NWV = T / 64u;
   u32 (&cf)[256] = S.cf;
-  u32 (&wcnt)[4][256] = S.wcnt;
+  u32 (&wcnt)[NWV][256] = S.wcnt;
   u32 (&wsum)[4] = S.wsum;
   const u32 tid = threadIdx.x, lane = tid & 63u, w = tid >> 6;
   const u32 n = D->nblock;
-  for (u32 i = tid; i < 1024u; i += 256u) (&wcnt[0][0])[i] = 0;
+  for (u32 i = tid; i < NWV * 256u; i += T) (&wcnt[0][0])[i] = 0;
   __syncthreads();
-  for (u32 i0 = 0; i0 < n; i0 += 256u) {                        /* byte counts (a wave's equal bytes in one add) and tt = bytes */
+  for (u32 i0 = 0; i0 < n; i0 += T) {                        /* byte counts (a wave's equal bytes in one add) and tt = bytes */
     const u32 i = i0 + tid;
     const bool ok = i < n;
     const u32 d = ok ? tt8[i] : 0u;
@@ -507,19 +544,22 @@ __device__ __forceinline__ void dsort_block(const lbz_dblock *D, const u8 *tt8, 
     if (ok && (mask & lanes_below()) == 0ull) wcnt[w][d] += (u32)__popcll(mask);
   }
   __syncthreads();
-  {
-    const u32 c = wcnt[0][tid] + wcnt[1][tid] + wcnt[2][tid] + wcnt[3][tid];
+  {                                                             /* the first 256 threads: one byte value each */
+    u32 c = 0;
+    if (tid < 256u) for (u32 k = 0; k < NWV; k++) c += wcnt[k][tid];
     u32 inc = c;
     for (u32 d = 1; d < 64u; d <<= 1) { const u32 o = (u32)__shfl_up((int)inc, d); if (lane >= d) inc += o; }
-    if (lane == 63u) wsum[w] = inc;
+    if (tid < 256u && lane == 63u) wsum[w] = inc;
     __syncthreads();
-    u32 basev = 0;
-    for (u32 i = 0; i < w; i++) basev += wsum[i];
-    cf[tid] = basev + inc - c;
+    if (tid < 256u) {
+      u32 basev = 0;
+      for (u32 i = 0; i < w; i++) basev += wsum[i];
+      cf[tid] = basev + inc - c;
+    }
   }
   __syncthreads();
-  for (u32 t0 = 0; t0 < n; t0 += 256u) {
-    for (u32 i = tid; i < 1024u; i += 256u) (&wcnt[0][0])[i] = 0;
+  for (u32 t0 = 0; t0 < n; t0 += T) {
+    for (u32 i = tid; i < NWV * 256u; i += T) (&wcnt[0][0])[i] = 0;
     __syncthreads();
     const u32 i = t0 + tid;
     const bool ok = i < n;
@@ -540,7 +580,7 @@ __device__ __forceinline__ void dsort_block(const lbz_dblock *D, const u8 *tt8, 
       tt[dst] |= i << 8;
     }
     __syncthreads();
-    cf[tid] += wcnt[0][tid] + wcnt[1][tid] + wcnt[2][tid] + wcnt[3][tid];
+    if (tid < 256u) { u32 c = 0; for (u32 k = 0; k < NWV; k++) c += wcnt[k][tid]; cf[tid] += c; }
     __syncthreads();
   }
 }
@@ -549,10 +589,10 @@ __device__ __forceinline__ void dsort_block(const lbz_dblock *D, const u8 *tt8, 
 /* The walk (decode.c:944-1146 is one pointer chase per block: n dependent loads) done as LIST RANKING so
  * that a block has hundreds of chases in flight instead of one:
  *
- *   1. every 512th list node (and the start node) is a splitter; from each splitter a lane follows the list
+ *   1. every 2^LOG-th list node (512th or 256th, see below; and the start node) is a splitter; from each splitter a lane follows the list
  *      to the next splitter and records (steps, splitter reached).  Lanes take splitters from a counter,
  *      so a long sublist does not hold the others up;
- *   2. one lane ranks the <= 1760 splitters: sublist k starts at output offset off[k].  A list that closes
+ *   2. one lane ranks the <= 1760 (3520) splitters: sublist k starts at output offset off[k].  A list that closes
  *      before n steps (the block is periodic: the BWT permutation has several cycles) gives the period;
  *   3. the sublists are followed again, bytes go to W[off[k] + j]; a periodic block is filled from its
  *      first period;
@@ -563,20 +603,20 @@ __device__ __forceinline__ void dsort_block(const lbz_dblock *D, const u8 *tt8, 
  *      CRC (from 0) and, per 16 bytes of W, the output offset + state that k_demit starts from;
  *   5. CRC-32 is linear: crc(A|B) = crc(A) * x^(8|B|) + crc(B) over GF(2)[x]/P -- the chunk CRCs are
  *      shifted by the decoded length behind them (square-and-multiply with x^(8 * 2^k)) and xor-ed.      */
-#define DW_LOG 9u
-#define DW_STRIDE (1u << DW_LOG)
-#define DW_MAXS ((LBZ_MAX_BLOCK >> DW_LOG) + 4u)
+/* splitters every 2^LOG list nodes: 512 for the 256-thread kernel; 256 for the 1024-thread one, whose blocks have the chip
+   almost to themselves and wait for their LONGEST sublist (~ 2^LOG ln(n / 2^LOG) nodes, one dependent load each) */
 #define DW_NONE 0xFFFFFFFFu
 #define CRC_POLY 0x04C11DB7u
 
-struct walk_lds {
-  u32 len[DW_MAXS], nxt[DW_MAXS], off[DW_MAXS];
+template <u32 T, u32 LOG> struct walk_lds {
+  static constexpr u32 MAXS = (LBZ_MAX_BLOCK >> LOG) + 4u;
+  u32 len[MAXS], nxt[MAXS], off[MAXS];
   u32 crctab[256];
   u32 pow8[32];
-  u32 fn[DW_T];          /* chunk maps, 3 bits per start state */
-  u32 olen[DW_T];        /* decoded bytes of the chunk, then the exclusive prefix */
+  u32 fn[T];             /* chunk maps, 3 bits per start state */
+  u32 olen[T];           /* decoded bytes of the chunk, then the exclusive prefix */
   u32 ctr, ctr2, period, total;
-  u32 xr[4];
+  u32 xr[T / 64u];
 };
 
 __device__ __forceinline__ u32 dec_crc_step(const u32 *tab, u32 crc, u32 byte) { return (crc << 8) ^ tab[(crc >> 24) ^ byte]; }
@@ -596,11 +636,12 @@ __device__ __forceinline__ u32 crc_shift(const u32 *pow8, u32 v, u32 nbytes)    
 }
 __device__ __forceinline__ u32 rle_step(u32 c, bool eq) { return eq ? (c == 4u ? 0u : c + 1u) : (c == 4u ? 0u : 1u); }
 
-__device__ __forceinline__ void dwalk_block(lbz_dblock *D, const u32 *tt, u8 *W, u32 *pinfo, walk_lds &S)
+template <u32 T, u32 LOG> __device__ __forceinline__ void dwalk_block(lbz_dblock *D, const u32 *tt, u8 *W, u32 *pinfo, walk_lds<T, LOG> &S)
 {
+  constexpr u32 DW_LOG = LOG, DW_STRIDE = 1u << LOG;
   const u32 tid = threadIdx.x;
   const u32 n = D->nblock;
-  {
+  if (tid < 256u) {
     u32 c = tid << 24;
     for (u32 k = 0; k < 8u; k++) c = (c & 0x80000000u) ? (c << 1) ^ CRC_POLY : c << 1;
     S.crctab[tid] = c;
@@ -615,7 +656,7 @@ __device__ __forceinline__ void dwalk_block(lbz_dblock *D, const u32 *tt, u8 *W,
   const bool extra = (t0 & (DW_STRIDE - 1u)) != 0u;
   const u32 ns = ns0 + (extra ? 1u : 0u);
   const u32 start_id = extra ? ns0 : t0 >> DW_LOG;
-  for (u32 i = tid; i < ns; i += DW_T) S.off[i] = DW_NONE;
+  for (u32 i = tid; i < ns; i += T) S.off[i] = DW_NONE;
   __syncthreads();
 
   /* 1. sublist lengths */
@@ -669,7 +710,7 @@ __device__ __forceinline__ void dwalk_block(lbz_dblock *D, const u32 *tt, u8 *W,
   __syncthreads();
   const u32 period = S.period;
   if (period < n) {
-    for (u32 j = period + tid; j < n; j += DW_T) W[j] = W[j % period];
+    for (u32 j = period + tid; j < n; j += T) W[j] = W[j % period];
     __syncthreads();
   }
 
@@ -677,12 +718,12 @@ __device__ __forceinline__ void dwalk_block(lbz_dblock *D, const u32 *tt, u8 *W,
     /* the format's obsolete "randomised" variant (bzip2 0.9.0 wrote it for blocks it found hard to sort; no current
        compressor does, the reference's decoder still takes it, tests/README "rand"): byte k is flipped iff k + 2 is a
        partial sum of the step table taken cyclically */
-    for (u32 i = tid; i < 512u; i += DW_T) S.nxt[i] = LBZ_RNUMS[i];
+    for (u32 i = tid; i < 512u; i += T) S.nxt[i] = LBZ_RNUMS[i];
     __syncthreads();
     if (tid == 0u) { u32 acc = 0; for (u32 i = 0; i < 512u; i++) { acc += S.nxt[i]; S.nxt[i] = acc; } }
     __syncthreads();
     const u32 cyc = S.nxt[511];
-    for (u32 m = tid;; m += DW_T) {
+    for (u32 m = tid;; m += T) {
       const u32 pos = (m >> 9) * cyc + S.nxt[m & 511u] - 2u;
       if (pos >= n) break;
       W[pos] ^= 1u;
@@ -692,7 +733,7 @@ __device__ __forceinline__ void dwalk_block(lbz_dblock *D, const u32 *tt, u8 *W,
 
   /* 4. chunk maps */
   const u32 npiece = (n + 15u) / 16u;
-  const u32 ppc = (npiece + DW_T - 1u) / DW_T;        /* 16-byte pieces per chunk */
+  const u32 ppc = (npiece + T - 1u) / T;        /* 16-byte pieces per chunk */
   const u32 cs = tid * ppc * 16u < n ? tid * ppc * 16u : n;
   const u32 ce = cs + ppc * 16u < n ? cs + ppc * 16u : n;
   {
@@ -715,7 +756,7 @@ __device__ __forceinline__ void dwalk_block(lbz_dblock *D, const u32 *tt, u8 *W,
   __syncthreads();
   if (tid == 0u) {                                    /* start state of every chunk (kept in fn[]) */
     u32 c = 0;
-    for (u32 t = 0; t < DW_T; t++) { const u32 f = S.fn[t]; S.fn[t] = c; c = (f >> (3u * c)) & 7u; }
+    for (u32 t = 0; t < T; t++) { const u32 f = S.fn[t]; S.fn[t] = c; c = (f >> (3u * c)) & 7u; }
   }
   __syncthreads();
   /* decoded length, CRC from 0 and the per-piece records (offsets relative to the chunk for now) */
@@ -748,9 +789,8 @@ __device__ __forceinline__ void dwalk_block(lbz_dblock *D, const u32 *tt, u8 *W,
   __syncthreads();
   if (tid == 0u) {
     u32 acc = 0;
-    for (u32 t = 0; t < DW_T; t++) { const u32 v = S.olen[t]; S.olen[t] = acc; acc += v; }
+    for (u32 t = 0; t < T; t++) { const u32 v = S.olen[t]; S.olen[t] = acc; acc += v; }
     S.total = acc;
-    S.xr[0] = S.xr[1] = S.xr[2] = S.xr[3] = 0;
   }
   __syncthreads();
   const u32 total = S.total, mybase = S.olen[tid];
@@ -762,7 +802,9 @@ __device__ __forceinline__ void dwalk_block(lbz_dblock *D, const u32 *tt, u8 *W,
   if ((tid & 63u) == 0u) S.xr[tid >> 6] = term;
   __syncthreads();
   if (tid == 0u) {
-    const u32 cc = ~(S.xr[0] ^ S.xr[1] ^ S.xr[2] ^ S.xr[3]);
+    u32 cc = 0;
+    for (u32 k = 0; k < T / 64u; k++) cc ^= S.xr[k];
+    cc = ~cc;
     D->computed_crc = cc;
     D->out_len = total;
     if (cc != D->stored_crc) D->err = 11;
@@ -773,15 +815,15 @@ __device__ __forceinline__ void dwalk_block(lbz_dblock *D, const u32 *tt, u8 *W,
 /* The three stages of one block in one workgroup: a block whose codes are done goes on to its sort and its
  * walk while others still decode, so a pass takes the slowest block's chain, not the sum of the slowest of
  * every stage.  Wave 0 decodes (the other three wait at the barrier); sort and walk use all four.       */
-union dblock_lds {
-  dec_lds h;
-  sort_lds s;
-  walk_lds w;
+template <u32 T> union dblock_lds {
+  dec_lds<T> h;
+  sort_lds<T> s;
+  walk_lds<T, (T > 256u ? 8u : 9u)> w;
 };
-__global__ void __launch_bounds__(DW_T)
-k_dblock(const u8 *in, u64 nbytes, lbz_dblock *blocks, u32 nblk, u8 *tt8_base, u32 *tt_base, u8 *W_base, u32 *pinfo_base, u32 cap)
+template <u32 T> __device__ __forceinline__ void
+dblock_body(const u8 *in, u64 nbytes, lbz_dblock *blocks, u32 nblk, u8 *tt8_base, u32 *tt_base, u8 *W_base, u32 *pinfo_base, u32 cap)
 {
-  __shared__ dblock_lds U;
+  __shared__ dblock_lds<T> U;
   const u32 tid = threadIdx.x;
   const u32 blk = blockIdx.x;
   if (blk >= nblk) return;
@@ -800,7 +842,12 @@ k_dblock(const u8 *in, u64 nbytes, lbz_dblock *blocks, u32 nblk, u8 *tt8_base, u
   /* wave 0 walks the codes; the others turn chunks of symbols into chunks of list indices as they come, and wave 0
      joins them when it has reached the end of the block */
   u64 ka = k0;
-  if (tid < 64u) { dhuff_block(in, nbytes, D, sym16, cap, U.h); ka = wall_clock64(); }
+  if (tid < 64u) {
+    const u64 c0 = clock64();
+    dhuff_block(in, nbytes, D, sym16, cap, U.h);
+    ka = wall_clock64();
+    if (tid == 0u) D->cyc = (u32)(clock64() - c0);
+  }
   dmtf_chunks(sym16, lists, lens, U.h);
   __threadfence_block();
   __syncthreads();
@@ -835,6 +882,19 @@ k_dblock(const u8 *in, u64 nbytes, lbz_dblock *blocks, u32 nblk, u8 *tt8_base, u
     D->tk[0] = (u32)(k1 - k0); D->tk[1] = (u32)(k2 - k1); D->tk[2] = (u32)(wall_clock64() - k2);
     D->tk[3] = (u32)(ka - k0); D->tk[4] = (u32)(kb - ka); D->tk[5] = (u32)(k1 - kb);
   }
+}
+
+/* 256 threads per block when the file has blocks enough for the chip; DW_TMAX when it has few, so that a block's sort and
+ * walk -- latency-bound, a lane at a time -- have four times the lanes (the host picks, lbz_api.hip) */
+__global__ void __launch_bounds__(256)
+k_dblock(const u8 *in, u64 nbytes, lbz_dblock *blocks, u32 nblk, u8 *tt8_base, u32 *tt_base, u8 *W_base, u32 *pinfo_base, u32 cap)
+{
+  dblock_body<256u>(in, nbytes, blocks, nblk, tt8_base, tt_base, W_base, pinfo_base, cap);
+}
+__global__ void __launch_bounds__(DW_TMAX)
+k_dblock_w(const u8 *in, u64 nbytes, lbz_dblock *blocks, u32 nblk, u8 *tt8_base, u32 *tt_base, u8 *W_base, u32 *pinfo_base, u32 cap)
+{
+  dblock_body<DW_TMAX>(in, nbytes, blocks, nblk, tt8_base, tt_base, W_base, pinfo_base, cap);
 }
 
 /* ------------------------------------------------------------------ k_demit */

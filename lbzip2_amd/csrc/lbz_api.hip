@@ -749,7 +749,7 @@ extern "C" long lbzamd_read_stage(lbzamd_ctx *c, uint32_t blk, int stage, void *
 
 struct lbzamd_dctx {
   int device = 0;
-  uint32_t max_blocks = 0, cap = 0;          /* cap: elements per block in the per-block arrays */
+  uint32_t max_blocks = 0, cap = 0, ncus = 0; /* cap: elements per block in the per-block arrays */
   hipStream_t q = nullptr;
   hipEvent_t ev[7] = {};
   u8 *tt8 = nullptr, *W = nullptr;
@@ -783,6 +783,7 @@ extern "C" int lbzamd_dcreate(lbzamd_dctx **out, int device, unsigned max_blocks
   HIPCHK(hipSetDevice(device));
   lbzamd_dctx *c = new lbzamd_dctx;
   c->device = device;
+  { hipDeviceProp_t prop; HIPCHK(hipGetDeviceProperties(&prop, device)); c->ncus = (uint32_t)prop.multiProcessorCount; }
   c->max_blocks = max_blocks;
   c->cap = round_up(LBZ_MAX_BLOCK + 64u, 256u);
   c->marks_cap = 1u << 20;
@@ -897,7 +898,11 @@ extern "C" int lbzamd_decompress_device(lbzamd_dctx *c, const void *d_in_v, size
     if (nb) {
       HIPCHK(hipMemcpyAsync(c->blocks, hb.data() + b0, nb * sizeof(lbz_dblock), hipMemcpyHostToDevice, q));
       HIPCHK(hipEventRecord(c->ev[1], q));
-      hipLaunchKernelGGL(k_dblock, dim3(nb), dim3(256), 0, q, d_in, (u64)len, c->blocks, nb, c->tt8, c->tt, c->W, c->pinfo, c->cap);
+      /* few blocks: 1024 threads each (two such workgroups fit a CU); LBZAMD_DWIDE=0/1 forces either */
+      const char *dw = getenv("LBZAMD_DWIDE");
+      const bool wide = dw ? dw[0] == '1' : nb <= 2u * c->ncus;
+      if (wide) hipLaunchKernelGGL(k_dblock_w, dim3(nb), dim3(1024), 0, q, d_in, (u64)len, c->blocks, nb, c->tt8, c->tt, c->W, c->pinfo, c->cap);
+      else hipLaunchKernelGGL(k_dblock, dim3(nb), dim3(256), 0, q, d_in, (u64)len, c->blocks, nb, c->tt8, c->tt, c->W, c->pinfo, c->cap);
       HIPCHK(hipEventRecord(c->ev[2], q));
       HIPCHK(hipMemcpyAsync(hb.data() + b0, c->blocks, nb * sizeof(lbz_dblock), hipMemcpyDeviceToHost, q));
       HIPCHK(hipStreamSynchronize(q));
@@ -909,9 +914,12 @@ extern "C" int lbzamd_decompress_device(lbzamd_dctx *c, const void *d_in_v, size
       u32 tk[6] = { 0, 0, 0, 0, 0, 0 };
       for (u32 i = 0; i < nb; i++) for (int k = 0; k < 6; k++) tk[k] = std::max(tk[k], hb[b0 + i].tk[k]);
       for (int k = 0; k < 3; k++) ms[1 + k] = std::max(ms[1 + k], tk[k] * 1e-5f);
-      if (getenv("LBZAMD_DTIMES"))
-        fprintf(stderr, "lbzamd: k_dblock %u blocks, slowest: codes %.2f ms (bit chain %.2f, move-to-front chunks %.2f, scan + expansion %.2f), sort %.2f, walk %.2f\n",
-                nb, tk[0] * 1e-5, tk[3] * 1e-5, tk[4] * 1e-5, tk[5] * 1e-5, tk[1] * 1e-5, tk[2] * 1e-5);
+      if (getenv("LBZAMD_DTIMES")) {
+        double mhz = 0;
+        for (u32 i = 0; i < nb; i++) if (hb[b0 + i].tk[3] == tk[3] && tk[3]) mhz = hb[b0 + i].cyc / (tk[3] * 1e-5 * 1e3);
+        fprintf(stderr, "lbzamd: k_dblock %u blocks, slowest: codes %.2f ms (bit chain %.2f at %.0f MHz, move-to-front chunks %.2f, scan + expansion %.2f), sort %.2f, walk %.2f\n",
+                nb, tk[0] * 1e-5, tk[3] * 1e-5, mhz, tk[4] * 1e-5, tk[5] * 1e-5, tk[1] * 1e-5, tk[2] * 1e-5);
+      }
     }
     /* the walk: marks in stream order, up to the last candidate of this batch */
     const bool last_batch = b0 + nb >= hb.size();

@@ -19,13 +19,15 @@ __device__ __forceinline__ int wave_shr1(int v)
 }
 
 /* The decoder's bit chain (k_decode.hip, dhuff_block): lane j of `nx` holds the bit offset of the code BEHIND the code
- * that starts at offset j (j itself where the walk must stop: no table entry, or the next code starts outside these 64
- * offsets).  Starting at `start`, follow the offsets until one points at itself; M collects the offsets visited
- * (the stop included), off is the stop.  A hop is one v_readlane whose lane select is the previous one's result (4 wait
- * states between them, one of which marks the offset); no branch for four hops -- hopping on from the stop goes nowhere. */
+ * that starts at offset j, or j | 64 where the walk must stop (no table entry, or the next code starts outside these 64
+ * offsets).  Starting at `start`, follow the offsets to a stop; M collects the offsets visited (the stop included), off
+ * is the stop.  A hop is one v_readlane whose lane select (its low six bits) is the previous one's result -- ~31 cycles
+ * from result to result whatever stands between them (tests/tools/micro/hops.hip), and a scalar instruction that reads
+ * such a result waits for it too, so the offsets are marked ten at a time behind the hops; hopping on from a stop goes
+ * nowhere. */
 __device__ __forceinline__ void huff_walk(unsigned nx, unsigned start, unsigned &off, unsigned long long &M)
 {
-  unsigned n1, n2, n3;
+  unsigned n1, n2, n3, n4, n5, n6, n7, n8, n9;
   asm volatile(
     "s_mov_b64 %[M], 0\n\t"
     "s_mov_b32 %[off], %[start]\n"
@@ -34,19 +36,56 @@ __device__ __forceinline__ void huff_walk(unsigned nx, unsigned start, unsigned 
     "s_bitset1_b64 %[M], %[off]\n\t"
     "s_nop 2\n\t"
     "v_readlane_b32 %[n2], %[nx], %[n1]\n\t"
-    "s_bitset1_b64 %[M], %[n1]\n\t"
-    "s_nop 2\n\t"
+    "s_nop 3\n\t"
     "v_readlane_b32 %[n3], %[nx], %[n2]\n\t"
+    "s_nop 3\n\t"
+    "v_readlane_b32 %[n4], %[nx], %[n3]\n\t"
+    "s_nop 3\n\t"
+    "v_readlane_b32 %[n5], %[nx], %[n4]\n\t"
+    "s_nop 3\n\t"
+    "v_readlane_b32 %[n6], %[nx], %[n5]\n\t"
+    "s_nop 3\n\t"
+    "v_readlane_b32 %[n7], %[nx], %[n6]\n\t"
+    "s_nop 3\n\t"
+    "v_readlane_b32 %[n8], %[nx], %[n7]\n\t"
+    "s_nop 3\n\t"
+    "v_readlane_b32 %[n9], %[nx], %[n8]\n\t"
+    "s_nop 3\n\t"
+    "v_readlane_b32 %[off], %[nx], %[n9]\n\t"
+    "s_bitset1_b64 %[M], %[n1]\n\t"
     "s_bitset1_b64 %[M], %[n2]\n\t"
-    "s_nop 2\n\t"
-    "v_readlane_b32 %[off], %[nx], %[n3]\n\t"
     "s_bitset1_b64 %[M], %[n3]\n\t"
-    "s_cmp_lg_u32 %[off], %[n3]\n\t"
-    "s_nop 1\n\t"
-    "s_cbranch_scc1 HW_LOOP_%=\n"
-    : [off] "=&s"(off), [M] "=&s"(M), [n1] "=&s"(n1), [n2] "=&s"(n2), [n3] "=&s"(n3)
+    "s_bitset1_b64 %[M], %[n4]\n\t"
+    "s_bitset1_b64 %[M], %[n5]\n\t"
+    "s_bitset1_b64 %[M], %[n6]\n\t"
+    "s_bitset1_b64 %[M], %[n7]\n\t"
+    "s_bitset1_b64 %[M], %[n8]\n\t"
+    "s_bitset1_b64 %[M], %[n9]\n\t"
+    "s_bitcmp0_b32 %[off], 6\n\t"
+    "s_cbranch_scc1 HW_LOOP_%=\n\t"
+    "s_bitset1_b64 %[M], %[off]\n\t"
+    "s_and_b32 %[off], %[off], 63"
+    : [off] "=&s"(off), [M] "=&s"(M), [n1] "=&s"(n1), [n2] "=&s"(n2), [n3] "=&s"(n3), [n4] "=&s"(n4), [n5] "=&s"(n5), [n6] "=&s"(n6), [n7] "=&s"(n7), [n8] "=&s"(n8), [n9] "=&s"(n9)
     : [nx] "v"(nx), [start] "s"(start)
     : "scc");
+}
+
+/* The lanes of M store the symbol of their table entry (e >> 5) side by side from sym16[at] on: the set of lanes IS the
+ * execution mask, a lane's place is the number of set bits below it. */
+__device__ __forceinline__ void huff_store(unsigned short *sym16, unsigned at, unsigned e, unsigned long long M)
+{
+  unsigned r, d;
+  asm volatile(
+    "s_mov_b64 exec, %[M]\n\t"
+    "v_mbcnt_lo_u32_b32 %[r], %[Mlo], 0\n\t"
+    "v_mbcnt_hi_u32_b32 %[r], %[Mhi], %[r]\n\t"
+    "v_lshrrev_b32 %[d], 5, %[e]\n\t"
+    "v_add_lshl_u32 %[r], %[r], %[at], 1\n\t"
+    "global_store_short %[r], %[d], %[base]\n\t"
+    "s_mov_b64 exec, -1"
+    : [r] "=&v"(r), [d] "=&v"(d)
+    : [M] "s"(M), [Mlo] "s"((unsigned)M), [Mhi] "s"((unsigned)(M >> 32)), [e] "v"(e), [at] "s"(at), [base] "s"(sym16)
+    : "memory");
 }
 
 /* The decoder's move-to-front chain over one strip of 64 symbols (k_decode.hip, dmtf_chunks): for every lane i of m, in

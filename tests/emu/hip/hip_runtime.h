@@ -71,6 +71,7 @@ static inline void __threadfence_block() {}
 static inline void __builtin_amdgcn_s_setprio(int) {}
 static inline void __builtin_amdgcn_s_sleep(int) { usleep(50); }   /* a spinning workgroup waits for one that runs on another host thread */
 static inline unsigned long long wall_clock64() { return 0; }
+static inline unsigned long long clock64() { return 0; }
 
 static inline unsigned long long __ballot(int pred) { return emu::wave_ballot(pred); }
 static inline int __any(int pred) { return emu::wave_ballot(pred) != 0; }

@@ -10,11 +10,17 @@ static inline void huff_walk(unsigned nx, unsigned start, unsigned &off, unsigne
 {
   off = start; M = 0;
   for (;;) {
-    M |= 1ull << off;
-    const unsigned n = (unsigned)__builtin_amdgcn_readlane((int)nx, (int)off);
-    if (n == off) break;
-    off = n;
+    M |= 1ull << (off & 63u);
+    if (off & 64u) break;
+    off = (unsigned)__builtin_amdgcn_readlane((int)nx, (int)off);
   }
+  off &= 63u;
+}
+/* C statement of lbz_asm.h's huff_store (same contract) */
+static inline void huff_store(unsigned short *sym16, unsigned at, unsigned e, unsigned long long M)
+{
+  const unsigned lane = threadIdx.x & 63;
+  if ((M >> lane) & 1ull) sym16[at + (unsigned)__builtin_popcountll(M & ((1ull << lane) - 1ull))] = (unsigned short)(e >> 5);
 }
 /* C statement of lbz_asm.h's mtf_strip (same contract) */
 static inline void mtf_strip(int &L0, int &L1, int &L2, int &L3, unsigned v, unsigned long long m, int &outv, unsigned lane)

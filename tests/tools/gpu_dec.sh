@@ -1,7 +1,10 @@
 #!/bin/bash
-# decoder on the GPU: tests/tools/quickdec.py (sizes x kinds, stage timings), optionally the decode tests
-mkdir -p gpurun_out
-[ "$1" = "tests" ] && timeout 900 python -m pytest tests/test_decode.py -x -q -m gpu > gpurun_out/dec_tests.log 2>&1
-timeout 600 python tests/tools/quickdec.py > gpurun_out/dec.log 2>&1
-cat gpurun_out/dec_tests.log 2>/dev/null | tail -3
-cat gpurun_out/dec.log
+# decoder timing of the default library and of variants: tests/tools/gpu_dec.sh [variant ...]
+cd /root/repo
+export PYTHONPATH=/root/repo:/root/repo/tests
+CASES=${LBZ_DEC_CASES:-wiki:1000000000,rand:100000000,mixed:210000000,tar:175000000}
+for v in default "$@"; do
+  echo "== $v"
+  if [ $v = default ]; then unset LBZ_LIB; else export LBZ_LIB=/root/repo/lbzip2_amd/csrc/variants/$v.so; fi
+  LBZAMD_DTIMES=1 LBZ_DEC_CASES=$CASES timeout 250 python tests/tools/quickdec.py 2>&1 | grep -v amdgpu.ids | uniq -w 40
+done
