@@ -6,15 +6,19 @@
  * retrieve() = prefix-code decoding + inverse MTF / zero-run expansion (src/decode.c:519-850),
  * decode() = the counting sort that turns the BWT string into a linked list (src/decode.c:852-942),
  * emit() = the list walk + inverse RLE1 + CRC (src/decode.c:944-1146) -- but the unit of parallelism
- * is the block, not the thread: three of the four stages are serial chains by nature (a bit cursor,
- * a move-to-front list, a pointer chase through a 3.6 MB array), so such a stage runs on ONE lane per
- * block and a thousand blocks hide each other's latency; the counting sort is wide.  The pointer
- * chase is bound by HBM latency (one dependent 4-byte load per output byte), not by bandwidth.
+ * is the block, not the thread, and inside a block only what is serial BY NATURE runs on one wave: the bit cursor
+ * (where a code starts depends on every code before it).  The move-to-front list is serial too, but composes: a chunk
+ * of symbols run from the identity list leaves a permutation, so chunks run on all waves at once and are stitched
+ * together afterwards; the pointer chase through the 3.6 MB list is done as list ranking, the counting sort is wide.
  *
  *   k_dscan   every bit position of the stream is tested for the two 48-bit magics
- *   k_dhuff   header, code tables, prefix-code decoding, inverse MTF, RUNA/RUNB expansion -> BWT bytes
- *   k_dsort   cftab + stable counting sort -> tt[] (next pointer << 8 | byte)
- *   k_dwalk   the walk: RLE1'd bytes W[], decoded size and CRC (inverse RLE1 state machine in the loop)
+ *   k_dblock  one workgroup per block (k_dblock_w: 1024 threads instead of 256, for files of few blocks):
+ *     dhuff_block   header, code tables, the walk from code to code -> symbols              (wave 0)
+ *     dmtf_chunks   symbols -> list indices + a permutation + a decoded length per chunk     (every wave, as the symbols come)
+ *     dmtf_scan     permutations composed, lengths summed                                     (wave 0)
+ *     dmtf_expand   list indices -> bytes, zero runs filled -> the BWT string                 (every wave)
+ *     dsort_block   cftab + stable counting sort -> tt[] (next pointer << 8 | byte)
+ *     dwalk_block   the walk: RLE1'd bytes W[], decoded size and CRC (inverse RLE1 as composed state maps)
  *   k_demit   inverse RLE1 of W[] into the output at the block's offset
  */
 #include "lbz_kernels.h"
@@ -27,6 +31,7 @@
 #define DH_HALVES 2                  /* a strip of the bit chain: 64 DH_HALVES bit offsets */
 #endif
 #define DM_CHUNK 1024u                /* symbols per move-to-front chunk */
+#define DH_EXIT 2048u                 /* dhuff_block: a walk's stop entry with this bit leads on into the next 64 offsets */
 #define DM_EOB 0xFFFFu                /* the end-of-block symbol as stored in the symbol array */
 
 template <u32 T> struct dec_lds {
@@ -130,12 +135,10 @@ k_dscan(const u8 *in, u64 nbytes, u64 *marks, u32 *nmarks, u32 cap)
   }
 }
 
-/* ------------------------------------------------------------------ k_dhuff */
-/* One wave per block.  The stage is one dependent chain (bit cursor -> code -> move-to-front list -> output
- * position), so the whole wave walks it in lockstep with wave-uniform state and the lanes are used as storage
- * and for the wide parts: the input window (ubit), the move-to-front list (256 entries in four vector
- * registers: a front move is one wave_shr), the code tables (built 64 symbols at a time), zero-run fills.
- * Codes of up to 10 bits -- nearly all -- resolve with one LDS lookup.                                     */
+/* ------------------------------------------------------------------ the codes */
+/* One wave per block parses the header, builds the tables (64 symbols at a time, with ballots) and walks the codes; all
+ * its state is wave-uniform and the lanes are used as storage and for the wide parts.  Codes of up to 10 bits -- nearly
+ * all -- resolve with one LDS lookup per bit OFFSET, 128 offsets at a time (see "symbols" below).                   */
 template <u32 T> __device__ __forceinline__ void dhuff_block(const u8 *in, u64 nbytes, lbz_dblock *D, u16 *sym16, u32 cap, dec_lds<T> &S)
 {
   const u32 lane = threadIdx.x;                  /* wave 0 of the workgroup */
@@ -286,22 +289,22 @@ template <u32 T> __device__ __forceinline__ void dhuff_block(const u8 *in, u64 n
       u32 cnt = 0, used = 0, start = 0;
       bool stop = false;                                         /* the walk ended on an offset without a table entry */
 #define DH_HALF(h)                                                                                            \
-      u32 e##h, nx##h, c##h = 0; u64 M##h = 0, Z##h;                                                           \
+      u32 e##h, nx##h, c##h = 0; u64 M##h = 0;                                                                 \
       {                                                                                                        \
         const u32 pos = g5 + lane + 64u * (h), idx = (gd + (pos >> 5)) & 255u;                                 \
         const u64 w = (u64)S.ring[idx] << 32 | S.ring[idx + 1u];                                               \
         e##h = S.lut[t][(u32)((w << (pos & 31u)) >> (64u - DEC_LUT_BITS))];                                     \
-        const u32 len = e##h & 31u;                                                                            \
-        Z##h = __ballot(len == 0u);                                                                            \
-        nx##h = (len == 0u || lane + len >= 64u) ? lane | 64u : lane + len;                                    \
+        const u32 len = e##h & 31u, tgt = lane + len;                                                          \
+        /* a stop: no entry here (j | 64), or the code behind starts in the next 64 offsets, at tgt - 64 (+ DH_EXIT) */ \
+        nx##h = len == 0u ? lane | 64u : (tgt >= 64u ? lane | 64u | DH_EXIT | (tgt - 64u) << 7 : tgt);           \
       }
       /* walk the offsets 64 h .. 64 h + 63 from `start`; the group may end there (another tree reads the bits behind it) */
 #define DH_WALK(h)                                                                                            \
       {                                                                                                        \
-        u32 off;                                                                                               \
-        huff_walk(nx##h, start, off, M##h);                                                                    \
-        if ((Z##h >> off) & 1ull) { M##h &= ~(1ull << off); used = 64u * (h) + off; stop = true; }             \
-        else { start = off + ((u32)__builtin_amdgcn_readlane((int)e##h, (int)off) & 31u) - 64u; used = 64u * (h + 1u) + start; } \
+        u32 raw;                                                                                               \
+        huff_walk(nx##h, start, raw, M##h);                                                                    \
+        if (raw & DH_EXIT) { start = (raw >> 7) & 15u; used = 64u * (h + 1u) + start; }                        \
+        else { M##h &= ~(1ull << (raw & 63u)); used = 64u * (h) + (raw & 63u); stop = true; }                  \
         c##h = (u32)__popcll(M##h);                                                                            \
         if (cnt + c##h >= rem) {                                                                               \
           if (cnt + c##h > rem) {                                                                              \

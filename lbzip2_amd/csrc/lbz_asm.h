@@ -19,13 +19,13 @@ __device__ __forceinline__ int wave_shr1(int v)
 }
 
 /* The decoder's bit chain (k_decode.hip, dhuff_block): lane j of `nx` holds the bit offset of the code BEHIND the code
- * that starts at offset j, or j | 64 where the walk must stop (no table entry, or the next code starts outside these 64
- * offsets).  Starting at `start`, follow the offsets to a stop; M collects the offsets visited (the stop included), off
- * is the stop.  A hop is one v_readlane whose lane select (its low six bits) is the previous one's result -- ~31 cycles
+ * that starts at offset j, or j | 64 | flags where the walk must stop (no table entry, or the next code starts outside
+ * these 64 offsets; the flags say which and where).  Starting at `start`, follow the offsets to a stop; M collects the
+ * offsets visited (the stop included), off is the stop's entry.  A hop is one v_readlane whose lane select (its low six bits) is the previous one's result -- ~31 cycles
  * from result to result whatever stands between them (tests/tools/micro/hops.hip), and a scalar instruction that reads
  * such a result waits for it too, so the offsets are marked ten at a time behind the hops; hopping on from a stop goes
  * nowhere. */
-__device__ __forceinline__ void huff_walk(unsigned nx, unsigned start, unsigned &off, unsigned long long &M)
+__device__ __forceinline__ void huff_walk(unsigned nx, unsigned start, unsigned &off, unsigned long long &M)   /* off: the stop's lane entry as it is (bits 0..5 = its offset) */
 {
   unsigned n1, n2, n3, n4, n5, n6, n7, n8, n9;
   asm volatile(
@@ -63,8 +63,7 @@ __device__ __forceinline__ void huff_walk(unsigned nx, unsigned start, unsigned 
     "s_bitset1_b64 %[M], %[n9]\n\t"
     "s_bitcmp0_b32 %[off], 6\n\t"
     "s_cbranch_scc1 HW_LOOP_%=\n\t"
-    "s_bitset1_b64 %[M], %[off]\n\t"
-    "s_and_b32 %[off], %[off], 63"
+    "s_bitset1_b64 %[M], %[off]"
     : [off] "=&s"(off), [M] "=&s"(M), [n1] "=&s"(n1), [n2] "=&s"(n2), [n3] "=&s"(n3), [n4] "=&s"(n4), [n5] "=&s"(n5), [n6] "=&s"(n6), [n7] "=&s"(n7), [n8] "=&s"(n8), [n9] "=&s"(n9)
     : [nx] "v"(nx), [start] "s"(start)
     : "scc");

@@ -12,9 +12,8 @@ static inline void huff_walk(unsigned nx, unsigned start, unsigned &off, unsigne
   for (;;) {
     M |= 1ull << (off & 63u);
     if (off & 64u) break;
-    off = (unsigned)__builtin_amdgcn_readlane((int)nx, (int)off);
+    off = (unsigned)__builtin_amdgcn_readlane((int)nx, (int)(off & 63u));
   }
-  off &= 63u;
 }
 /* C statement of lbz_asm.h's huff_store (same contract) */
 static inline void huff_store(unsigned short *sym16, unsigned at, unsigned e, unsigned long long M)
