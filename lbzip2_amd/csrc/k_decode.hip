@@ -614,8 +614,11 @@ template <u32 T> __device__ __forceinline__ void dsort_block(const lbz_dblock *D
 template <u32 T, u32 LOG> struct walk_lds {
   static constexpr u32 MAXS = (LBZ_MAX_BLOCK >> LOG) + 4u;
   u32 len[MAXS], nxt[MAXS], off[MAXS];
+  u16 ord[MAXS];         /* the sublists that are on the list, longest first */
+  u32 bins[24], nord;
   u32 crctab[256];
   u32 pow8[32];
+  u32 p8[256], s8[256];  /* x^(8 b) and x^0 + x^8 + .. + x^(8 (b - 1)) mod P: the CRC over b copies of one byte in two multiplications */
   u32 fn[T];             /* chunk maps, 3 bits per start state */
   u32 olen[T];           /* decoded bytes of the chunk, then the exclusive prefix */
   u32 ctr, ctr2, period, total;
@@ -661,7 +664,23 @@ template <u32 T, u32 LOG> __device__ __forceinline__ void dwalk_block(lbz_dblock
   const u32 start_id = extra ? ns0 : t0 >> DW_LOG;
   for (u32 i = tid; i < ns; i += T) S.off[i] = DW_NONE;
   __syncthreads();
+  if (tid < 256u) S.p8[tid] = crc_shift(S.pow8, 1u, tid);
+  __syncthreads();
+  {                                                   /* s8[b] = p8[0] ^ .. ^ p8[b - 1] */
+    const u32 pv = tid < 256u ? S.p8[tid] : 0u;
+    u32 inc = pv;
+    for (u32 d = 1; d < 64u; d <<= 1) { const u32 o = (u32)__shfl_up((int)inc, d); if ((tid & 63u) >= d) inc ^= o; }
+    if (tid < 256u && (tid & 63u) == 63u) S.xr[tid >> 6] = inc;
+    __syncthreads();
+    if (tid < 256u) {
+      u32 v = inc ^ pv;
+      for (u32 w = 0; w < (tid >> 6); w++) v ^= S.xr[w];
+      S.s8[tid] = v;
+    }
+  }
+  __syncthreads();
 
+  const u64 w0 = wall_clock64();
   /* 1. sublist lengths */
   {
     u32 k = atomicAdd(&S.ctr, 1u);
@@ -679,6 +698,7 @@ template <u32 T, u32 LOG> __device__ __forceinline__ void dwalk_block(lbz_dblock
     }
   }
   __syncthreads();
+  const u64 w1 = wall_clock64();
   /* 2. rank the splitters */
   if (tid == 0u) {
     u32 k = start_id, total = 0, steps = 0;
@@ -690,24 +710,45 @@ template <u32 T, u32 LOG> __device__ __forceinline__ void dwalk_block(lbz_dblock
     S.period = total < n ? total : n;
   }
   __syncthreads();
-  /* 3. bytes */
+  const u64 w2 = wall_clock64();
+  /* 3. bytes.  Sublists are taken longest first (by power of two: a counting sort over 20 bins), so that what a lane takes
+     last is short; a lane collects four bytes before it stores -- a store is waited for together with the next load */
+  if (tid < 24u) S.bins[tid] = 0;
+  __syncthreads();
+  for (u32 i = tid; i < ns; i += T) if (S.off[i] != DW_NONE) atomicAdd(&S.bins[31u - (u32)__clz((int)(S.len[i] | 1u))], 1u);
+  __syncthreads();
+  if (tid == 0u) {
+    u32 acc = 0;
+    for (int b = 23; b >= 0; b--) { const u32 c = S.bins[b]; S.bins[b] = acc; acc += c; }
+    S.nord = acc;
+  }
+  __syncthreads();
+  for (u32 i = tid; i < ns; i += T) if (S.off[i] != DW_NONE) S.ord[atomicAdd(&S.bins[31u - (u32)__clz((int)(S.len[i] | 1u))], 1u)] = (u16)i;
+  __syncthreads();
   {
-    u32 k = DW_NONE, node = 0, o = 0, left = 0;
+    const u32 nord = S.nord;
+    u32 node = 0, o = 0, left = 0, acc = 0, nacc = 0;
     for (;;) {
       if (left == 0u) {
-        k = atomicAdd(&S.ctr2, 1u);
-        if (k >= ns) break;
+        const u32 t = atomicAdd(&S.ctr2, 1u);
+        if (t >= nord) break;
+        const u32 k = S.ord[t];
         o = S.off[k];
-        if (o == DW_NONE) continue;
         left = S.len[k];
         if (o + left > n) left = n - o;
         node = k < ns0 ? k << DW_LOG : t0;
         if (left == 0u) continue;
       }
       const u32 x = tt[node];
-      W[o++] = (u8)x;
+      acc |= (x & 255u) << (8u * nacc);
+      nacc++;
       node = x >> 8;
       left--;
+      if (((o + nacc) & 3u) == 0u || left == 0u) {
+        if (nacc == 4u) *reinterpret_cast<u32 *>(W + o) = acc;
+        else for (u32 j = 0; j < nacc; j++) W[o + j] = (u8)(acc >> (8u * j));
+        o += nacc; acc = 0; nacc = 0;
+      }
     }
   }
   __syncthreads();
@@ -734,6 +775,7 @@ template <u32 T, u32 LOG> __device__ __forceinline__ void dwalk_block(lbz_dblock
     __syncthreads();
   }
 
+  const u64 w3 = wall_clock64();
   /* 4. chunk maps */
   const u32 npiece = (n + 15u) / 16u;
   const u32 ppc = (npiece + T - 1u) / T;        /* 16-byte pieces per chunk */
@@ -776,7 +818,8 @@ template <u32 T, u32 LOG> __device__ __forceinline__ void dwalk_block(lbz_dblock
       for (u32 j = 0; j < m; j++) {
         const u32 b = (wq[j >> 2] >> (8u * (j & 3u))) & 255u;
         if (c == 4u) {                                /* a count: b more copies of the run's byte */
-          for (u32 r = 0; r < b; r++) crc = dec_crc_step(S.crctab, crc, pb);
+          if (b >= 48u) crc = gf2_mulmod(crc, S.p8[b]) ^ gf2_mulmod(S.crctab[pb & 255u], S.s8[b]);
+          else for (u32 r = 0; r < b; r++) crc = dec_crc_step(S.crctab, crc, pb);
           outl += b;
           c = 0;
         } else {
@@ -811,6 +854,7 @@ template <u32 T, u32 LOG> __device__ __forceinline__ void dwalk_block(lbz_dblock
     D->computed_crc = cc;
     D->out_len = total;
     if (cc != D->stored_crc) D->err = 11;
+    D->wk[0] = (u32)(w1 - w0); D->wk[1] = (u32)(w2 - w1); D->wk[2] = (u32)(w3 - w2); D->wk[3] = (u32)(wall_clock64() - w3);
   }
 }
 

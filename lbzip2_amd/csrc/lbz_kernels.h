@@ -26,6 +26,7 @@ struct lbz_dblock {
   u32 nblock;         /* length before inverse RLE1 */
   u32 out_len;        /* decoded bytes */
   u32 err;            /* 0 ok; 1..9 malformed block; 11 CRC mismatch */
+  u32 wk[4];          /* ticks of the walk's parts: sublist lengths, ranking, bytes, inverse RLE1 maps + CRC (diagnostic) */
   u32 cyc;            /* shader clock cycles of the bit chain (diagnostic: with tk[3] the clock the wave ran at) */
   u32 tk[6];          /* 100 MHz ticks of the block's three stages (codes, sort, walk); of the codes stage: bit chain, move-to-front chunks, scan + expansion */
 };
