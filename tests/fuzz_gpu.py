@@ -62,6 +62,37 @@ def run(lib, oracle_compress, seed, count, big=False, save=None, small=False):
     return bad
 
 
+def run_decode(lib, seed, count, small=False, both_widths=False):
+    """The inverse path on the same inputs: streams written by Python's bz2 (bzip2's own encoder: bit-aligned blocks, its
+    own code tables) and by this library, one or two streams per file.  Returns the mismatching case indices."""
+    import bz2, os
+    global BIG, SMALL
+    BIG, SMALL = False, small
+    rng = random.Random(seed)
+    bad = []
+    for i in range(count):
+        data = make(rng)
+        level = rng.choice([1, 1, 2, 9])
+        z = bz2.compress(data, level) if rng.random() < 0.6 else lib.compress(data, level)
+        want = data
+        if rng.random() < 0.3:
+            more = make(rng)[:50000]
+            z += bz2.compress(more, rng.choice([1, 9]))
+            want = data + more
+        for wide in (("0", "1") if both_widths else (None,)):
+            if wide is not None:
+                os.environ["LBZAMD_DWIDE"] = wide
+            try:
+                ok = lib.decompress(z) == want
+            except Exception as ex:                                   # noqa: BLE001 -- a refused valid stream is a failure too
+                ok = False
+            if not ok:
+                bad.append((i, len(data), level, wide))
+    if both_widths:
+        os.environ.pop("LBZAMD_DWIDE", None)
+    return bad
+
+
 if __name__ == "__main__":
     sys.path.insert(0, "/root/repo"); sys.path.insert(0, "/root/repo/tests")
     import torch, lbzip2_amd  # noqa: F401
@@ -71,3 +102,5 @@ if __name__ == "__main__":
     t0 = time.time()
     bad = run(lbzip2_amd.library(), L.orc_compress, seed, count, len(sys.argv) > 3 and sys.argv[3] == "big", "/root/repo/gpurun_out")
     print("fuzz seed", seed, "cases", count, "mismatches", bad, "in %.1f s" % (time.time() - t0), flush=True)
+    t0 = time.time()
+    print("decode fuzz seed", seed, "cases", count, "mismatches", run_decode(lbzip2_amd.library(), seed, count, both_widths=True), "in %.1f s" % (time.time() - t0), flush=True)

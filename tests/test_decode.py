@@ -33,6 +33,13 @@ def test_round_trip_of_oracle_streams(emu, name, data, level):
     assert emu.decompress(L.orc_compress(data, level)) == data
 
 
+def test_fuzz_slice(emu):
+    """A slice of tests/fuzz_gpu.py::run_decode small enough for the emulator: structured random inputs, streams of
+    Python's bz2 and of this library, one or two streams per file."""
+    import fuzz_gpu
+    assert fuzz_gpu.run_decode(emu, 31, 40, small=True) == []
+
+
 def test_wide_workgroups(emu, monkeypatch):
     """Files of few blocks are decoded by 1024-thread workgroups (k_dblock_w; lbz_api.hip picks by the block count,
     LBZAMD_DWIDE forces either): same bytes.  The rest of this file runs the 256-thread kernel under the emulator (its
@@ -238,6 +245,15 @@ def test_reference_compress_suite_streams_decode_on_the_gpu():
     with lbzip2_amd.library().decoder(64) as d:
         for name, z in suite_streams(1):
             assert d.decompress(z) == bz2.decompress(z), name
+
+
+@pytest.mark.gpu
+def test_fuzz_on_the_gpu():
+    """tests/fuzz_gpu.py::run_decode: structured random inputs up to 400 000 bytes, streams of Python's bz2 and of this
+    library, one or two streams per file, through both workgroup sizes of k_dblock."""
+    import fuzz_gpu
+    import lbzip2_amd
+    assert fuzz_gpu.run_decode(lbzip2_amd.library(), 41, 120, both_widths=True) == []
 
 
 @pytest.mark.gpu
