@@ -53,7 +53,6 @@ struct lbzamd_ctx {
   /* host-buffer calls: every round's slabs come in on ONE copy stream, in round order at the full rate of the link (copies
      on several streams share it and all arrive late); a short head round on a lane of its own starts the device early */
   hipStream_t copy_q = nullptr, head_q = nullptr;
-  unsigned prio = 0;                          /* LBZAMD_PRIO (experiments): 1 copy stream high, 2 head round high, 4 last lane low */
   std::vector<hipEvent_t> cev;                /* round i's slabs are in device memory */
   hipEvent_t head_ev = nullptr;
   u8 *ws_head = nullptr;                      /* BWT workspaces of the head round */
@@ -110,16 +109,6 @@ static int ctx_free(lbzamd_ctx *c)
 extern "C" void lbzamd_destroy(lbzamd_ctx *c) { ctx_free(c); }
 
 static int ctx_create(lbzamd_ctx **out, int device, unsigned bs100k, unsigned max_slabs, unsigned nslots, unsigned force_streams);
-
-/* level: 1 = the device's highest stream priority, -1 = its lowest.  Streams of different priorities do not share a
- * hardware queue with each other (the runtime keeps a pool of queues per priority). */
-static hipError_t stream_with_priority(hipStream_t *q, int level)
-{
-  int least = 0, greatest = 0;
-  hipError_t e = hipDeviceGetStreamPriorityRange(&least, &greatest);
-  if (e != hipSuccess) return e;
-  return hipStreamCreateWithPriority(q, hipStreamDefault, level > 0 ? greatest : least);
-}
 
 extern "C" int lbzamd_create(lbzamd_ctx **out, int device, unsigned bs100k, unsigned max_slabs, unsigned nslots)
 {
@@ -201,11 +190,10 @@ static int ctx_create(lbzamd_ctx **out, int device, unsigned bs100k, unsigned ma
   ALLOC(c->meta, nblk * sizeof(lbz_block_meta));
   ALLOC(c->st, sizeof(lbz_stream_state));
 #undef ALLOC
-  { const char *pr = getenv("LBZAMD_PRIO"); if (pr) c->prio = (unsigned)atoi(pr); }
   hipError_t e = hipStreamCreate(&c->stream);
   if (e != hipSuccess) { ctx_free(c); return fail_msg("hipStreamCreate", e); }
   for (unsigned i = 0; i + 1 < c->nstreams; i++) {
-    e = ((c->prio & 4u) && i + 2u == c->nstreams) ? stream_with_priority(&c->side[i], -1) : hipStreamCreate(&c->side[i]);
+    e = hipStreamCreate(&c->side[i]);
     if (e != hipSuccess) { ctx_free(c); return fail_msg("hipStreamCreate", e); }
   }
   for (auto &ev : c->ev) {
@@ -321,7 +309,7 @@ static int run_chunk(lbzamd_ctx *c, const u8 *d_in, size_t len, uint32_t nsl, in
     if (fin) {
       uint32_t at = 0;
       if (host_in && nsl > 4u * head && nsl > c->nslots) {
-        if (!c->head_q) HIPCHK((c->prio & 2u) ? stream_with_priority(&c->head_q, 1) : hipStreamCreate(&c->head_q));
+        if (!c->head_q) HIPCHK(hipStreamCreate(&c->head_q));
         if (!c->head_ev) HIPCHK(hipEventCreateWithFlags(&c->head_ev, hipEventDisableTiming));
         if (!c->ws_head) HIPCHK(hipMalloc((void **)&c->ws_head, (size_t)head * (c->slot_bytes + c->spill_bytes)));
         plan.push_back({ 0u, head }); at = head; has_head = true;
@@ -345,7 +333,7 @@ static int run_chunk(lbzamd_ctx *c, const u8 *d_in, size_t len, uint32_t nsl, in
     if (two) for (unsigned k = 0; k + 1 < c->nstreams; k++) HIPCHK(hipStreamWaitEvent(c->side[k], c->ev[1], 0));
     if (has_head) HIPCHK(hipStreamWaitEvent(c->head_q, c->ev[1], 0));
     if (host_in) {
-      if (!c->copy_q) HIPCHK((c->prio & 1u) ? stream_with_priority(&c->copy_q, 1) : hipStreamCreate(&c->copy_q));
+      if (!c->copy_q) HIPCHK(hipStreamCreate(&c->copy_q));
       while (c->cev.size() < nrounds) {
         hipEvent_t e;
         HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
