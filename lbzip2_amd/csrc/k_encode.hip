@@ -41,7 +41,6 @@ struct enc_lds {
   u32 parent[LBZ_MAX_TREES][LBZ_MAX_ALPHA];
   u32 dcnt[LBZ_MAX_TREES][2][32];
   u32 lfreq[LBZ_MAX_ALPHA];
-  u32 pkg[LBZ_MAX_ALPHA];
   u32 items[PM_LEVELS + 1][PM_ITEMS];            /* reused as selector-MTF bytes when packing */
   u16 leaves_in[PM_LEVELS + 1][PM_ITEMS + 2];
   u32 nitems[PM_LEVELS + 2];
@@ -145,32 +144,31 @@ __device__ u32 limited_code(enc_lds *S, u32 t, u32 as)
   if (tid == 0) { S->nitems[1] = as; S->leaves_in[1][0] = 0; }
   __syncthreads();
 
+  /* one barrier per level: the item counts follow from as alone (every thread keeps them), a package's weight is the
+     sum of two items of the level below and is formed where it is compared */
+  u32 nprev = as;
   for (u32 lv = 2; lv <= PM_LEVELS; lv++) {
-    const u32 nprev = S->nitems[lv - 1u];
     const u32 npk = nprev / 2u;
-    if (tid < npk) S->pkg[tid] = S->items[lv - 1u][2u * tid] + S->items[lv - 1u][2u * tid + 1u];
-    __syncthreads();
+    const u32 *below = S->items[lv - 1u];
     for (u32 e = tid; e < as + npk; e += LBZ_WG) {
       if (e < as) {                                     /* leaf: packages strictly lighter go first */
         const u32 f = S->lfreq[e];
         u32 lo = 0, hi = npk;
-        while (lo < hi) { const u32 mid = (lo + hi) >> 1; if (S->pkg[mid] < f) lo = mid + 1u; else hi = mid; }
+        while (lo < hi) { const u32 mid = (lo + hi) >> 1; if (below[2u * mid] + below[2u * mid + 1u] < f) lo = mid + 1u; else hi = mid; }
         const u32 pos = e + lo;
         if (pos < want) { S->items[lv][pos] = f; S->leaves_in[lv][pos + 1u] = (u16)(e + 1u); }
       } else {                                          /* package: leaves of equal weight go first */
         const u32 k = e - as;
-        const u32 f = S->pkg[k];
+        const u32 f = below[2u * k] + below[2u * k + 1u];
         u32 lo = 0, hi = as;
         while (lo < hi) { const u32 mid = (lo + hi) >> 1; if (S->lfreq[mid] <= f) lo = mid + 1u; else hi = mid; }
         const u32 pos = k + lo;
         if (pos < want) { S->items[lv][pos] = f; S->leaves_in[lv][pos + 1u] = (u16)lo; }
       }
     }
-    if (tid == 0) {
-      const u32 tot = as + npk;
-      S->nitems[lv] = tot < want ? tot : want;
-      S->leaves_in[lv][0] = 0;
-    }
+    const u32 tot = as + npk;
+    nprev = tot < want ? tot : want;
+    if (tid == 0) { S->nitems[lv] = nprev; S->leaves_in[lv][0] = 0; }
     __syncthreads();
   }
 
