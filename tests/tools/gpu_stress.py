@@ -26,6 +26,18 @@ for kind, n, seed, level in want:
                 bad += 1
                 print("MISMATCH", kind, n, level, "pass", p, m, fx["out_len"], flush=True)
     print("%s(%d) -%d: %d passes, %.1f s, mismatches so far %d" % (kind, n, level, passes, time.time() - t0, bad), flush=True)
+    # the inverse path on the last stream, as many times (the waves of a block hand symbols to each other through LDS counters)
+    back = torch.empty(n + 64, dtype=torch.uint8, device="cuda")
+    t0 = time.time()
+    with lib.decoder(2 * ((n + M - 1) // M) + 8) as dec:
+        for p in range(passes):
+            back.zero_()
+            k = dec.decompress_device(dst.data_ptr(), m, back.data_ptr(), back.numel())
+            if k != n or not torch.equal(back[:n], src):
+                bad += 1
+                print("DECODE MISMATCH", kind, n, level, "pass", p, k, flush=True)
+    print("   decoded %d times, %.1f s, mismatches so far %d" % (passes, time.time() - t0, bad), flush=True)
+    del back
     del src, dst
     torch.cuda.empty_cache()
 print("STRESS", "OK" if bad == 0 else "FAILED", bad)
