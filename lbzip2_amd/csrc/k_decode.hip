@@ -642,7 +642,7 @@ __device__ __forceinline__ u32 crc_shift(const u32 *pow8, u32 v, u32 nbytes)    
 }
 __device__ __forceinline__ u32 rle_step(u32 c, bool eq) { return eq ? (c == 4u ? 0u : c + 1u) : (c == 4u ? 0u : 1u); }
 
-template <u32 T, u32 LOG> __device__ __forceinline__ void dwalk_block(lbz_dblock *D, const u32 *tt, u8 *W, u32 *pinfo, walk_lds<T, LOG> &S)
+template <u32 T, u32 LOG> __device__ __forceinline__ void dwalk_block(lbz_dblock *D, const u32 *tt, u8 *W, u32 *pinfo, u8 *A, u8 *X, walk_lds<T, LOG> &S)
 {
   constexpr u32 DW_LOG = LOG, DW_STRIDE = 1u << LOG;
   const u32 tid = threadIdx.x;
@@ -681,19 +681,33 @@ template <u32 T, u32 LOG> __device__ __forceinline__ void dwalk_block(lbz_dblock
   __syncthreads();
 
   const u64 w0 = wall_clock64();
-  /* 1. sublist lengths */
+  /* 1. sublist lengths -- and the bytes met on the way: the first 2 * 2^LOG of sublist k go to A (the BWT bytes' array,
+     done with) and X at k * 2^LOG, four at a time, so that the second pass (3.) copies them to their place in order
+     instead of chasing the list again; where a longer sublist goes on is kept in pinfo[k] (not yet in use) */
   {
     u32 k = atomicAdd(&S.ctr, 1u);
-    u32 node = k < ns0 ? k << DW_LOG : t0, cnt = 0;
+    u32 node = k < ns0 ? k << DW_LOG : t0, cnt = 0, acc = 0;
     while (k < ns) {
-      node = tt[node] >> 8;
+      const u32 capk = k < ns0 ? 2u * DW_STRIDE : 0u;
+      const u32 x = tt[node];
+      if (cnt < capk) {
+        acc |= (x & 255u) << (8u * (cnt & 3u));
+        if ((cnt & 3u) == 3u) {
+          *reinterpret_cast<u32 *>((cnt < DW_STRIDE ? A : X) + (k << DW_LOG) + (cnt & (DW_STRIDE - 1u)) - 3u) = acc;
+          acc = 0;
+        }
+      }
+      node = x >> 8;
       cnt++;
+      if (cnt == capk) pinfo[k] = node;
       if ((node & (DW_STRIDE - 1u)) == 0u || node == t0 || cnt >= n) {
+        if (cnt <= capk)
+          for (u32 j = cnt & ~3u; j < cnt; j++) ((j < DW_STRIDE ? A : X) + (k << DW_LOG))[j & (DW_STRIDE - 1u)] = (u8)(acc >> (8u * (j & 3u)));
         S.len[k] = cnt;
         S.nxt[k] = node == t0 ? start_id : node >> DW_LOG;
         k = atomicAdd(&S.ctr, 1u);
         node = k < ns0 ? k << DW_LOG : t0;
-        cnt = 0;
+        cnt = 0; acc = 0;
       }
     }
   }
@@ -711,11 +725,19 @@ template <u32 T, u32 LOG> __device__ __forceinline__ void dwalk_block(lbz_dblock
   }
   __syncthreads();
   const u64 w2 = wall_clock64();
-  /* 3. bytes.  Sublists are taken longest first (by power of two: a counting sort over 20 bins), so that what a lane takes
-     last is short; a lane collects four bytes before it stores -- a store is waited for together with the next load */
+  /* 3. bytes: what pass 1 kept is copied to its place (a wave per sublist, in order); only sublists longer than that are
+     followed again from where the copy ends -- longest first (by power of two: a counting sort over 20 bins), so that what
+     a lane takes last is short; a lane collects four bytes before it stores (a store is waited for together with the next
+     load) */
   if (tid < 24u) S.bins[tid] = 0;
   __syncthreads();
-  for (u32 i = tid; i < ns; i += T) if (S.off[i] != DW_NONE) atomicAdd(&S.bins[31u - (u32)__clz((int)(S.len[i] | 1u))], 1u);
+  for (u32 i = tid; i < ns; i += T) {
+    const u32 o = S.off[i];
+    if (o == DW_NONE) continue;
+    const u32 capk = i < ns0 ? 2u * DW_STRIDE : 0u;
+    const u32 left = o + S.len[i] > n ? n - o : S.len[i];
+    if (left > capk) atomicAdd(&S.bins[31u - (u32)__clz((int)(left - capk))], 1u);
+  }
   __syncthreads();
   if (tid == 0u) {
     u32 acc = 0;
@@ -723,7 +745,13 @@ template <u32 T, u32 LOG> __device__ __forceinline__ void dwalk_block(lbz_dblock
     S.nord = acc;
   }
   __syncthreads();
-  for (u32 i = tid; i < ns; i += T) if (S.off[i] != DW_NONE) S.ord[atomicAdd(&S.bins[31u - (u32)__clz((int)(S.len[i] | 1u))], 1u)] = (u16)i;
+  for (u32 i = tid; i < ns; i += T) {
+    const u32 o = S.off[i];
+    if (o == DW_NONE) continue;
+    const u32 capk = i < ns0 ? 2u * DW_STRIDE : 0u;
+    const u32 left = o + S.len[i] > n ? n - o : S.len[i];
+    if (left > capk) S.ord[atomicAdd(&S.bins[31u - (u32)__clz((int)(left - capk))], 1u)] = (u16)i;
+  }
   __syncthreads();
   {
     const u32 nord = S.nord;
@@ -733,11 +761,12 @@ template <u32 T, u32 LOG> __device__ __forceinline__ void dwalk_block(lbz_dblock
         const u32 t = atomicAdd(&S.ctr2, 1u);
         if (t >= nord) break;
         const u32 k = S.ord[t];
+        const u32 capk = k < ns0 ? 2u * DW_STRIDE : 0u;
         o = S.off[k];
         left = S.len[k];
         if (o + left > n) left = n - o;
-        node = k < ns0 ? k << DW_LOG : t0;
-        if (left == 0u) continue;
+        o += capk; left -= capk;
+        node = k < ns0 ? pinfo[k] : t0;
       }
       const u32 x = tt[node];
       acc |= (x & 255u) << (8u * nacc);
@@ -750,6 +779,13 @@ template <u32 T, u32 LOG> __device__ __forceinline__ void dwalk_block(lbz_dblock
         o += nacc; acc = 0; nacc = 0;
       }
     }
+  }
+  for (u32 k = tid >> 6; k < ns0; k += T / 64u) {
+    const u32 o = S.off[k];
+    if (o == DW_NONE) continue;
+    u32 m = o + S.len[k] > n ? n - o : S.len[k];
+    if (m > 2u * DW_STRIDE) m = 2u * DW_STRIDE;
+    for (u32 j = tid & 63u; j < m; j += 64u) W[o + j] = ((j < DW_STRIDE ? A : X) + (k << DW_LOG))[j & (DW_STRIDE - 1u)];
   }
   __syncthreads();
   const u32 period = S.period;
@@ -868,7 +904,7 @@ template <u32 T> union dblock_lds {
   walk_lds<T, (T > 256u ? 8u : 9u)> w;
 };
 template <u32 T> __device__ __forceinline__ void
-dblock_body(const u8 *in, u64 nbytes, lbz_dblock *blocks, u32 nblk, u8 *tt8_base, u32 *tt_base, u8 *W_base, u32 *pinfo_base, u32 cap)
+dblock_body(const u8 *in, u64 nbytes, lbz_dblock *blocks, u32 nblk, u8 *tt8_base, u32 *tt_base, u8 *W_base, u32 *pinfo_base, u8 *X_base, u32 cap)
 {
   __shared__ dblock_lds<T> U;
   const u32 tid = threadIdx.x;
@@ -924,7 +960,7 @@ dblock_body(const u8 *in, u64 nbytes, lbz_dblock *blocks, u32 nblk, u8 *tt8_base
   __threadfence_block();
   __syncthreads();
   const u64 k2 = wall_clock64();
-  dwalk_block(D, tt, W_base + (size_t)blk * cap, pinfo_base + (size_t)blk * (cap / 16u), U.w);
+  dwalk_block(D, tt, W_base + (size_t)blk * cap, pinfo_base + (size_t)blk * (cap / 16u), tt8, X_base + (size_t)blk * cap, U.w);
   if (tid == 0u) {
     D->tk[0] = (u32)(k1 - k0); D->tk[1] = (u32)(k2 - k1); D->tk[2] = (u32)(wall_clock64() - k2);
     D->tk[3] = (u32)(ka - k0); D->tk[4] = (u32)(kb - ka); D->tk[5] = (u32)(k1 - kb);
@@ -934,14 +970,14 @@ dblock_body(const u8 *in, u64 nbytes, lbz_dblock *blocks, u32 nblk, u8 *tt8_base
 /* 256 threads per block when the file has blocks enough for the chip; DW_TMAX when it has few, so that a block's sort and
  * walk -- latency-bound, a lane at a time -- have four times the lanes (the host picks, lbz_api.hip) */
 __global__ void __launch_bounds__(256)
-k_dblock(const u8 *in, u64 nbytes, lbz_dblock *blocks, u32 nblk, u8 *tt8_base, u32 *tt_base, u8 *W_base, u32 *pinfo_base, u32 cap)
+k_dblock(const u8 *in, u64 nbytes, lbz_dblock *blocks, u32 nblk, u8 *tt8_base, u32 *tt_base, u8 *W_base, u32 *pinfo_base, u8 *X_base, u32 cap)
 {
-  dblock_body<256u>(in, nbytes, blocks, nblk, tt8_base, tt_base, W_base, pinfo_base, cap);
+  dblock_body<256u>(in, nbytes, blocks, nblk, tt8_base, tt_base, W_base, pinfo_base, X_base, cap);
 }
 __global__ void __launch_bounds__(DW_TMAX)
-k_dblock_w(const u8 *in, u64 nbytes, lbz_dblock *blocks, u32 nblk, u8 *tt8_base, u32 *tt_base, u8 *W_base, u32 *pinfo_base, u32 cap)
+k_dblock_w(const u8 *in, u64 nbytes, lbz_dblock *blocks, u32 nblk, u8 *tt8_base, u32 *tt_base, u8 *W_base, u32 *pinfo_base, u8 *X_base, u32 cap)
 {
-  dblock_body<DW_TMAX>(in, nbytes, blocks, nblk, tt8_base, tt_base, W_base, pinfo_base, cap);
+  dblock_body<DW_TMAX>(in, nbytes, blocks, nblk, tt8_base, tt_base, W_base, pinfo_base, X_base, cap);
 }
 
 /* ------------------------------------------------------------------ k_demit */

@@ -752,7 +752,7 @@ struct lbzamd_dctx {
   uint32_t max_blocks = 0, cap = 0, ncus = 0; /* cap: elements per block in the per-block arrays */
   hipStream_t q = nullptr;
   hipEvent_t ev[7] = {};
-  u8 *tt8 = nullptr, *W = nullptr;
+  u8 *tt8 = nullptr, *W = nullptr, *X = nullptr;   /* X: the second half of what the walk's first pass keeps of every sublist */
   u32 *tt = nullptr, *nmarks = nullptr, *pinfo = nullptr;
   u64 *marks = nullptr;
   lbz_dblock *blocks = nullptr;
@@ -766,7 +766,7 @@ struct lbzamd_dctx {
 extern "C" void lbzamd_ddestroy(lbzamd_dctx *c)
 {
   if (!c) return;
-  (void)hipFree(c->tt8); (void)hipFree(c->W); (void)hipFree(c->tt);
+  (void)hipFree(c->tt8); (void)hipFree(c->W); (void)hipFree(c->X); (void)hipFree(c->tt);
   (void)hipFree(c->pinfo); (void)hipFree(c->nmarks); (void)hipFree(c->marks); (void)hipFree(c->blocks); (void)hipFree(c->d_in); (void)hipFree(c->d_out);
   for (auto &e : c->ev) if (e) (void)hipEventDestroy(e);
   if (c->q) (void)hipStreamDestroy(c->q);
@@ -791,6 +791,7 @@ extern "C" int lbzamd_dcreate(lbzamd_dctx **out, int device, unsigned max_blocks
     if (e_ != hipSuccess) { lbzamd_ddestroy(c); return fail_msg("hipMalloc " #p, e_); } } while (0)
   DALLOC(c->tt8, (size_t)max_blocks * c->cap);
   DALLOC(c->W, (size_t)max_blocks * c->cap);
+  DALLOC(c->X, (size_t)max_blocks * c->cap);
   DALLOC(c->tt, (size_t)max_blocks * c->cap * sizeof(u32));
   DALLOC(c->pinfo, (size_t)max_blocks * (c->cap / 16u) * sizeof(u32));
   DALLOC(c->blocks, (size_t)max_blocks * sizeof(lbz_dblock));
@@ -901,8 +902,8 @@ extern "C" int lbzamd_decompress_device(lbzamd_dctx *c, const void *d_in_v, size
       /* few blocks: 1024 threads each (two such workgroups fit a CU); LBZAMD_DWIDE=0/1 forces either */
       const char *dw = getenv("LBZAMD_DWIDE");
       const bool wide = dw ? dw[0] == '1' : nb <= 2u * c->ncus;
-      if (wide) hipLaunchKernelGGL(k_dblock_w, dim3(nb), dim3(1024), 0, q, d_in, (u64)len, c->blocks, nb, c->tt8, c->tt, c->W, c->pinfo, c->cap);
-      else hipLaunchKernelGGL(k_dblock, dim3(nb), dim3(256), 0, q, d_in, (u64)len, c->blocks, nb, c->tt8, c->tt, c->W, c->pinfo, c->cap);
+      if (wide) hipLaunchKernelGGL(k_dblock_w, dim3(nb), dim3(1024), 0, q, d_in, (u64)len, c->blocks, nb, c->tt8, c->tt, c->W, c->pinfo, c->X, c->cap);
+      else hipLaunchKernelGGL(k_dblock, dim3(nb), dim3(256), 0, q, d_in, (u64)len, c->blocks, nb, c->tt8, c->tt, c->W, c->pinfo, c->X, c->cap);
       HIPCHK(hipEventRecord(c->ev[2], q));
       HIPCHK(hipMemcpyAsync(hb.data() + b0, c->blocks, nb * sizeof(lbz_dblock), hipMemcpyDeviceToHost, q));
       HIPCHK(hipStreamSynchronize(q));

@@ -31,8 +31,8 @@ struct lbz_dblock {
   u32 tk[6];          /* 100 MHz ticks of the block's three stages (codes, sort, walk); of the codes stage: bit chain, move-to-front chunks, scan + expansion */
 };
 __global__ void k_dscan(const u8 *in, u64 nbytes, u64 *marks, u32 *nmarks, u32 cap);
-__global__ void k_dblock(const u8 *in, u64 nbytes, lbz_dblock *blocks, u32 nblk, u8 *tt8_base, u32 *tt_base, u8 *W_base, u32 *pinfo_base, u32 cap);
-__global__ void k_dblock_w(const u8 *in, u64 nbytes, lbz_dblock *blocks, u32 nblk, u8 *tt8_base, u32 *tt_base, u8 *W_base, u32 *pinfo_base, u32 cap);   /* 1024 threads per block */
+__global__ void k_dblock(const u8 *in, u64 nbytes, lbz_dblock *blocks, u32 nblk, u8 *tt8_base, u32 *tt_base, u8 *W_base, u32 *pinfo_base, u8 *X_base, u32 cap);
+__global__ void k_dblock_w(const u8 *in, u64 nbytes, lbz_dblock *blocks, u32 nblk, u8 *tt8_base, u32 *tt_base, u8 *W_base, u32 *pinfo_base, u8 *X_base, u32 cap);   /* 1024 threads per block */
 __global__ void k_demit(const lbz_dblock *blocks, u32 nblk, const u8 *W_base, const u32 *pinfo_base, u8 *out, u64 out_cap, u32 cap);
 
 /* slabs [first, first + gridDim.x) of the chunk that starts at `in` */
