@@ -532,11 +532,10 @@ template <u32 T> __device__ __forceinline__ void dsort_block(const lbz_dblock *D
   const u32 n = D->nblock;
   for (u32 i = tid; i < NWV * 256u; i += T) (&wcnt[0][0])[i] = 0;
   __syncthreads();
-  for (u32 i0 = 0; i0 < n; i0 += T) {                        /* byte counts (a wave's equal bytes in one add) and tt = bytes */
+  for (u32 i0 = 0; i0 < n; i0 += T) {                        /* byte counts (a wave's equal bytes in one add) */
     const u32 i = i0 + tid;
     const bool ok = i < n;
     const u32 d = ok ? tt8[i] : 0u;
-    if (ok) tt[i] = d;
     u64 mask = __ballot(ok);
 #pragma unroll
     for (u32 bb = 0; bb < 8u; bb++) {
@@ -580,7 +579,7 @@ template <u32 T> __device__ __forceinline__ void dsort_block(const lbz_dblock *D
     if (ok) {
       u32 dst = cf[d] + below;
       for (u32 w2 = 0; w2 < w; w2++) dst += wcnt[w2][d];
-      tt[dst] |= i << 8;
+      tt[dst] = i << 8 | tt8[dst];                     /* the byte at dst from the 0.9 MB array: no read-modify-write of the list */
     }
     __syncthreads();
     if (tid < 256u) { u32 c = 0; for (u32 k = 0; k < NWV; k++) c += wcnt[k][tid]; cf[tid] += c; }
