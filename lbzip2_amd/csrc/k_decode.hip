@@ -289,7 +289,7 @@ template <u32 T> __device__ __forceinline__ void dhuff_block(const u8 *in, u64 n
       u32 cnt = 0, used = 0, start = 0;
       bool stop = false;                                         /* the walk ended on an offset without a table entry */
 #define DH_HALF(h)                                                                                            \
-      u32 e##h, nx##h, c##h = 0; u64 M##h = 0;                                                                 \
+      u32 e##h, nx##h, nz##h, c##h = 0; u64 M##h = 0;                                                              \
       {                                                                                                        \
         const u32 pos = g5 + lane + 64u * (h), idx = (gd + (pos >> 5)) & 255u;                                 \
         const u64 w = (u64)S.ring[idx] << 32 | S.ring[idx + 1u];                                               \
@@ -297,12 +297,13 @@ template <u32 T> __device__ __forceinline__ void dhuff_block(const u8 *in, u64 n
         const u32 len = e##h & 31u, tgt = lane + len;                                                          \
         /* a stop: no entry here (j | 64), or the code behind starts in the next 64 offsets, at tgt - 64 (+ DH_EXIT) */ \
         nx##h = len == 0u ? lane | 64u : (tgt >= 64u ? lane | 64u | DH_EXIT | (tgt - 64u) << 7 : tgt);           \
+        nz##h = (u32)__shfl((int)nx##h, (int)(nx##h & 63u));          /* two codes on; a stop stays where it is */ \
       }
       /* walk the offsets 64 h .. 64 h + 63 from `start`; the group may end there (another tree reads the bits behind it) */
 #define DH_WALK(h)                                                                                            \
       {                                                                                                        \
         u32 raw;                                                                                               \
-        huff_walk(nx##h, start, raw, M##h);                                                                    \
+        huff_walk(nx##h, nz##h, start, raw, M##h);                                                                  \
         if (raw & DH_EXIT) { start = (raw >> 7) & 15u; used = 64u * (h + 1u) + start; }                        \
         else { M##h &= ~(1ull << (raw & 63u)); used = 64u * (h) + (raw & 63u); stop = true; }                  \
         c##h = (u32)__popcll(M##h);                                                                            \
@@ -352,10 +353,10 @@ template <u32 T> __device__ __forceinline__ void dhuff_block(const u8 *in, u64 n
       const u32 i0 = (u32)(G >> 5) & 255u;
       const u64 w = (u64)rfl(S.ring[i0]) << 32 | rfl(S.ring[i0 + 1u]);
       const u32 code = (u32)((w << ((u32)G & 31u)) >> 44);
-      u32 l = rfl(S.minlen[t]);
-      const u32 mx = rfl(S.maxlen[t]);
-      while (l <= mx && (int)code > (int)rfl((u32)S.limit[t][l])) l++;
-      if (l > mx) { err = 6; break; }
+      /* the shortest length whose largest code is not below the window: every length at once, lane l looks at length l */
+      const u64 fits = __ballot(lane >= S.minlen[t] && lane <= S.maxlen[t] && (int)code <= S.limit[t][lane < 24u ? lane : 0u]);
+      if (fits == 0ull) { err = 6; break; }
+      const u32 l = (u32)__builtin_ctzll(fits);
       const int pi = (int)(code >> (20u - l)) - (int)rfl((u32)S.base[t][l]);
       if (pi < 0 || pi >= (int)alpha) { err = 6; break; }
       const u32 sym = rfl(S.perm[t][pi]);

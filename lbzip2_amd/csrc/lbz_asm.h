@@ -20,52 +20,60 @@ __device__ __forceinline__ int wave_shr1(int v)
 
 /* The decoder's bit chain (k_decode.hip, dhuff_block): lane j of `nx` holds the bit offset of the code BEHIND the code
  * that starts at offset j, or j | 64 | flags where the walk must stop (no table entry, or the next code starts outside
- * these 64 offsets; the flags say which and where).  Starting at `start`, follow the offsets to a stop; M collects the
- * offsets visited (the stop included), off is the stop's entry.  A hop is one v_readlane whose lane select (its low six bits) is the previous one's result -- ~31 cycles
- * from result to result whatever stands between them (tests/tools/micro/hops.hip), and a scalar instruction that reads
- * such a result waits for it too, so the offsets are marked ten at a time behind the hops; hopping on from a stop goes
- * nowhere. */
-__device__ __forceinline__ void huff_walk(unsigned nx, unsigned start, unsigned &off, unsigned long long &M)   /* off: the stop's lane entry as it is (bits 0..5 = its offset) */
+ * these 64 offsets; the flags say which and where); nx2 = nx o nx (a stop maps to itself).  Starting at `start`, follow the
+ * offsets to a stop; M collects the offsets visited (the stop included), off is the stop's entry.  A hop is a v_readlane
+ * whose lane select (its low six bits) is an earlier one's result -- ~31 cycles from result to result whatever stands
+ * between them (tests/tools/micro/hops.hip), so TWO walks are in flight, over the codes of even and of odd number, each
+ * hopping two codes at a time through nx2; a scalar instruction that reads such a result waits for it too, so the offsets
+ * are marked a dozen at a time behind the hops.  Hopping on from a stop goes nowhere, and both walks end on the same one. */
+__device__ __forceinline__ void huff_walk(unsigned nx, unsigned nx2, unsigned start, unsigned &off, unsigned long long &M)
 {
-  unsigned n1, n2, n3, n4, n5, n6, n7, n8, n9;
+  unsigned a0, a1, a2, a3, a4, a5, b0, b1, b2, b3, b4, b5, b6;
   asm volatile(
     "s_mov_b64 %[M], 0\n\t"
-    "s_mov_b32 %[off], %[start]\n"
+    "s_mov_b32 %[a0], %[start]\n\t"
+    "v_readlane_b32 %[b0], %[nx], %[a0]\n\t"
+    "s_nop 3\n"
     "HW_LOOP_%=:\n\t"
-    "v_readlane_b32 %[n1], %[nx], %[off]\n\t"
-    "s_bitset1_b64 %[M], %[off]\n\t"
+    "v_readlane_b32 %[a1], %[nx2], %[a0]\n\t"
+    "v_readlane_b32 %[b1], %[nx2], %[b0]\n\t"
     "s_nop 2\n\t"
-    "v_readlane_b32 %[n2], %[nx], %[n1]\n\t"
-    "s_nop 3\n\t"
-    "v_readlane_b32 %[n3], %[nx], %[n2]\n\t"
-    "s_nop 3\n\t"
-    "v_readlane_b32 %[n4], %[nx], %[n3]\n\t"
-    "s_nop 3\n\t"
-    "v_readlane_b32 %[n5], %[nx], %[n4]\n\t"
-    "s_nop 3\n\t"
-    "v_readlane_b32 %[n6], %[nx], %[n5]\n\t"
-    "s_nop 3\n\t"
-    "v_readlane_b32 %[n7], %[nx], %[n6]\n\t"
-    "s_nop 3\n\t"
-    "v_readlane_b32 %[n8], %[nx], %[n7]\n\t"
-    "s_nop 3\n\t"
-    "v_readlane_b32 %[n9], %[nx], %[n8]\n\t"
-    "s_nop 3\n\t"
-    "v_readlane_b32 %[off], %[nx], %[n9]\n\t"
-    "s_bitset1_b64 %[M], %[n1]\n\t"
-    "s_bitset1_b64 %[M], %[n2]\n\t"
-    "s_bitset1_b64 %[M], %[n3]\n\t"
-    "s_bitset1_b64 %[M], %[n4]\n\t"
-    "s_bitset1_b64 %[M], %[n5]\n\t"
-    "s_bitset1_b64 %[M], %[n6]\n\t"
-    "s_bitset1_b64 %[M], %[n7]\n\t"
-    "s_bitset1_b64 %[M], %[n8]\n\t"
-    "s_bitset1_b64 %[M], %[n9]\n\t"
-    "s_bitcmp0_b32 %[off], 6\n\t"
-    "s_cbranch_scc1 HW_LOOP_%=\n\t"
-    "s_bitset1_b64 %[M], %[off]"
-    : [off] "=&s"(off), [M] "=&s"(M), [n1] "=&s"(n1), [n2] "=&s"(n2), [n3] "=&s"(n3), [n4] "=&s"(n4), [n5] "=&s"(n5), [n6] "=&s"(n6), [n7] "=&s"(n7), [n8] "=&s"(n8), [n9] "=&s"(n9)
-    : [nx] "v"(nx), [start] "s"(start)
+    "v_readlane_b32 %[a2], %[nx2], %[a1]\n\t"
+    "v_readlane_b32 %[b2], %[nx2], %[b1]\n\t"
+    "s_nop 2\n\t"
+    "v_readlane_b32 %[a3], %[nx2], %[a2]\n\t"
+    "v_readlane_b32 %[b3], %[nx2], %[b2]\n\t"
+    "s_nop 2\n\t"
+    "v_readlane_b32 %[a4], %[nx2], %[a3]\n\t"
+    "v_readlane_b32 %[b4], %[nx2], %[b3]\n\t"
+    "s_nop 2\n\t"
+    "v_readlane_b32 %[a5], %[nx2], %[a4]\n\t"
+    "v_readlane_b32 %[b5], %[nx2], %[b4]\n\t"
+    "s_nop 2\n\t"
+    "v_readlane_b32 %[a6], %[nx2], %[a5]\n\t"
+    "v_readlane_b32 %[b6], %[nx2], %[b5]\n\t"
+    "s_bitset1_b64 %[M], %[a0]\n\t"
+    "s_bitset1_b64 %[M], %[b0]\n\t"
+    "s_bitset1_b64 %[M], %[a1]\n\t"
+    "s_bitset1_b64 %[M], %[b1]\n\t"
+    "s_bitset1_b64 %[M], %[a2]\n\t"
+    "s_bitset1_b64 %[M], %[b2]\n\t"
+    "s_bitset1_b64 %[M], %[a3]\n\t"
+    "s_bitset1_b64 %[M], %[b3]\n\t"
+    "s_bitset1_b64 %[M], %[a4]\n\t"
+    "s_bitset1_b64 %[M], %[b4]\n\t"
+    "s_bitset1_b64 %[M], %[a5]\n\t"
+    "s_bitset1_b64 %[M], %[b5]\n\t"
+    "s_bitcmp1_b32 %[a6], 6\n\t"
+    "s_cbranch_scc1 HW_DONE_%=\n\t"
+    "s_mov_b32 %[a0], %[a6]\n\t"
+    "s_mov_b32 %[b0], %[b6]\n\t"
+    "s_branch HW_LOOP_%=\n"
+    "HW_DONE_%=:\n\t"
+    "s_bitset1_b64 %[M], %[a6]\n\t"
+    "s_bitset1_b64 %[M], %[b6]"
+    : [a6] "=&s"(off), [M] "=&s"(M), [a0] "=&s"(a0), [a1] "=&s"(a1), [a2] "=&s"(a2), [a3] "=&s"(a3), [a4] "=&s"(a4), [a5] "=&s"(a5), [b0] "=&s"(b0), [b1] "=&s"(b1), [b2] "=&s"(b2), [b3] "=&s"(b3), [b4] "=&s"(b4), [b5] "=&s"(b5), [b6] "=&s"(b6)
+    : [nx] "v"(nx), [nx2] "v"(nx2), [start] "s"(start)
     : "scc");
 }
 

@@ -5,15 +5,19 @@
 static inline int lane_write(int old, int val, int lane) { return (int)(threadIdx.x & 63) == lane ? val : old; }
 static inline int wave_shr1(int v) { const int o = __shfl_up(v, 1u); return (threadIdx.x & 63) == 0 ? v : o; }
 static inline int wave_shl1(int v) { const int o = __shfl_down(v, 1u); return (threadIdx.x & 63) == 63 ? v : o; }
-/* C statement of lbz_asm.h's huff_walk (same contract) */
-static inline void huff_walk(unsigned nx, unsigned start, unsigned &off, unsigned long long &M)
+/* C statement of lbz_asm.h's huff_walk (same contract): the walks over the codes of even and of odd number */
+static inline void huff_walk(unsigned nx, unsigned nx2, unsigned start, unsigned &off, unsigned long long &M)
 {
-  off = start; M = 0;
+  unsigned a = start, b = (unsigned)__builtin_amdgcn_readlane((int)nx, (int)start);
+  M = 0;
   for (;;) {
-    M |= 1ull << (off & 63u);
-    if (off & 64u) break;
-    off = (unsigned)__builtin_amdgcn_readlane((int)nx, (int)(off & 63u));
+    M |= 1ull << (a & 63u);
+    M |= 1ull << (b & 63u);
+    if (a & 64u) break;
+    a = (unsigned)__builtin_amdgcn_readlane((int)nx2, (int)(a & 63u));
+    b = (unsigned)__builtin_amdgcn_readlane((int)nx2, (int)(b & 63u));
   }
+  off = a;
 }
 /* C statement of lbz_asm.h's huff_store (same contract) */
 static inline void huff_store(unsigned short *sym16, unsigned at, unsigned e, unsigned long long M)
