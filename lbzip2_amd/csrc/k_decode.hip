@@ -120,17 +120,38 @@ __device__ __forceinline__ u64 ub_bitpos(const ubit *b) { return b->dw * 32ull -
 __global__ void __launch_bounds__(256)
 k_dscan(const u8 *in, u64 nbytes, u64 *marks, u32 *nmarks, u32 cap)
 {
-  const u64 p = (u64)blockIdx.x * 256u + threadIdx.x;
-  if (p + 6u > nbytes) return;
-  u64 v = 0;
-  for (u32 i = 0; i < 8u; i++) v = (v << 8) | (u64)(p + i < nbytes ? in[p + i] : 0u);
-  for (u32 s = 0; s < 8u; s++) {
-    if (s && p + 7u > nbytes) break;
-    const u64 w = (v >> (16u - s)) & 0xFFFFFFFFFFFFull;
+  /* a thread takes the eight byte positions of one aligned 8-byte word (two 8-byte loads: the word and its successor)
+     and tests their 64 bit offsets; grid = LBZ_DSCAN_GRID(nbytes) */
+  const u32 mis = (u32)((uintptr_t)in & 7u);
+  const u64 *base = reinterpret_cast<const u64 *>(in - mis);
+  const u64 nwords = (mis + nbytes + 7u) >> 3;
+  const u64 g = (u64)blockIdx.x * 256u + threadIdx.x;
+  if (g >= nwords) return;
+  u64 a = base[g], b = g + 1u < nwords ? base[g + 1u] : 0ull;
+  /* bytes of these words in front of in[0] or behind in[nbytes - 1] read as zero (they are in the same aligned word as
+     bytes of the stream: no fault, nothing of them is used) */
+  const long long r0 = (long long)(g * 8u) - (long long)mis;           /* stream position of byte 0 of word a */
+  for (u32 k = 0; k < 8u; k++) {
+    const long long ra = r0 + (long long)k, rb = ra + 8;
+    if (ra < 0 || (u64)ra >= nbytes) a &= ~(0xFFull << (8u * k));
+    if ((u64)rb >= nbytes) b &= ~(0xFFull << (8u * k));
+  }
+  const u64 hi = __builtin_bswap64(a), lo = __builtin_bswap64(b);
+  const u32 W[4] = { (u32)(hi >> 32), (u32)hi, (u32)(lo >> 32), (u32)lo };
+  /* the first 32 bits of either magic at bit offset t of the 128 bits: one funnel shift and two compares; the rare hit
+     is checked in full */
+#pragma unroll
+  for (u32 t = 0; t < 64u; t++) {
+    const u32 top = (t & 31u) ? (W[t >> 5] << (t & 31u)) | (W[(t >> 5) + 1u] >> (32u - (t & 31u))) : W[t >> 5];
+    if (top != 0x31415926u && top != 0x17724538u) continue;
+    const long long p = r0 + (long long)(t >> 3);
+    const u32 sh = t & 7u;
+    if (p < 0 || (u64)p + (sh ? 7u : 6u) > nbytes) continue;
+    const u64 w = ((t ? (hi << t) | (lo >> (64u - t)) : hi) >> 16);
     const int kind = w == 0x314159265359ull ? 0 : (w == 0x177245385090ull ? 1 : -1);
     if (kind >= 0) {
       const u32 k = atomicAdd(nmarks, 1u);
-      if (k < cap) marks[k] = ((p * 8ull + s) << 1) | (u64)kind;
+      if (k < cap) marks[k] = (((u64)p * 8ull + sh) << 1) | (u64)kind;
     }
   }
 }

@@ -827,7 +827,7 @@ extern "C" int lbzamd_decompress_device(lbzamd_dctx *c, const void *d_in_v, size
   /* 1. magics */
   HIPCHK(hipEventRecord(c->ev[0], q));
   HIPCHK(hipMemsetAsync(c->nmarks, 0, sizeof(u32), q));
-  hipLaunchKernelGGL(k_dscan, dim3((u32)((len + 255u) / 256u)), dim3(256), 0, q, d_in, (u64)len, c->marks, c->nmarks, c->marks_cap);
+  hipLaunchKernelGGL(k_dscan, dim3(LBZ_DSCAN_GRID((u64)len)), dim3(256), 0, q, d_in, (u64)len, c->marks, c->nmarks, c->marks_cap);
   HIPCHK(hipEventRecord(c->ev[1], q));
   u32 nm = 0;
   HIPCHK(hipMemcpyAsync(&nm, c->nmarks, sizeof nm, hipMemcpyDeviceToHost, q));
@@ -837,7 +837,7 @@ extern "C" int lbzamd_decompress_device(lbzamd_dctx *c, const void *d_in_v, size
     HIPCHK(hipMalloc((void **)&c->marks, (size_t)nm * sizeof(u64)));
     c->marks_cap = nm;
     HIPCHK(hipMemsetAsync(c->nmarks, 0, sizeof(u32), q));
-    hipLaunchKernelGGL(k_dscan, dim3((u32)((len + 255u) / 256u)), dim3(256), 0, q, d_in, (u64)len, c->marks, c->nmarks, c->marks_cap);
+    hipLaunchKernelGGL(k_dscan, dim3(LBZ_DSCAN_GRID((u64)len)), dim3(256), 0, q, d_in, (u64)len, c->marks, c->nmarks, c->marks_cap);
     HIPCHK(hipMemcpyAsync(&nm, c->nmarks, sizeof nm, hipMemcpyDeviceToHost, q));
     HIPCHK(hipStreamSynchronize(q));
     if (nm > c->marks_cap) { g_err = "lbzamd_decompress: the list of magics changed between two scans"; return -1; }

@@ -30,6 +30,7 @@ struct lbz_dblock {
   u32 cyc;            /* shader clock cycles of the bit chain (diagnostic: with tk[3] the clock the wave ran at) */
   u32 tk[6];          /* 100 MHz ticks of the block's three stages (codes, sort, walk); of the codes stage: bit chain, move-to-front chunks, scan + expansion */
 };
+#define LBZ_DSCAN_GRID(nbytes) ((u32)((((nbytes) + 14u) / 8u + 255u) / 256u))      /* one thread per aligned 8-byte word */
 __global__ void k_dscan(const u8 *in, u64 nbytes, u64 *marks, u32 *nmarks, u32 cap);
 __global__ void k_dblock(const u8 *in, u64 nbytes, lbz_dblock *blocks, u32 nblk, u8 *tt8_base, u32 *tt_base, u8 *W_base, u32 *pinfo_base, u8 *X_base, u32 cap);
 __global__ void k_dblock_w(const u8 *in, u64 nbytes, lbz_dblock *blocks, u32 nblk, u8 *tt8_base, u32 *tt_base, u8 *W_base, u32 *pinfo_base, u8 *X_base, u32 cap);   /* 1024 threads per block */

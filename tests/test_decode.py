@@ -40,6 +40,24 @@ def test_fuzz_slice(emu):
     assert fuzz_gpu.run_decode(emu, 31, 40, small=True) == []
 
 
+def test_unaligned_stream_pointer(emu):
+    """lbzamd_decompress_device on a stream that starts at any byte of an 8-byte word (the magic scan reads aligned words
+    and must neither see the bytes in front of the stream -- here they spell the start of a block magic -- nor miss its end)."""
+    import ctypes as C
+    data = bytes(gen("text", 5000, 3))
+    z = bz2.compress(data, 1) + bz2.compress(b"xyz" * 100, 9)
+    want = data + b"xyz" * 100
+    f = emu.lib.lbzamd_decompress_device
+    f.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]
+    for off in range(9):
+        raw = C.create_string_buffer((b"\x31\x41\x59" * 3)[:off] + z + b"\x55" * 16)
+        out = C.create_string_buffer(len(want) + 64)
+        n = C.c_size_t()
+        with emu.decoder(8) as d:
+            assert f(d.h, C.addressof(raw) + off, len(z), C.addressof(out), len(want) + 64, C.byref(n)) == 0, off
+        assert out.raw[:n.value] == want, off
+
+
 def test_wide_workgroups(emu, monkeypatch):
     """Files of few blocks are decoded by 1024-thread workgroups (k_dblock_w; lbz_api.hip picks by the block count,
     LBZAMD_DWIDE forces either): same bytes.  The rest of this file runs the 256-thread kernel under the emulator (its
