@@ -128,7 +128,9 @@ __device__ __forceinline__ void mtf_ranks(const u8 *bwt, u8 *rk_out, u32 lo, u32
       u64 mtot[NQ];
 #pragma unroll
       for (int q = 0; q < NQ; q++) {
-        const u64 mine = (first && (r0 >> 6) == (u32)q) ? 1ull << (r0 & 63u) : 0ull;
+        const bool inq = first && (r0 >> 6) == (u32)q;
+        if (NQ > 1 && q > 0 && __ballot(inq) == 0ull) { mtot[q] = 0ull; continue; }   /* no first occurrence from this far back: usual for q >= 1 */
+        const u64 mine = inq ? 1ull << (r0 & 63u) : 0ull;
         const u64 seen = wave_excl_or64(mine, &mtot[q]);           /* ranks taken by first occurrences in front of me, word q */
         const u64 lowbits = (r0 >> 6) > (u32)q ? ~0ull : ((r0 >> 6) == (u32)q ? (1ull << (r0 & 63u)) - 1ull : 0ull);
         B -= (u32)__popcll(seen & lowbits);
