@@ -370,17 +370,21 @@ template <u32 T> __device__ __forceinline__ void dhuff_block(const u8 *in, u64 n
       { const u64 p3 = clock64(); prof[0] += p1 - p0; prof[1] += p2 - p1; prof[2] += p3 - p2; prof[3]++; }
 #endif
       if (!stop) continue;
-      /* a long code or the end of the block */
+      /* a long code or the end of the block: lane l tries length l -- is the 20-bit window at most the largest code of
+         that length, and which symbol would it be -- and the shortest length that fits wins.  Two LDS round trips (window,
+         limits and bases; then the symbols) instead of one per step of the canonical search.                        */
       const u32 i0 = (u32)(G >> 5) & 255u;
-      const u64 w = (u64)rfl(S.ring[i0]) << 32 | rfl(S.ring[i0 + 1u]);
-      const u32 code = (u32)((w << ((u32)G & 31u)) >> 44);
-      /* the shortest length whose largest code is not below the window: every length at once, lane l looks at length l */
-      const u64 fits = __ballot(lane >= S.minlen[t] && lane <= S.maxlen[t] && (int)code <= S.limit[t][lane < 24u ? lane : 0u]);
+      const u64 w = (u64)S.ring[i0] << 32 | S.ring[i0 + 1u];
+      const u32 code = (u32)((w << ((u32)G & 31u)) >> 44);           /* the same in every lane */
+      const u32 ll = lane < 21u ? lane : 0u;
+      const bool fit = lane >= S.minlen[t] && lane <= S.maxlen[t] && lane < 21u && (int)code <= S.limit[t][ll];
+      const int pi = (int)(code >> (20u - ll)) - S.base[t][ll];
+      const u32 sv = (fit && pi >= 0 && pi < (int)alpha) ? (u32)S.perm[t][pi] : 0xFFFFu;
+      const u64 fits = __ballot(fit);
       if (fits == 0ull) { err = 6; break; }
       const u32 l = (u32)__builtin_ctzll(fits);
-      const int pi = (int)(code >> (20u - l)) - (int)rfl((u32)S.base[t][l]);
-      if (pi < 0 || pi >= (int)alpha) { err = 6; break; }
-      const u32 sym = rfl(S.perm[t][pi]);
+      const u32 sym = (u32)__builtin_amdgcn_readlane((int)sv, (int)l);
+      if (sym == 0xFFFFu) { err = 6; break; }
       G += l;
       k++;
       if (lane == 0u) sym16[nsym] = sym == eob ? (u16)DM_EOB : (u16)sym;
