@@ -20,3 +20,8 @@ for cfg in "256 2" "371 3" "556 2" "186 4" "128 6"; do
   done
 done
 md5sum /tmp/w1.bz2
+# the inverse path through the same driver: whole file in (pageable), every block decoded, whole file out (malloc'ed)
+for f in w1 w3; do
+  $EXE -d -f /tmp/$f.bz2 -o /tmp/$f.out -t 2>&1 | grep "decode:" | sed "s/^/$f -d: /"
+done
+cmp /tmp/w1.out /tmp/w1.bin && echo "w1 round trip ok"
