@@ -899,9 +899,9 @@ extern "C" int lbzamd_decompress_device(lbzamd_dctx *c, const void *d_in_v, size
     if (nb) {
       HIPCHK(hipMemcpyAsync(c->blocks, hb.data() + b0, nb * sizeof(lbz_dblock), hipMemcpyHostToDevice, q));
       HIPCHK(hipEventRecord(c->ev[1], q));
-      /* few blocks: 1024 threads each (two such workgroups fit a CU); LBZAMD_DWIDE=0/1 forces either */
+      /* a block per CU at most: 1024 threads each (one such workgroup is what a CU holds: 85 VGPRs); LBZAMD_DWIDE=0/1 forces either */
       const char *dw = getenv("LBZAMD_DWIDE");
-      const bool wide = dw ? dw[0] == '1' : nb <= 2u * c->ncus;
+      const bool wide = dw ? dw[0] == '1' : nb <= c->ncus;
       if (wide) hipLaunchKernelGGL(k_dblock_w, dim3(nb), dim3(1024), 0, q, d_in, (u64)len, c->blocks, nb, c->tt8, c->tt, c->W, c->pinfo, c->X, c->cap);
       else hipLaunchKernelGGL(k_dblock, dim3(nb), dim3(256), 0, q, d_in, (u64)len, c->blocks, nb, c->tt8, c->tt, c->W, c->pinfo, c->X, c->cap);
       HIPCHK(hipEventRecord(c->ev[2], q));
