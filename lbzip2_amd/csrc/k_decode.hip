@@ -992,12 +992,17 @@ dblock_body(const u8 *in, u64 nbytes, lbz_dblock *blocks, u32 nblk, u8 *tt8_base
   }
 }
 
-/* 256 threads per block when the file has more blocks than the device has CUs; DW_TMAX when it has fewer, so that a block's sort and
+/* 256 threads per block when the file has more than two blocks per CU, 512 (k_dblock_m) down to one per CU, DW_TMAX when it has fewer, so that a block's sort and
  * walk -- latency-bound, a lane at a time -- have four times the lanes (the host picks, lbz_api.hip) */
 __global__ void __launch_bounds__(256)
 k_dblock(const u8 *in, u64 nbytes, lbz_dblock *blocks, u32 nblk, u8 *tt8_base, u32 *tt_base, u8 *W_base, u32 *pinfo_base, u8 *X_base, u32 cap)
 {
   dblock_body<256u>(in, nbytes, blocks, nblk, tt8_base, tt_base, W_base, pinfo_base, X_base, cap);
+}
+__global__ void __launch_bounds__(512)
+k_dblock_m(const u8 *in, u64 nbytes, lbz_dblock *blocks, u32 nblk, u8 *tt8_base, u32 *tt_base, u8 *W_base, u32 *pinfo_base, u8 *X_base, u32 cap)
+{
+  dblock_body<512u>(in, nbytes, blocks, nblk, tt8_base, tt_base, W_base, pinfo_base, X_base, cap);
 }
 __global__ void __launch_bounds__(DW_TMAX)
 k_dblock_w(const u8 *in, u64 nbytes, lbz_dblock *blocks, u32 nblk, u8 *tt8_base, u32 *tt_base, u8 *W_base, u32 *pinfo_base, u8 *X_base, u32 cap)

@@ -899,10 +899,12 @@ extern "C" int lbzamd_decompress_device(lbzamd_dctx *c, const void *d_in_v, size
     if (nb) {
       HIPCHK(hipMemcpyAsync(c->blocks, hb.data() + b0, nb * sizeof(lbz_dblock), hipMemcpyHostToDevice, q));
       HIPCHK(hipEventRecord(c->ev[1], q));
-      /* a block per CU at most: 1024 threads each (one such workgroup is what a CU holds: 85 VGPRs); LBZAMD_DWIDE=0/1 forces either */
+      /* a block per CU at most: 1024 threads each (one such workgroup is what a CU holds: 85 VGPRs); up to two per CU: 512
+         threads; more: 256.  LBZAMD_DWIDE=0/1/2 forces 256 / 1024 / 512 */
       const char *dw = getenv("LBZAMD_DWIDE");
-      const bool wide = dw ? dw[0] == '1' : nb <= c->ncus;
-      if (wide) hipLaunchKernelGGL(k_dblock_w, dim3(nb), dim3(1024), 0, q, d_in, (u64)len, c->blocks, nb, c->tt8, c->tt, c->W, c->pinfo, c->X, c->cap);
+      const int width = dw ? dw[0] - '0' : (nb <= c->ncus ? 1 : (nb <= 2u * c->ncus ? 2 : 0));
+      if (width == 1) hipLaunchKernelGGL(k_dblock_w, dim3(nb), dim3(1024), 0, q, d_in, (u64)len, c->blocks, nb, c->tt8, c->tt, c->W, c->pinfo, c->X, c->cap);
+      else if (width == 2) hipLaunchKernelGGL(k_dblock_m, dim3(nb), dim3(512), 0, q, d_in, (u64)len, c->blocks, nb, c->tt8, c->tt, c->W, c->pinfo, c->X, c->cap);
       else hipLaunchKernelGGL(k_dblock, dim3(nb), dim3(256), 0, q, d_in, (u64)len, c->blocks, nb, c->tt8, c->tt, c->W, c->pinfo, c->X, c->cap);
       HIPCHK(hipEventRecord(c->ev[2], q));
       HIPCHK(hipMemcpyAsync(hb.data() + b0, c->blocks, nb * sizeof(lbz_dblock), hipMemcpyDeviceToHost, q));

@@ -33,6 +33,7 @@ struct lbz_dblock {
 #define LBZ_DSCAN_GRID(nbytes) ((u32)((((nbytes) + 14u) / 8u + 255u) / 256u))      /* one thread per aligned 8-byte word */
 __global__ void k_dscan(const u8 *in, u64 nbytes, u64 *marks, u32 *nmarks, u32 cap);
 __global__ void k_dblock(const u8 *in, u64 nbytes, lbz_dblock *blocks, u32 nblk, u8 *tt8_base, u32 *tt_base, u8 *W_base, u32 *pinfo_base, u8 *X_base, u32 cap);
+__global__ void k_dblock_m(const u8 *in, u64 nbytes, lbz_dblock *blocks, u32 nblk, u8 *tt8_base, u32 *tt_base, u8 *W_base, u32 *pinfo_base, u8 *X_base, u32 cap);   /* 512 threads per block */
 __global__ void k_dblock_w(const u8 *in, u64 nbytes, lbz_dblock *blocks, u32 nblk, u8 *tt8_base, u32 *tt_base, u8 *W_base, u32 *pinfo_base, u8 *X_base, u32 cap);   /* 1024 threads per block */
 __global__ void k_demit(const lbz_dblock *blocks, u32 nblk, const u8 *W_base, const u32 *pinfo_base, u8 *out, u64 out_cap, u32 cap);
 

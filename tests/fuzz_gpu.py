@@ -79,7 +79,7 @@ def run_decode(lib, seed, count, small=False, both_widths=False):
             more = make(rng)[:50000]
             z += bz2.compress(more, rng.choice([1, 9]))
             want = data + more
-        for wide in (("0", "1") if both_widths else (None,)):
+        for wide in (("0", "1", "2") if both_widths else (None,)):
             if wide is not None:
                 os.environ["LBZAMD_DWIDE"] = wide
             try:

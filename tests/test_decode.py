@@ -62,12 +62,13 @@ def test_wide_workgroups(emu, monkeypatch):
     """Files of few blocks are decoded by 1024-thread workgroups (k_dblock_w; lbz_api.hip picks by the block count,
     LBZAMD_DWIDE forces either): same bytes.  The rest of this file runs the 256-thread kernel under the emulator (its
     1024 fibers per block are slow) -- on the GPU both are taken as the block counts have it."""
-    monkeypatch.setenv("LBZAMD_DWIDE", "1")
-    for name, data, level in CASES:
-        if name in ("empty", "banana", "run259", "zeros", "all256", "text3k", "rand30k", "abab"):
-            assert emu.decompress(L.orc_compress(data, level)) == data, name
     d2 = bytes(gen("wiki", 120000, 4))
-    assert emu.decompress(bz2.compress(d2, 1) + L.orc_compress(b"tail" * 100, 9)) == d2 + b"tail" * 100
+    for width in ("1", "2"):                                          # 1024 and 512 threads (k_dblock_w, k_dblock_m)
+        monkeypatch.setenv("LBZAMD_DWIDE", width)
+        for name, data, level in CASES:
+            if name in ("empty", "banana", "run259", "zeros", "all256", "text3k", "rand30k", "abab"):
+                assert emu.decompress(L.orc_compress(data, level)) == data, (name, width)
+        assert emu.decompress(bz2.compress(d2, 1) + L.orc_compress(b"tail" * 100, 9)) == d2 + b"tail" * 100, width
 
 
 def test_reference_and_python_streams(emu):
