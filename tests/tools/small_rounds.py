@@ -4,7 +4,7 @@ sys.path.insert(0, "/root/repo")
 import torch, lbzip2_amd, os
 import bench
 lib = lbzip2_amd.Library(os.environ["LBZ_LIB"]) if os.environ.get("LBZ_LIB") else lbzip2_amd.library()
-for n in (14_400_000, 57_600_000, 100_000_000):
+for n in [int(a) for a in sys.argv[1:]] or (14_400_000, 57_600_000, 100_000_000):
     data = bench.gen_input("wiki", n, 1)
     src = torch.frombuffer(data, dtype=torch.uint8).cuda()
     dst = torch.empty(lib.bound(n), dtype=torch.uint8, device="cuda")
