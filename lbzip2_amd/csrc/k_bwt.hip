@@ -89,20 +89,20 @@
 #ifndef SPLIT_MIN
 #define SPLIT_MIN 256u                  /* a group longer than this is first cut into sub-groups on its next key byte */
 #endif
-#ifndef REFINE_BUDGET_DIV
-#define REFINE_BUDGET_DIV 8u             /* a block stops refining after re-sorting n / this many tied rows */
+#ifndef BIG_RUN
+#define BIG_RUN 63u                     /* a run of equal keys longer than this is refined in LDS (k_bwt_batch: its wave radix-sorts it on the next
+                                           sy symbols of the text); shorter runs fit one 64-lane strip and go to the text rounds (k_bwt_deep) */
 #endif
-#ifndef REFINE_ROUNDS
-#define REFINE_ROUNDS 12u                /* in-LDS refinements of a batch before rows are left to the doubling */
+#ifndef BIG_ROUNDS
+#define BIG_ROUNDS 16u                  /* such refinements a chunk gets at most; what is still tied in long runs then is left to the rank rounds */
 #endif
-#ifndef DEEP_REFINE
-#define DEEP_REFINE 0u                   /* refinements every tied run gets in k_bwt_batch whatever the budget says (0 or 1): with 1 the
-                                            block leaves k_bwt_batch sorted to depth 2 S and the doubling starts at h = 2 S -- its first
-                                            round, the one over two thirds of the rows of a text block, is never run.  Measured (round 3,
-                                            same box, 10^9 bytes): wiki 6.57 GB/s with 1 against 6.75 with 0 (k_bwt_batch +71 ms of summed
-                                            launch time, the rounds -59), tar 6.78 against 6.61, mixed 6.79 against 6.74: a tied-row round
-                                            costs about the same on either side of the kernel boundary, so the default stays 0 */
+#define DEEP_ROUNDS LBZ_DEEP_ROUNDS      /* launches of k_bwt_deep (lbz_kernels.h); what they leave tied goes to the rank rounds (k_bwt_fix*) */
+#ifndef DEEP_HANDOVER
+#define DEEP_HANDOVER 3u                /* from this launch of k_bwt_deep on, a block with more than 1/16 of its rows tied goes to the rank rounds */
 #endif
+#define DEEP_STACK 48u
+#define DEEP_CHUNK 256u                 /* list entries a wave claims at a time in k_bwt_deep */
+#define DEEP_STEP 13u                   /* symbols a text step decides: 2 x 52 bits of the 16 bytes it loads */
 #define TIE_FLAG 0x80000000u
 /* a suffix-array / tie-list entry: rotation index (n < 2^20) | dense code of the byte before it << 20 | TIE_FLAG.
    The byte rides along so that a row that becomes unique needs no look-up in the text.          */
@@ -149,8 +149,8 @@ struct batch_lds {                      /* one batch resident in LDS */
 struct bwt_lds {
   wg_scratch sc;
   u32 bc[16];
-  u32 isa_from, tied0;                /* k_bwt_batch: rows from isa_from on get their rank written with them; tied0 = rows tied on their first key so far */
-  u32 budget, shallow;                /* k_bwt_batch: tied-row rounds this segment may spend on in-LDS refinement; ties were left at depth S */
+  u32 listn, seglo;                   /* k_bwt_batch: entries in the segment's list of tied rows so far; the segment's first row */
+  u32 h0min, lmin;                    /* k_bwt_batch: least depth of a tie left for the rank rounds; of a run in the list */
   u32 msd_shift, pad2_;               /* 64 - the block's partition depth: rows with equal key >> msd_shift form a group */
   u32 dbg[4];                         /* LDS_SORT_TICKS: whole-workgroup batch sorts (count, ticks), oversized groups (count, ticks) */
   u8 cmap[256];                       /* byte -> dense code */
@@ -194,6 +194,14 @@ __device__ __forceinline__ bwt_slot round_slot(u8 *ws, u64 slot_bytes, u8 *ws_sp
 {
   return i < count ? slot_carve(ws + (u64)i * slot_bytes, L.cap_a)
                    : slot_carve(ws_spill + (u64)(i - count) * spill_bytes, L.cap_b);
+}
+
+/* the slot as a segment sees it: its list of tied rows and its scratch start at the segment's first row */
+__device__ __forceinline__ bwt_slot seg_view(bwt_slot s, u32 lo)
+{
+  s.sufx += lo; s.grp += lo; s.pos += lo;          /* the segment's list */
+  s.k0 += lo; s.k1 += lo; s.v0 += lo; s.v1 += lo;  /* scratch of the HBM sorter (runs longer than a batch) */
+  return s;
 }
 
 struct sort_lds;
@@ -354,6 +362,10 @@ __device__ u32 wg_regroup(const u64 *key, const u32 *val, u32 rowbase, u32 out_b
 __device__ __forceinline__ u64 key_from_text(const u8 *T, u32 n, u32 start, const u8 *cmap, keycfg c)
 {
   u64 key = 0;
+  if (c.b == 8u && start + 8u <= n) {
+    /* more than 128 byte values in use: codes are the bytes themselves (bwt_setup), the key is the text, big-endian */
+    return __builtin_bswap64(reinterpret_cast<const lbz_text16 *>(T + start)->a);
+  }
   if (c.sy <= 16u && start + 20u <= n) {
     /* five aligned dwords cover the 16 bytes; one wait instead of sy dependent loads */
     const u32 shb = (start & 3u) * 8u;
@@ -844,11 +856,12 @@ __device__ u32 wave_runs(batch_lds *B, u32 cs, u32 ce, u32 sh = 0u)
   return ntied;
 }
 
-/* Everything a wave does for its chunk after the groups are known: order the rows (unless they
- * already are), refine runs of equal keys with further symbols of the text, emit.  No workgroup
- * barrier inside: the 16 waves of a batch run their chunks independently.                   */
-__device__ void wave_finish_chunk(batch_lds *B, u32 cs, u32 ce, bool need_sort, const u8 *T, u32 n, keycfg c,
-                                  u8 *bwt, u32 *sa, u64 *isa, u32 lo, lbz_block_meta *meta, bwt_lds *S)   /* isa == nullptr: ranks not wanted yet */
+/* Everything a wave does for its chunk after the groups are known: order the rows (unless they already are) and emit
+ * them.  Rows that stay tied (runs of equal keys: on text two thirds of a block) are appended, run by run, to the
+ * segment's list for the text rounds (k_bwt_deep) together with `depth`, the symbols a key covers.  No workgroup
+ * barrier inside: the waves of a batch run their chunks independently.                                            */
+__device__ void wave_finish_chunk(batch_lds *B, u32 cs, u32 ce, bool need_sort, u32 depth,
+                                  u8 *bwt, bwt_slot s, u32 lo, lbz_block_meta *meta, bwt_lds *S)
 {
   const u32 lane = lane_id();
   u32 ntied;
@@ -869,58 +882,32 @@ __device__ void wave_finish_chunk(batch_lds *B, u32 cs, u32 ce, bool need_sort, 
       ntied += (u32)__popcll(__ballot(j < ce && B->tied[j]));
     }
   }
-
-  /* Refinement pays while ties are few or shrink quickly.  A chunk with many ties that barely
-     shrink (source code, markup, logs: long exact repeats) is left to the prefix doubling, which
-     needs O(log depth) rounds instead of depth/sy.  A handful of deep ties is cheaper to chase
-     here than to pay the doubling's full rank build for.                                    */
-  u32 depth = c.sy;
-  u32 before = ntied;
-  if (ntied && lane == 0u) atomicAdd(&S->tied0, ntied);      /* rows tied on their first key: what k_bwt_batch judges the block by */
   const u64 tw1 = wall_clock64();
-  /* a block that keeps tying (isa != nullptr: batch_process has switched the rank emission on) goes through
-     k_bwt_fix whatever is refined here, and a tied-row round costs the same on either side: skip it */
-  u32 rounds_done = 0;
-  for (u32 r = 0; r < REFINE_ROUNDS && ntied; r++) {
-    if (r >= DEEP_REFINE) {                     /* the first DEEP_REFINE rounds are unconditional: see DEEP_REFINE */
-      if (isa || !before) break;
-      /* block-wide budget of tied-row rounds: a block that has burnt n/8 of them is a repetitive
-         one that will need the doubling anyway -- stop refining its remaining chunks */
-      if ((u32)__builtin_amdgcn_readfirstlane((int)S->bc[9]) > S->budget) break;
-      if (lane == 0u) atomicAdd(&S->bc[9], ntied);
-    }
-    rounds_done++;
-    /* every tied rotation trades its key for its next sy symbols; its run is re-sorted on them
-       (counting for short runs, a per-run radix sort otherwise) and split where they differ */
-    for (u32 j = cs + lane; j < ce; j += 64u)
-      if (B->tied[j]) {
-        const u32 idx = B->vA[j] & 0x00FFFFFFu;
-        B->kA[j] = key_from_text(T, n, (idx + depth % n) % n, S->cmap, c);
-      }
-    wave_sync();
-    wave_sort_chunk<false>(B, cs, ce);
-    ntied = wave_runs<true>(B, cs, ce);
-    depth += c.sy;
-    if (ntied > 256u && 4u * ntied > 3u * before) before = 0; else before = ntied;   /* many ties, barely shrinking */
-  }
-
-  for (u32 j = cs + lane; j < ce; j += 64u) {
-    const u32 v = B->vA[j];
+  const bwt_slot ls = seg_view(s, S->seglo);
+  /* the chunk's tied runs take ONE stretch of the list: the rows of a run must lie side by side there */
+  u32 lbase = ntied ? wave_reserve(&S->listn, ntied) : 0u;
+  for (u32 j0 = cs; j0 < ce; j0 += 64u) {
+    const u32 j = j0 + lane;
+    const bool ok = j < ce;
+    const u32 v = ok ? B->vA[j] : 0u;
     const u32 idx = v & 0x00FFFFFFu;
-    const bool flagged = B->tied[j] && B->gh[j] != j;
-    bwt[lo + j] = S->inv[v >> 24];
-    sa[lo + j] = SA_ENTRY(idx, v >> 24) | (flagged ? TIE_FLAG : 0u);
-    /* rank of the rotation = first row of its run.  k_bwt_fix needs it for every rotation of a block
-       with deep ties; written here, these scattered stores ride under a kernel that is bound by LDS work,
-       instead of being a pass of their own in a kernel that is bound by scattered HBM traffic.  Only once
-       the block has shown that it will need k_bwt_fix (batch_process decides): text whose ties are
-       shallow never pays for it.                                                                   */
-#ifndef DIAG_NO_ISA          /* timing experiments only: what the scattered rank stores cost this kernel */
-    if (isa) { const u32 rk = lo + (u32)B->gh[j]; isa[idx] = ISA_ENTRY(rk, rk, 0u); }
-#endif
-    if (idx == 0u) meta->bwt_idx = lo + j;
+    const bool td = ok && ntied && B->tied[j];
+    const u32 head = td ? (u32)B->gh[j] : j;
+    if (ok) {
+      bwt[lo + j] = S->inv[v >> 24];
+      s.sa[lo + j] = SA_ENTRY(idx, v >> 24) | ((td && head != j) ? TIE_FLAG : 0u);
+      if (idx == 0u) meta->bwt_idx = lo + j;
+    }
+    const u64 mask = __ballot(td);
+    if (td) {
+      const u32 o = lbase + (u32)__popcll(mask & lanes_below());
+      ls.sufx[o] = SA_ENTRY(idx, v >> 24);
+      ls.grp[o] = lo + head;                           /* rank of the run = its first row */
+      ls.pos[o] = depth;                               /* symbols the run shares */
+    }
+    lbase += (u32)__popcll(mask);
   }
-  if (ntied && lane == 0u) { S->bc[8] = 1u; if (rounds_done < DEEP_REFINE || DEEP_REFINE == 0u) S->shallow = 1u; }
+  if (ntied && lane == 0u) atomicMin(&S->lmin, depth);
   if (lane == 0u) {
     const u64 tw2 = wall_clock64();
     atomicAdd(&S->bc[13], (u32)(tw2 - tw0));
@@ -1000,7 +987,7 @@ __device__ u32 chunk_plan(batch_lds *B, u32 cnt)
  * batch).  Finding the cut on the rows already in LDS saves the separate search in HBM.      */
 __device__ u32 batch_process(const u8 *T, u32 n, u8 *bwt, lbz_block_meta *meta, bwt_slot s,
                              bwt_lds *S, keycfg c, u32 lo, u32 cnt, bool presorted, bool preloaded,
-                             bool trim = false)
+                             bool trim = false, u32 depth = 0u)        /* depth: symbols the rows' keys reach (0: the first key, c.sy) */
 {
   batch_lds *B = &S->u.B;
   const u32 tid = threadIdx.x;
@@ -1070,7 +1057,7 @@ __device__ u32 batch_process(const u8 *T, u32 n, u8 *bwt, lbz_block_meta *meta, 
     if (t >= nwin) break;
     const u32 k = B->corder[t];
     const u32 cs = B->cstart[k], ce = B->cstart[k + 1u];
-    if (cs < ce) wave_finish_chunk(B, cs, ce, need_sort, T, n, c, bwt, s.sa, lo >= S->isa_from ? s.isa : nullptr, lo, meta, S);
+    if (cs < ce) wave_finish_chunk(B, cs, ce, need_sort, depth ? depth : c.sy, bwt, s, lo, meta, S);
   }
   __syncthreads();
   if (tid == 0) {
@@ -1080,16 +1067,16 @@ __device__ u32 batch_process(const u8 *T, u32 n, u8 *bwt, lbz_block_meta *meta, 
   return cnt;
 }
 
-/* rows [lo,hi) share one 64-bit key: nothing an LDS batch can do for them */
-__device__ void emit_tied_rows(u8 *bwt, bwt_slot s, bwt_lds *S, u32 lo, u32 hi)
+/* rows [lo,hi) share one 64-bit key and are more than a batch: left to the rank rounds */
+__device__ void emit_tied_rows(u8 *bwt, bwt_slot s, bwt_lds *S, u32 lo, u32 hi, lbz_block_meta *meta, u32 depth)
 {
   for (u32 j = lo + threadIdx.x; j < hi; j += LBZ_WG) {
     const u32 v = s.v0[j];
     bwt[j] = S->inv[v >> 24];
     s.sa[j] = SA_ENTRY(v & 0x00FFFFFFu, v >> 24) | (j > lo ? TIE_FLAG : 0u);
-    s.isa[v & 0x00FFFFFFu] = ISA_ENTRY(lo, lo, 0u);
+    if ((v & 0x00FFFFFFu) == 0u) meta->bwt_idx = j;
   }
-  if (threadIdx.x == 0) { S->bc[8] = 1u; S->shallow = 1u; }
+  if (threadIdx.x == 0) { S->bc[8] = 1u; atomicMin(&S->h0min, depth); }
   __syncthreads();
 }
 
@@ -1137,33 +1124,66 @@ __device__ u32 find_run_end(const K *keys, u32 pos, u32 from, u32 hi, u32 sh, bw
   return b < hi ? b : hi;
 }
 
-/* An oversized group [lo,hi) (> BATCH_CAP rows with equal top MSD_BITS): HBM radix sort on the
- * remaining key bits, then batches cut at key boundaries (only ties are refined).           */
+/* An oversized group [lo,hi) (> BATCH_CAP rows with equal top MSD_BITS): HBM radix sort on the remaining key bits, then
+ * batches cut at key boundaries.  A run of more than a batch of EQUAL keys (" of the ": thousands of rows of a text
+ * block) trades its keys for the next sy symbols of its rotations and is sorted again the same way -- a frame on a
+ * small stack: the rows of the frame, the symbols they are known to share -- up to BIG_LEVELS deep; what is still
+ * more than a batch of equal keys then (long runs of one or two byte values: "abababab") is left to the rank rounds. */
+#ifndef BIG_LEVELS
+#define BIG_LEVELS 4u
+#endif
 __device__ void big_group(const u8 *T, u32 n, u8 *bwt, lbz_block_meta *meta, bwt_slot s,
                           bwt_lds *S, keycfg c, u32 lo, u32 hi)
 {
   const u32 tid = threadIdx.x;
-  const u32 m = hi - lo;
-  const u32 which = wg_radix_sort(s.k0 + lo, s.v0 + lo, s.k1 + lo, s.v1 + lo, m, S->msd_shift, S);
-  if (which) {
-    for (u32 i = tid; i < m; i += LBZ_WG) { s.k0[lo + i] = s.k1[lo + i]; s.v0[lo + i] = s.v1[lo + i]; }
-    __syncthreads();
-  }
-  u32 pos = lo;
-  while (pos < hi) {
-    u32 e = pos + BATCH_CAP < hi ? pos + BATCH_CAP : hi;
-    if (e < hi) {
+  u32 fhi[BIG_LEVELS + 1u], fdepth[BIG_LEVELS + 1u];
+  u32 lev = 0, pos = lo;
+  fhi[0] = hi; fdepth[0] = c.sy;
+  bool fresh = true;                                   /* rows [pos, fhi[lev]) have new keys: sort them */
+  u32 nbits = S->msd_shift;
+  for (;;) {
+    if (pos >= fhi[lev]) {
+      if (lev == 0u) break;
+      lev--;
+      continue;
+    }
+    if (fresh) {
+      const u32 m = fhi[lev] - pos;
+      const u32 which = wg_radix_sort(s.k0 + pos, s.v0 + pos, s.k1 + pos, s.v1 + pos, m, nbits, S);
+      if (which) {
+        for (u32 i = tid; i < m; i += LBZ_WG) { s.k0[pos + i] = s.k1[pos + i]; s.v0[pos + i] = s.v1[pos + i]; }
+        __syncthreads();
+      }
+      fresh = false;
+    }
+    const u32 top = fhi[lev];
+    u32 e = pos + BATCH_CAP < top ? pos + BATCH_CAP : top;
+    if (e < top) {
       const u32 cut = find_cut(s.k0, pos, e, 0u, S);
       if (!cut) {
-        /* a run of > BATCH_CAP equal keys: leave it to the doubling */
-        const u32 end = find_run_end(s.k0, pos, e, hi, 0u, S);
-        emit_tied_rows(bwt, s, S, pos, end);
+        /* a run of > BATCH_CAP equal keys */
+        const u32 end = find_run_end(s.k0, pos, e, top, 0u, S);
+        const u32 depth = fdepth[lev];
+        if (lev < BIG_LEVELS && depth + c.sy < n) {
+          __syncthreads();
+          for (u32 i = pos + tid; i < end; i += LBZ_WG) {
+            u32 t = (s.v0[i] & 0x00FFFFFFu) + depth;
+            if (t >= n) t -= n;
+            s.k0[i] = key_from_text(T, n, t, S->cmap, c);
+          }
+          __syncthreads();
+          lev++;
+          fhi[lev] = end; fdepth[lev] = depth + c.sy;
+          fresh = true; nbits = 64u;
+          continue;
+        }
+        emit_tied_rows(bwt, s, S, pos, end, meta, depth);
         pos = end;
         continue;
       }
       e = cut;
     }
-    batch_process(T, n, bwt, meta, s, S, c, pos, e - pos, true, false);
+    batch_process(T, n, bwt, meta, s, S, c, pos, e - pos, true, false, false, fdepth[lev]);
     pos = e;
   }
 }
@@ -1295,8 +1315,11 @@ __device__ keycfg bwt_setup(const lbz_block_meta *meta, bwt_lds *S)
   u32 ninuse;
   const u32 f = (tid < 256u && meta->inuse[tid]) ? 1u : 0u;
   const u32 ex = wg_excl_add(f, &ninuse, &S->sc);
-  if (tid < 256u) S->cmap[tid] = (u8)ex;
-  if (f) S->inv[ex] = (u8)tid;
+  /* dense codes pack more symbols into a key; with more than 128 byte values in use they are 8 bits like the bytes, and the
+     bytes serve as their own codes (keys are then the text itself: key_from_text, k_bwt_deep) */
+  if (tid < 256u) S->cmap[tid] = ninuse > 128u ? (u8)tid : (u8)ex;
+  if (ninuse > 128u) { if (tid < 256u) S->inv[tid] = (u8)tid; }
+  else if (f) S->inv[ex] = (u8)tid;
   keycfg c;
   c.b = 1u;
   while ((1u << c.b) < ninuse) c.b++;
@@ -1317,8 +1340,8 @@ __device__ keycfg bwt_setup(const lbz_block_meta *meta, bwt_lds *S)
 struct part_lds {
   wg_scratch sc;
   u32 bc[16];
-  u32 isa_from, tied0;
-  u32 budget, shallow;
+  u32 listn, seglo;
+  u32 h0min, lmin;
   u32 msd_shift, pad2_;
   u32 dbg[4];
   u8 cmap[256];
@@ -1336,7 +1359,8 @@ __device__ __forceinline__ void part_block(bwt_lds &S, const u8 *Tbase, lbz_bloc
   const u32 n = meta[blk].n;
   if (tid == 0) {                             /* the sorter's part of the block record: the segment workgroups add to it */
     lbz_block_meta *M = &meta[blk];
-    M->periodic = 0; M->rounds = 0; M->sort_elems = 0; M->isa_from = 0; M->nseg = 0; M->deep_start = DEEP_REFINE ? 1u : 0u;
+    M->periodic = 0; M->rounds = 0; M->sort_elems = 0; M->deep_rows = 0; M->nseg = 0; M->deep_h0 = 0xFFFFFFFFu; M->deep_skip = 0;
+    for (u32 i = 0; i <= LBZ_DEEP_ROUNDS; i++) { M->deep_tot[i] = 0; M->deep_hmin[i] = 0xFFFFFFFFu; }
     M->msd_bits = MSD_BITS;
     for (u32 i = 0; i < 8u; i++) M->ticks[i] = 0;
     for (u32 i = 0; i < 16u; i++) M->fticks[i] = 0;
@@ -1455,7 +1479,7 @@ k_bwt_batch(const u8 *Tbase, u8 *Bbase, lbz_block_meta *meta, lbz_layout L, u32 
     hi = seg + 1u == nseg ? n : seg_cut(s.k0, (u32)((u64)(seg + 1u) * n / nseg), n, &S);
   }
   if (tid == 0) {
-    S.isa_from = hi; S.tied0 = 0; S.budget = (hi - lo) / REFINE_BUDGET_DIV; S.shallow = 0;
+    S.listn = 0; S.seglo = lo; S.h0min = 0xFFFFFFFFu; S.lmin = 0xFFFFFFFFu;
     for (u32 i = 0; i < 4; i++) S.dbg[i] = 0;
     M->seg_lo[seg] = lo;
     if (seg + 1u == nseg) M->seg_lo[nseg] = n;
@@ -1473,13 +1497,6 @@ k_bwt_batch(const u8 *Tbase, u8 *Bbase, lbz_block_meta *meta, lbz_layout L, u32 
   } else {
     u32 pos = lo;
     while (pos < hi) {
-      /* a segment whose rows keep tying (more than a fifth so far) will go through the deep-tie rounds: from here
-         on its batches write the ranks along with the rows */
-      if (S.isa_from == hi && pos - lo >= 2u * BATCH_CAP && 5u * S.tied0 > pos - lo) {
-        __syncthreads();
-        if (tid == 0) S.isa_from = pos;
-        __syncthreads();
-      }
       const u32 want = hi - pos < BATCH_CAP ? hi - pos : BATCH_CAP;
       const u32 used = batch_process(T, n, bwt, M, s, &S, c, pos, want, false, false, true);
       if (used == 0u) {                          /* one group fills the batch: sort it in HBM first */
@@ -1499,10 +1516,10 @@ k_bwt_batch(const u8 *Tbase, u8 *Bbase, lbz_block_meta *meta, lbz_layout L, u32 
   }
   __syncthreads();
   if (tid == 0) {
-    if (S.bc[8]) atomicMax(&M->periodic, 2u);  /* 2 = ties left for the deep-tie rounds */
-    if (S.shallow) M->deep_start = 0;          /* some of them only S symbols deep: the block needs the round at h = S too */
-    M->seg_isa_from[seg] = S.isa_from;
-    atomicAdd(&M->isa_from, hi - S.isa_from);
+    if (S.bc[8]) { atomicMax(&M->periodic, 2u); atomicMin(&M->deep_h0, S.h0min); M->deep_skip = 1u; }  /* 2 = ties left for the rank rounds: long runs BIG_ROUNDS did not split */
+    M->seg_m[seg] = S.listn;                   /* short runs: the text rounds' list */
+    if (S.listn) { atomicAdd(&M->deep_tot[0], S.listn); atomicMin(&M->deep_hmin[0], S.lmin); }
+    atomicAdd(&M->deep_rows, S.listn);
     atomicAdd(&M->sort_elems, hi - lo);
     /* diagnostics, summed over the block's segments (tests/tools/quickperf.py) */
     atomicAdd(&M->ticks[0], (u32)(wall_clock64() - tk0));
@@ -1515,6 +1532,441 @@ k_bwt_batch(const u8 *Tbase, u8 *Bbase, lbz_block_meta *meta, lbz_layout L, u32 
 #else
     atomicAdd(&M->ticks[1], S.bc[3]); atomicAdd(&M->ticks[2], S.bc[4]);    /* summed over waves: busy, of which first sort */
 #endif
+  }
+}
+
+/* ---- kernel 2b: the text rounds -- short runs of tied rows, ordered a 64-lane strip at a time ----
+ * k_bwt_batch leaves the rows that are tied in runs of at most BIG_RUN rows (on text two thirds of a block: equal on
+ * their first 8 symbols, rarely on their first 40) in a list per segment: (suffix + code of the byte before it, rank =
+ * first row of the run, symbols the run is known to share), the rows of a run side by side.  What orders them is the
+ * text itself: 0.9 MB per block that the segment workgroups of a block keep in their XCD's L2, read-only -- against
+ * 7.2 MB of rank entries per block that the rank rounds gather from and scatter into across HBM (64 useful bits per
+ * 128-byte line, at the chip's 50 G random accesses a second: profiles/r04_micro_random.json).
+ *
+ * A wave claims DEEP_CHUNK list entries at a time and owns the runs that START inside; it walks them in strips of
+ * whole runs, one row per lane.  A step: every tied lane loads the 16 bytes behind the symbols its run shares (one
+ * unaligned global_load_dwordx4, big-endian = string order) and the strip is sorted inside its runs on 2 x 52 bits of
+ * them (deep_stage): the key (first lane of the run : 52 bits : lane) is unique, so a row's place in the strip is the
+ * number of smaller keys -- counted against all 64 keys, which sit in LDS and are read at a wave-uniform address
+ * (broadcast, two per ds_read_b128): one compare and one add per pair, no branch, no dependence on run lengths.  The
+ * rows move through LDS to their places, runs split where neighbours differ.  Steps repeat while enough of the strip
+ * is tied (a strip that thins out is left to the next launch, which gets the survivors side by side again); launch r
+ * allows more steps per strip than the one before, so long repeats -- pairs of rows as a rule -- are followed for
+ * thousands of symbols by a strip that holds nothing else.  Rows that become unique write their BWT byte; every row
+ * writes the suffix array (the rank rounds rebuild their lists from its tie flags should they be needed).
+ * Whatever is still tied after DEEP_ROUNDS launches (exactly periodic blocks, repeats of more than 6 KB) marks the
+ * block for the rank rounds, which start at the least depth such a run has reached (deep_h0).                     */
+struct u64x2 { u64 x, y; };
+struct deep_wave {
+  alignas(16) u64 comp[64];             /* the strip's keys, read by every lane */
+  u64 srt[64];                          /* (run, slice) in sorted order */
+  u64 k2[64];                           /* the second slice travels with its row */
+  u32 val[64];
+  u32 cnt[256], fill[256];              /* long runs: rows per value of the symbol they are split on, rows placed so far */
+  u16 base[256], obase[256];            /* ... first row of each value's rows inside the run, and inside the run's stretch of the list */
+  u32 st_off[DEEP_STACK], st_len[DEEP_STACK], st_dep[DEEP_STACK], st_buf[DEEP_STACK], sp;   /* pieces of a long run that are still long */
+};
+struct deep_lds {
+  wg_scratch sc;
+  u32 ticket, outn, h0min, bad;
+  u8 inv[256];
+  deep_wave w[LBZ_NW];
+};
+
+/* steps a strip may take in launch r: 2 2 2 8 64 1024.  A step decides 13 symbols, or skips 16 to 64 that all its runs
+   share -- the last launches follow what is left (pairs of long repeats as a rule) for up to 64 KB */
+__device__ __forceinline__ u32 deep_kmax(u32 round) { return round < 3u ? 2u : (round == 3u ? 8u : (round == 4u ? 64u : 1024u)); }
+
+/* Sort the strip inside its runs on `slice` (52 bits).  val and k2 move with their rows; hl (first lane of the lane's
+ * run) and tied describe places, and are refined.  Lanes >= nv are not part of the strip.                         */
+__device__ __forceinline__ void deep_stage(deep_wave *W, u32 lane, u32 nv, u64 slice, u32 &val, u64 &k2, u32 &hl, bool &tied)
+{
+  const bool in = lane < nv;
+  const u64 ck = ((u64)hl << 52) | slice;
+  const u64 comp = (ck << 6) | (u64)lane;
+  W->comp[lane] = in ? comp : ~0ull;
+  wave_sync();
+  u32 pos = 0;
+  const u64x2 *cp = reinterpret_cast<const u64x2 *>(W->comp);
+  /* 16 keys at a time: eight broadcast reads in flight, then sixteen compare-and-add pairs */
+#pragma unroll
+  for (u32 b = 0; b < 4u; b++) {
+    if (16u * b < nv) {
+      u64x2 c2[8];
+#pragma unroll
+      for (u32 q = 0; q < 8u; q++) c2[q] = cp[8u * b + q];
+#pragma unroll
+      for (u32 q = 0; q < 8u; q++) pos = add_if_less2(pos, c2[q].x, c2[q].y, comp);
+    }
+  }
+  if (in) { W->srt[pos] = ck; W->val[pos] = val; W->k2[pos] = k2; }
+  wave_sync();
+  u64 me = 0, below = 1;
+  if (in) {
+    val = W->val[lane]; k2 = W->k2[lane];
+    me = W->srt[lane];
+    below = lane ? W->srt[lane - 1u] : ~me;
+  }
+  const bool head = !in || me != below;
+  hl = wave_incl_max(head ? lane : 0u);
+  const u64 hm = __ballot(head);
+  const bool nexthead = lane == 63u || ((hm >> (lane + 1u)) & 1ull);
+  tied = in && !(head && nexthead);
+  wave_sync();
+}
+
+/* text of rotation idx from symbol d on: 16 bytes, memory order (first symbol in the low byte of .a) */
+__device__ __forceinline__ u64x2 deep_load16(const u8 *T, u32 n, u32 idx, u32 d)
+{
+  u32 at = idx + d;
+  if (at >= n) at -= n;
+  if (at + 16u <= n) {
+    const lbz_text16 *q = reinterpret_cast<const lbz_text16 *>(T + at);
+    u64x2 r; r.x = q->a; r.y = q->b;
+    return r;
+  }
+  u64 xa = 0, xb = 0;
+  for (u32 q = 0; q < 16u; q++) {
+    const u64 by = T[at];
+    if (q < 8u) xa |= by << (8u * q); else xb |= by << (8u * (q - 8u));
+    at = at + 1u == n ? 0u : at + 1u;
+  }
+  u64x2 x; x.x = xa; x.y = xb;
+  return x;
+}
+
+struct deep_lists { const u32 *sin, *gin, *din; u32 *sout, *gout, *dout; };
+
+/* A run of g >= 64 tied rows (list entries [p, p + g)): too long for a strip.  Its wave takes it apart symbol by symbol:
+ * it finds how many further symbols ALL rows of the piece share (compared with the piece's first row, 16 bytes a step, up
+ * to 64), then splits the piece on the first symbol they do not all share -- a counting sort on one byte whose only state
+ * in LDS is 256 counters: a row's slot inside its value's rows is the return value of an LDS atomic (the order inside a
+ * sub-run is free, it is still tied).  Rows alone with their value are done; values with 2..63 rows become runs of the next
+ * list (the strips of the next launch order them); values with 64 rows or more are pieces again -- their suffixes go to the
+ * other of two scratch columns (the run's own stretch of the incoming list and the partition's value column, free by now)
+ * and onto a small stack.  " of the ", four thousand rows of a text block, is thirty pieces after one symbol and short runs
+ * after two or three; a template that a hundred rows share for 60 symbols costs four 16-byte steps.  A piece that shares
+ * 64 further symbols (or overflows the stack) goes to the next list as it is, deeper, and the next launch carries on.    */
+__device__ void deep_big_run(deep_wave *W, u32 lane, u32 p, u32 g, deep_lists Ls, u32 *ping, u32 *pong, const u8 *T, u32 n,
+                             u32 *sa, u8 *bwt, const u8 *inv, lbz_block_meta *M, u32 *outn, u32 &hmin, bool late)
+{
+  const u32 rank0 = Ls.gin[p];
+  const u32 d0 = Ls.din[p];
+  if (lane == 0u) { W->st_off[0] = 0u; W->st_len[0] = g; W->st_dep[0] = d0; W->st_buf[0] = 0u; W->sp = 1u; }
+  wave_sync();
+  for (;;) {
+    const u32 sp = W->sp;
+    if (sp == 0u) break;
+    const u32 off = W->st_off[sp - 1u], len = W->st_len[sp - 1u], buf = W->st_buf[sp - 1u];
+    u32 d = W->st_dep[sp - 1u];
+    wave_sync();
+    if (lane == 0u) W->sp = sp - 1u;
+    const u32 *src = (buf ? pong : ping) + p + off;
+    u32 *dst = (buf ? ping : pong) + p + off;
+    const u32 r0 = rank0 + off;                         /* the piece's rows are consecutive from here */
+    const u32 idx0 = SA_IDX(src[0]);
+    bool split = false;
+    for (u32 it = 0; it < 4u && d + 16u <= n; it++) {
+      const u64x2 ref = deep_load16(T, n, idx0, d);
+      u32 lc = 16u;
+      for (u32 k0 = 0; k0 < len; k0 += 256u) {           /* four strips a trip: their loads are in flight together */
+        u32 v4[4];
+        u64x2 x4[4];
+#pragma unroll
+        for (u32 q = 0; q < 4u; q++) { const u32 k = k0 + 64u * q + lane; v4[q] = src[k < len ? k : 0u]; }
+#pragma unroll
+        for (u32 q = 0; q < 4u; q++) x4[q] = deep_load16(T, n, SA_IDX(v4[q]), d);
+#pragma unroll
+        for (u32 q = 0; q < 4u; q++) {
+          const u64 xa = x4[q].x ^ ref.x, xb = x4[q].y ^ ref.y;
+          const u32 l = xa ? (u32)__builtin_ctzll(xa) >> 3 : (xb ? 8u + ((u32)__builtin_ctzll(xb) >> 3) : 16u);
+          lc = l < lc ? l : lc;
+        }
+      }
+      lc = wave_min(lc);
+      d += lc;
+      if (lc < 16u) { split = true; break; }
+    }
+    if (!split || d >= n || sp + 16u > DEEP_STACK) {
+      /* nothing to split on yet (64 more symbols shared, or tied all the way round), or no room on the stack: the piece
+         goes on as it is, deeper */
+      const u32 ob = wave_reserve(outn, len);
+      for (u32 k = lane; k < len; k += 64u) { Ls.sout[ob + k] = src[k]; Ls.gout[ob + k] = r0; Ls.dout[ob + k] = d; }
+      hmin = d < hmin ? d : hmin;
+      wave_sync();
+      continue;
+    }
+    for (u32 i = lane; i < 256u; i += 64u) { W->cnt[i] = 0; W->fill[i] = 0; }
+    wave_sync();
+    for (u32 k0 = 0; k0 < len; k0 += 256u) {
+      u32 v4[4], b4[4];
+#pragma unroll
+      for (u32 q = 0; q < 4u; q++) { const u32 k = k0 + 64u * q + lane; v4[q] = src[k < len ? k : 0u]; }
+#pragma unroll
+      for (u32 q = 0; q < 4u; q++) { u32 at = SA_IDX(v4[q]) + d; if (at >= n) at -= n; b4[q] = T[at]; }
+#pragma unroll
+      for (u32 q = 0; q < 4u; q++) if (k0 + 64u * q + lane < len) atomicAdd(&W->cnt[b4[q]], 1u);
+    }
+    wave_sync();
+    u32 shorttot;
+    {
+      u32 c[4], t[4];
+      u32 sum = 0, tsum = 0;
+#pragma unroll
+      for (u32 q = 0; q < 4u; q++) {
+        c[q] = W->cnt[4u * lane + q];
+        t[q] = (c[q] > 1u && c[q] <= BIG_RUN) ? c[q] : 0u;
+        sum += c[q]; tsum += t[q];
+      }
+      const u32 tin = wave_incl_add(tsum);
+      u32 ex = wave_incl_add(sum) - sum, tex = tin - tsum;
+      shorttot = (u32)__builtin_amdgcn_readlane((int)tin, 63);
+#pragma unroll
+      for (u32 q = 0; q < 4u; q++) {
+        W->base[4u * lane + q] = (u16)ex; W->obase[4u * lane + q] = (u16)tex;
+        if (c[q] > BIG_RUN) {                           /* a piece again: at most len / 64 <= 16 of them */
+          const u32 at = atomicAdd(&W->sp, 1u);
+          W->st_off[at] = off + ex; W->st_len[at] = c[q]; W->st_dep[at] = d + 1u; W->st_buf[at] = buf ^ 1u;
+        }
+        ex += c[q]; tex += t[q];
+      }
+    }
+    wave_sync();
+    const u32 ob = shorttot ? wave_reserve(outn, shorttot) : 0u;
+    for (u32 k0 = 0; k0 < len; k0 += 256u) {
+      u32 v4[4], b4[4];
+#pragma unroll
+      for (u32 q = 0; q < 4u; q++) { const u32 k = k0 + 64u * q + lane; v4[q] = src[k < len ? k : 0u]; }
+#pragma unroll
+      for (u32 q = 0; q < 4u; q++) { u32 at = SA_IDX(v4[q]) + d; if (at >= n) at -= n; b4[q] = T[at]; }
+#pragma unroll
+      for (u32 q = 0; q < 4u; q++) {
+        if (k0 + 64u * q + lane >= len) continue;
+        const u32 val = v4[q], by = b4[q];
+        const u32 slot = atomicAdd(&W->fill[by], 1u);
+        const u32 c = W->cnt[by], b0 = (u32)W->base[by];
+        const u32 row = r0 + b0 + slot;
+        if (c == 1u || late) {                           /* see the strips' output */
+          sa[row] = val | ((c > 1u && slot) ? TIE_FLAG : 0u);
+          if (c == 1u) bwt[row] = inv[SA_CODE(val)];
+          if (SA_IDX(val) == 0u) M->bwt_idx = row;
+        }
+        if (c > BIG_RUN) {
+          dst[b0 + slot] = val;
+        } else if (c > 1u) {
+          const u32 o = ob + (u32)W->obase[by] + slot;
+          Ls.sout[o] = val; Ls.gout[o] = r0 + b0; Ls.dout[o] = d + 1u;
+        }
+      }
+    }
+    if (shorttot) hmin = d + 1u < hmin ? d + 1u : hmin;
+    __threadfence_block();                              /* dst is read back by this wave from the next piece on */
+    wave_sync();
+  }
+}
+
+__global__ void __launch_bounds__(LBZ_WG, 4)
+k_bwt_deep(const u8 *Tbase, u8 *Bbase, lbz_block_meta *meta, lbz_layout L, u32 first, u32 count, u32 nblk, u32 segs,
+           u8 *ws, u64 slot_bytes, u8 *ws_spill, u64 spill_bytes, const u32 *slabs, u32 round)
+{
+  __shared__ deep_lds S;
+  u32 bi, seg;
+  if (!seg_item(nblk, segs, &bi, &seg)) return;
+  const u32 blk = lbz_round_block(first, count, bi, slabs);
+  lbz_block_meta *M = &meta[blk];
+  const u32 n = M->n;
+  if (n < 2u || seg >= M->nseg) return;
+  const u32 tot = M->deep_tot[round];            /* the block's tied rows that are left for this round, all segments */
+  if (tot == 0u) return;
+  /* Blocks the text cannot finish cheaply go to the rank rounds as they are: long runs left over by k_bwt_batch, or --
+     from the fourth launch on -- more than a sixteenth of the rows still tied (source trees, logs: repeats of hundreds of
+     symbols, which ranks double through and text steps walk through).  Every segment decides the same.              */
+#ifdef DEEP_DEBUG
+  if (seg == 0u && threadIdx.x == 0u) printf("blk %u round %u tot %u hmin %u skip %u n %u\n", blk, round, tot, M->deep_hmin[round], M->deep_skip, n);
+#endif
+  if (M->deep_skip || (round >= DEEP_HANDOVER && (u64)tot * 16ull > n)) {
+    if (seg == 0u && threadIdx.x == 0u) { atomicMax(&M->periodic, 2u); atomicMin(&M->deep_h0, M->deep_hmin[round]); }
+    return;
+  }
+  const u32 m = M->seg_m[seg];
+  if (m == 0u) return;
+  const u64 tk0 = wall_clock64();
+  const u32 tid = threadIdx.x, lane = lane_id();
+  const u32 lo = M->seg_lo[seg];
+  const bwt_slot s = round_slot(ws, slot_bytes, ws_spill, spill_bytes, count, L, bi);
+  const u32 cap = bi < count ? L.cap_a : L.cap_b;
+  const size_t off = lbz_elem_off(L, blk);
+  const u8 *T = Tbase + off;
+  u8 *bwt = Bbase + off;
+  /* the list alternates between the slot's list columns and the partition's second buffers (free since k_bwt_batch) */
+  u32 *colA[3] = { s.sufx + lo, s.grp + lo, s.pos + lo };
+  u32 *colB[3] = { s.v1 + lo, reinterpret_cast<u32 *>(s.k1) + lo, reinterpret_cast<u32 *>(s.k1) + cap + lo };
+  const u32 *sin = (round & 1u) ? colB[0] : colA[0], *gin = (round & 1u) ? colB[1] : colA[1], *din = (round & 1u) ? colB[2] : colA[2];
+  u32 *sout = (round & 1u) ? colA[0] : colB[0], *gout = (round & 1u) ? colA[1] : colB[1], *dout = (round & 1u) ? colA[2] : colB[2];
+  {
+    u32 tot;
+    const u32 f = (tid < 256u && M->inuse[tid]) ? 1u : 0u;
+    const u32 ex = wg_excl_add(f, &tot, &S.sc);
+    if (tot > 128u) { if (tid < 256u) S.inv[tid] = (u8)tid; }       /* bwt_setup's rule */
+    else if (f) S.inv[ex] = (u8)tid;
+    if (tid == 0) { S.ticket = 0; S.outn = 0; S.h0min = 0xFFFFFFFFu; S.bad = 0; }
+    __syncthreads();
+  }
+  deep_wave *W = &S.w[wave_id()];
+  const deep_lists Ls = { sin, gin, din, sout, gout, dout };
+#ifdef DEEP_TICKS
+  u64 tkb = 0, tks = 0, tkp = 0, tko = 0, tkn = 0;          /* long runs, strip set-up, steps, output; strips */
+#define DT_MARK(v) const u64 v = wall_clock64()
+#define DT_ADD(acc, a, b) acc += (b) - (a)
+#else
+#define DT_MARK(v)
+#define DT_ADD(acc, a, b)
+#endif
+  const u32 kmax = deep_kmax(round);
+  const u32 chunk = m < 16u * DEEP_CHUNK ? 64u : DEEP_CHUNK;    /* a short list (the late launches: long repeats, a strip's steps are a chain of
+                                                                   round trips) is dealt out a strip at a time */
+  u32 hmin = 0xFFFFFFFFu;
+  for (;;) {
+    const u32 a = wave_claim(&S.ticket) * chunk;
+    if (a >= m) break;
+    const u32 e = a + chunk < m ? a + chunk : m;
+    u32 p = 0;
+    if (a) {                                            /* the first run that starts in [a, e): none if a long run covers them all */
+      p = e;
+      for (u32 w0 = a; w0 < e; w0 += 64u) {
+        const u32 k = w0 + lane;
+        const u32 g1 = k < m ? gin[k] : 0u, g0 = k - 1u < m ? gin[k - 1u] : 0u;
+        const u64 hd = __ballot(k < e && g1 != g0);
+        if (hd) { p = w0 + (u32)__ffsll((long long)hd) - 1u; break; }
+      }
+    }
+    while (p < e) {
+      DT_MARK(t0);
+      const u32 k = p + lane;
+      const bool have = k < m;
+      u32 val = have ? sin[k] : 0u;
+      const u32 g = have ? gin[k] : 0xFFFFFFFFu - lane;
+      u32 d = have ? din[k] : 0u;
+      const u32 gbelow = lane_from_below(g);
+      const bool head0 = lane == 0u || g != gbelow;
+      u32 hl = wave_incl_max(head0 ? lane : 0u);
+      u32 cut = m - p <= 64u ? m - p : (u32)__builtin_amdgcn_readlane((int)hl, 63);   /* the run lane 63 sits in may go on: next strip */
+      const u64 lim = __ballot(head0 && k >= e);                                       /* runs that start behind the chunk are the next claim's */
+      if (lim) { const u32 f = (u32)__ffsll((long long)lim) - 1u; cut = f < cut ? f : cut; }
+      if (cut == 0u) {                                                                 /* a run of 64 rows or more: not a strip's job */
+        const u32 rank0 = (u32)__builtin_amdgcn_readlane((int)g, 0);
+        u32 len = 64u;
+        for (;;) {
+          const u32 kk = p + len + lane;
+          const u64 df = __ballot(kk >= m || gin[kk] != rank0);
+          if (df) { len += (u32)__ffsll((long long)df) - 1u; break; }
+          len += 64u;
+        }
+        deep_big_run(W, lane, p, len, Ls, const_cast<u32 *>(sin), s.v0 + lo, T, n, s.sa, bwt, S.inv, M, &S.outn, hmin, round + 1u >= DEEP_HANDOVER);
+        p += len;
+        DT_MARK(t9); DT_ADD(tkb, t0, t9);
+        continue;
+      }
+      const bool in = lane < cut;
+      const u32 row = g + (lane - hl);                  /* places are fixed: the run's rows are consecutive from its rank on */
+      if (!in) hl = lane;
+      bool tied = in, longmode = false;
+      u64 k2 = 0;
+      DT_MARK(t1); DT_ADD(tks, t0, t1);
+      for (u32 step = 0; step < kmax; step++) {
+        const bool can = tied && d + 16u <= n;          /* d + 16 > n: tied nearly all the way round (tiny or periodic blocks) */
+        const u64 cm = __ballot(can);
+        if (!cm || (round + 2u < DEEP_ROUNDS && step >= 2u && 2u * (u32)__popcll(cm) < cut)) break;   /* thinned out: the next launch packs the rest */
+        u32 at = SA_IDX(val) + d;
+        if (at >= n) at -= n;
+        u64 xa = 0, xb = 0;
+        const bool mate = can && hl != lane;            /* has a row of its run in the lane below */
+        if (longmode && !__ballot(can && (at + 64u > n || d + 64u > n))) {
+          /* long repeats: 64 bytes at a time while every run agrees on them, 16 by 16 (no order needed for that: raw words) */
+          u64 ya[4], yb[4];
+#pragma unroll
+          for (u32 q = 0; q < 4u; q++) {
+            ya[q] = 0; yb[q] = 0;
+            if (can) { const lbz_text16 *t16 = reinterpret_cast<const lbz_text16 *>(T + at + 16u * q); ya[q] = t16->a; yb[q] = t16->b; }
+          }
+          u32 same = 0;
+#pragma unroll
+          for (u32 q = 0; q < 4u; q++) {
+            const u64 a0 = (u64)lane_from_below((u32)ya[q]) | (u64)lane_from_below((u32)(ya[q] >> 32)) << 32;
+            const u64 b0 = (u64)lane_from_below((u32)yb[q]) | (u64)lane_from_below((u32)(yb[q] >> 32)) << 32;
+            const bool differs = mate && (a0 != ya[q] || b0 != yb[q]);
+            if (same == q && !__ballot(differs)) same = q + 1u;
+          }
+          if (can) d += 16u * same;
+          if (same == 4u) continue;
+          xa = same == 0u ? ya[0] : (same == 1u ? ya[1] : (same == 2u ? ya[2] : ya[3]));
+          xb = same == 0u ? yb[0] : (same == 1u ? yb[1] : (same == 2u ? yb[2] : yb[3]));
+          longmode = same != 0u;
+        } else {
+          if (can) { const u64x2 x = deep_load16(T, n, SA_IDX(val), d); xa = x.x; xb = x.y; }
+          /* every run agrees on these 16 bytes: no sort, and the next step looks at 64 */
+          const u64 a0 = (u64)lane_from_below((u32)xa) | (u64)lane_from_below((u32)(xa >> 32)) << 32;
+          const u64 b0 = (u64)lane_from_below((u32)xb) | (u64)lane_from_below((u32)(xb >> 32)) << 32;
+          if (!__ballot(mate && (a0 != xa || b0 != xb))) {
+            if (can) d += 16u;
+            longmode = true;
+            continue;
+          }
+        }
+        const u64 hi = __builtin_bswap64(xa), lw = __builtin_bswap64(xb);        /* big-endian: integer order = string order */
+        k2 = can ? ((hi & 0xFFFull) << 40) | (lw >> 24) : 0ull;
+        deep_stage(W, lane, cut, can ? hi >> 12 : 0ull, val, k2, hl, tied);
+        if (__ballot(tied && can))                      /* can is a property of the place: runs only split */
+          deep_stage(W, lane, cut, k2, val, k2, hl, tied);
+        if (can) d += DEEP_STEP;
+      }
+#ifdef DEEP_DEBUG
+      if (in && (row == 3902u || row == 3903u)) printf("round %u row %u lane %u cut %u idx %u d %u tied %d hl %u g %u p %u a %u e %u m %u\n", round, row, lane, cut, SA_IDX(val), d, (int)tied, hl, g, p, a, e, m);
+#endif
+      DT_MARK(t2); DT_ADD(tkp, t1, t2);
+      /* a row that became unique is final: its BWT byte and its suffix-array entry.  A row that is still tied is written
+         again by whoever orders it -- the suffix array (what the rank rounds rebuild their lists from, should the block be
+         handed to them: from launch DEEP_HANDOVER on) only has to be current from the launch before that one on */
+      if (in && (!tied || round + 1u >= DEEP_HANDOVER)) {
+        s.sa[row] = val | ((tied && hl != lane) ? TIE_FLAG : 0u);
+        if (!tied) bwt[row] = S.inv[SA_CODE(val)];
+        if (SA_IDX(val) == 0u) M->bwt_idx = row;
+      }
+      const u64 tm = __ballot(tied);
+      if (tm) {
+        const u32 base = wave_reserve(&S.outn, (u32)__popcll(tm));
+        if (tied) {
+          const u32 o = base + (u32)__popcll(tm & lanes_below());
+          sout[o] = val; gout[o] = row - (lane - hl); dout[o] = d;
+          hmin = d < hmin ? d : hmin;
+        }
+      }
+      p += cut;
+      DT_MARK(t3); DT_ADD(tko, t2, t3);
+#ifdef DEEP_TICKS
+      tkn++;
+#endif
+    }
+  }
+#ifdef DEEP_TICKS
+  if (lane == 0u && round == 0u) {
+    atomicAdd(&M->fticks[0], (u32)tkb); atomicAdd(&M->fticks[1], (u32)tks); atomicAdd(&M->fticks[2], (u32)tkp);
+    atomicAdd(&M->fticks[3], (u32)tko); atomicAdd(&M->fticks[4], (u32)tkn);
+  }
+#endif
+  hmin = wave_min(hmin);
+  if (lane == 0u && hmin != 0xFFFFFFFFu) atomicMin(&S.h0min, hmin);
+  __syncthreads();
+  if (tid == 0) {
+    M->seg_m[seg] = S.outn;
+    if (S.bad) M->err = 7u;
+    if (S.outn) { atomicAdd(&M->deep_tot[round + 1u], S.outn); atomicMin(&M->deep_hmin[round + 1u], S.h0min); }
+    if (round + 1u == DEEP_ROUNDS && S.outn) { atomicMax(&M->periodic, 2u); atomicMin(&M->deep_h0, S.h0min); }
+#ifdef DEEP_DEBUG
+    if (S.outn && round + 1u == DEEP_ROUNDS) printf("blk %u seg %u left %u hmin %u\n", blk, seg, S.outn, S.h0min);
+#endif
+    atomicAdd(&M->sort_elems, m);
+    atomicAdd(&M->fticks[8 + (round < 7u ? round : 7u)], (u32)(wall_clock64() - tk0));
   }
 }
 
@@ -1531,12 +1983,6 @@ k_bwt_batch(const u8 *Tbase, u8 *Bbase, lbz_block_meta *meta, lbz_layout L, u32 
  *              assumes.  A launch whose segment has nothing tied (or whose h has passed n) exits at once; the
  *              host enqueues the log2(M / 8) launches a block can need without looking.
  * k_bwt_fixend origin pointer and "exactly periodic" flag, the bytes of rows that stay tied for good.           */
-__device__ __forceinline__ bwt_slot seg_view(bwt_slot s, u32 lo)
-{
-  s.sufx += lo; s.grp += lo; s.pos += lo;          /* the segment's list */
-  s.k0 += lo; s.k1 += lo; s.v0 += lo; s.v1 += lo;  /* scratch of the HBM sorter (runs longer than a batch) */
-  return s;
-}
 
 __global__ void __launch_bounds__(LBZ_WG, 4)
 k_bwt_fix0(const u8 *Tbase, u8 *Bbase, lbz_block_meta *meta, lbz_layout L, u32 first, u32 count, u32 nblk, u32 segs,
@@ -1555,7 +2001,7 @@ k_bwt_fix0(const u8 *Tbase, u8 *Bbase, lbz_block_meta *meta, lbz_layout L, u32 f
   const bwt_slot s = seg_view(round_slot(ws, slot_bytes, ws_spill, spill_bytes, count, L, bi), lo);
   const size_t off = lbz_elem_off(L, blk);
   bwt_setup(M, &S);
-  const u32 m = wg_regroup<true>(nullptr, s.sa + lo, lo, 0u, hi - lo, s, &S, Tbase + off, n, nullptr, M->seg_isa_from[seg]);
+  const u32 m = wg_regroup<true>(nullptr, s.sa + lo, lo, 0u, hi - lo, s, &S, Tbase + off, n, nullptr);
   if (threadIdx.x == 0) {
     M->seg_m[seg] = m;
     atomicAdd(&M->fticks[1], m);
@@ -1575,13 +2021,13 @@ k_bwt_fixr(const u8 *Tbase, u8 *Bbase, lbz_block_meta *meta, lbz_layout L, u32 f
   const u32 n = M->n;
   if (n < 2u || M->periodic != 2u || seg >= M->nseg) return;
   const u32 m = M->seg_m[seg];
-  if (m == 0u || round < M->deep_start) return;
+  if (m == 0u) return;
   const u64 tk0 = wall_clock64();
   const u32 lo = M->seg_lo[seg];
   const bwt_slot s = seg_view(round_slot(ws, slot_bytes, ws_spill, spill_bytes, count, L, bi), lo);
   const size_t off = lbz_elem_off(L, blk);
-  const keycfg c = bwt_setup(M, &S);
-  const u64 h = (u64)c.sy << round;
+  bwt_setup(M, &S);
+  const u64 h = (u64)M->deep_h0 << round;       /* every tie left is at least deep_h0 symbols deep, every rank at least as deep as that */
   if (h >= n) return;                           /* tied at depth >= n: tied for good (k_bwt_fixend) */
   const u32 m2 = doubling_round(Tbase + off, n, Bbase + off, s, &S, (u32)h, m, round + 1u);
   if (threadIdx.x == 0) {
@@ -1611,7 +2057,8 @@ k_bwt_fixend(u8 *Bbase, lbz_block_meta *meta, lbz_layout L, u32 first, u32 count
     u32 tot;
     const u32 f = (tid < 256u && M->inuse[tid]) ? 1u : 0u;
     const u32 ex = wg_excl_add(f, &tot, &sc);
-    if (f) inv[ex] = (u8)tid;
+    if (tot > 128u) { if (tid < 256u) inv[tid] = (u8)tid; }         /* bwt_setup's rule */
+    else if (f) inv[ex] = (u8)tid;
     __syncthreads();
   }
   /* rows that are tied for good (exactly periodic block): their bytes are all equal anyway */

@@ -263,6 +263,9 @@ static void launch_sort(lbzamd_ctx *c, hipStream_t q, u32 first, u32 count, u32 
     hipLaunchKernelGGL(k_bwt_batch, dim3(lbz_seg_grid(nblk, segs)), dim3(LBZ_BWT_WG), 0, q, (const u8 *)c->T, c->B, c->meta, c->L,
                        first, count, nblk, segs, ws, (u64)c->slot_bytes, wsp, (u64)c->spill_bytes, lst);
   } else {
+    for (u32 r = 0; r < LBZ_DEEP_ROUNDS; r++)
+      hipLaunchKernelGGL(k_bwt_deep, dim3(lbz_seg_grid(nblk, segs)), dim3(LBZ_BWT_WG), 0, q, (const u8 *)c->T, c->B, c->meta, c->L,
+                         first, count, nblk, segs, ws, (u64)c->slot_bytes, wsp, (u64)c->spill_bytes, lst, r);
     hipLaunchKernelGGL(k_bwt_fix0, dim3(lbz_seg_grid(nblk, segs)), dim3(LBZ_BWT_WG), 0, q, (const u8 *)c->T, c->B, c->meta, c->L,
                        first, count, nblk, segs, ws, (u64)c->slot_bytes, wsp, (u64)c->spill_bytes, lst);
     const u32 R = lbz_fix_rounds(c->L.M);

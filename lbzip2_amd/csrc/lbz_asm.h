@@ -196,4 +196,25 @@ __device__ __forceinline__ unsigned wave_claim(unsigned *tickets)
   return (unsigned)__builtin_amdgcn_readfirstlane((int)r) >> 6;
 }
 
+
+/* Reserve `amount` (wave-uniform) consecutive places behind a counter (LDS or HBM): returns the first, wave-uniform.
+ * Written without a branch for the reason given at wave_claim: every lane takes part in the atomic, lane 0 alone adds. */
+__device__ __forceinline__ unsigned wave_reserve(unsigned *counter, unsigned amount)
+{
+  const unsigned r = atomicAdd(counter, (threadIdx.x & 63u) == 0u ? amount : 0u);
+  return (unsigned)__builtin_amdgcn_readfirstlane((int)r);
+}
+
+/* 16 bytes of the block text at any byte address (global_load_dwordx4: gfx950 takes unaligned addresses) */
+struct __attribute__((packed, aligned(1))) lbz_text16 { unsigned long long a, b; };
+
+/* acc + (a0 < b) + (a1 < b), unsigned 64-bit: two v_cmp_lt_u64 + v_addc_co_u32 pairs in one block (the compiler's form
+ * is compare, select, add, and it separates two blocks that both write VCC with a wait state) */
+__device__ __forceinline__ unsigned add_if_less2(unsigned acc, unsigned long long a0, unsigned long long a1, unsigned long long b)
+{
+  asm("v_cmp_lt_u64 vcc, %1, %3\n\tv_addc_co_u32 %0, vcc, 0, %0, vcc\n\t"
+      "v_cmp_lt_u64 vcc, %2, %3\n\tv_addc_co_u32 %0, vcc, 0, %0, vcc" : "+v"(acc) : "v"(a0), "v"(a1), "v"(b) : "vcc");
+  return acc;
+}
+
 #endif

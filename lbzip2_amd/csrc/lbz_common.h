@@ -45,6 +45,7 @@
 #ifndef LBZ_BWT_SEGS
 #define LBZ_BWT_SEGS 16u    /* segments of a block's sorted rows = workgroups per block in k_bwt_batch / k_bwt_fix* (8: -5 %, 32: -2 %) */
 #endif
+#define LBZ_DEEP_ROUNDS 6u  /* launches of k_bwt_deep (the text rounds) per round of blocks */
 #define LBZ_BWT_MAXSEGS 32u /* ... and in rounds of fewer blocks than CUs, where a block's chain of launches is what the caller waits for */
 
 /* Per-block record in HBM.  Blocks are numbered 2*slab (primary) and 2*slab+1 (spill). */
@@ -62,16 +63,18 @@ typedef struct lbz_block_meta {
   uint32_t err;        /* non-zero: internal capacity problem */
   uint32_t rounds;     /* prefix-doubling rounds run (diagnostic) */
   uint32_t sort_elems; /* sum of elements passed through the radix sorter (diagnostic) */
-  uint32_t isa_from;   /* (diagnostic) rows whose ranks k_bwt_batch wrote itself, summed over the block's segments */
+  uint32_t deep_rows;  /* (diagnostic) tied rows k_bwt_batch handed to the text rounds (k_bwt_deep), summed over the segments */
   /* The sorted rows of a block are cut into up to LBZ_BWT_SEGS segments at boundaries of the partition's groups; from
      k_bwt_batch on every (block, segment) is a workgroup of its own (k_bwt.hip).  Rows [seg_lo[s], seg_lo[s+1]).    */
   uint32_t nseg;
   uint32_t msd_bits;    /* key bits the block was partitioned on in HBM (k_bwt_part decides: 32, or 16 for incompressible data) */
-  uint32_t deep_start;  /* first doubling round the block needs: 1 if every tie k_bwt_batch left over has been through one
-                           refinement in LDS (the block is sorted to depth 2 S), 0 otherwise */
+  uint32_t deep_h0;     /* depth every tie that is left for the rank rounds (k_bwt_fix*) is known to reach: they double from here.
+                           0xFFFFFFFF while nothing is left (k_bwt_batch and the last k_bwt_deep launch lower it) */
+  uint32_t deep_skip;   /* k_bwt_batch left long runs tied (BIG_ROUNDS refinements did not split them): the block goes to the rank rounds as it is */
+  uint32_t deep_tot[LBZ_DEEP_ROUNDS + 1];   /* tied rows of the block that enter text round r (its segments' lists together); [LBZ_DEEP_ROUNDS]: left over */
+  uint32_t deep_hmin[LBZ_DEEP_ROUNDS + 1];  /* ... and the least depth any of them is known to share */
   uint32_t seg_lo[LBZ_BWT_MAXSEGS + 1];
-  uint32_t seg_isa_from[LBZ_BWT_MAXSEGS];  /* k_bwt_batch wrote the ranks (isa) of the segment's rows >= this; k_bwt_fix0 fills in the rest */
-  uint32_t seg_m[LBZ_BWT_MAXSEGS];         /* rows of the segment that are still tied (length of its list, k_bwt_fix*) */
+  uint32_t seg_m[LBZ_BWT_MAXSEGS];         /* length of the segment's list of tied rows (k_bwt_batch -> k_bwt_deep rounds; k_bwt_fix* build their own) */
   uint32_t ticks[8];   /* wall_clock64 ticks of k_bwt_part / k_bwt_batch phases (diagnostic) */
   uint32_t fticks[16];  /* wall_clock64 ticks of k_bwt_fix phases (diagnostic) */
   uint8_t  inuse[256]; /* used-byte map (encode.c:63) */

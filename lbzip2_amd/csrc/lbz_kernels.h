@@ -68,6 +68,9 @@ __global__ void k_bwt_part_w(const u8 *Tbase, lbz_block_meta *meta, lbz_layout L
  * grid = lbz_seg_grid(nblk), nblk = blocks of the round (2 * count, or count when only primaries are listed) */
 __global__ void k_bwt_batch(const u8 *Tbase, u8 *Bbase, lbz_block_meta *meta, lbz_layout L, u32 first,
                             u32 count, u32 nblk, u32 segs, u8 *ws, u64 slot_bytes, u8 *ws_spill, u64 spill_bytes, const u32 *slabs);
+/* the text rounds: launch r of LBZ_DEEP_ROUNDS orders the short runs of tied rows k_bwt_batch listed, strip by strip */
+__global__ void k_bwt_deep(const u8 *Tbase, u8 *Bbase, lbz_block_meta *meta, lbz_layout L, u32 first,
+                           u32 count, u32 nblk, u32 segs, u8 *ws, u64 slot_bytes, u8 *ws_spill, u64 spill_bytes, const u32 *slabs, u32 round);
 __global__ void k_bwt_fix0(const u8 *Tbase, u8 *Bbase, lbz_block_meta *meta, lbz_layout L, u32 first,
                            u32 count, u32 nblk, u32 segs, u8 *ws, u64 slot_bytes, u8 *ws_spill, u64 spill_bytes, const u32 *slabs);
 __global__ void k_bwt_fixr(const u8 *Tbase, u8 *Bbase, lbz_block_meta *meta, lbz_layout L, u32 first,

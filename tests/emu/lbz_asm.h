@@ -63,4 +63,13 @@ static inline unsigned wave_claim(unsigned *tickets)
   if ((threadIdx.x & 63) == 0) r = atomicAdd(tickets, 64u);
   return (unsigned)__builtin_amdgcn_readfirstlane((int)r) >> 6;
 }
+/* lbz_asm.h's wave_reserve: lane 0 takes the places for the wave (see wave_claim) */
+static inline unsigned wave_reserve(unsigned *counter, unsigned amount)
+{
+  unsigned r = 0;
+  if ((threadIdx.x & 63) == 0) r = atomicAdd(counter, amount);
+  return (unsigned)__builtin_amdgcn_readfirstlane((int)r);
+}
+struct __attribute__((packed, aligned(1))) lbz_text16 { unsigned long long a, b; };
+static inline unsigned add_if_less2(unsigned acc, unsigned long long a0, unsigned long long a1, unsigned long long b) { return acc + (a0 < b ? 1u : 0u) + (a1 < b ? 1u : 0u); }
 #endif
