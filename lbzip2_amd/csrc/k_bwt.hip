@@ -97,9 +97,8 @@
 #define BIG_ROUNDS 16u                  /* such refinements a chunk gets at most; what is still tied in long runs then is left to the rank rounds */
 #endif
 #define DEEP_ROUNDS LBZ_DEEP_ROUNDS      /* launches of k_bwt_deep (lbz_kernels.h); what they leave tied goes to the rank rounds (k_bwt_fix*) */
-#ifndef DEEP_HANDOVER
-#define DEEP_HANDOVER 3u                /* from this launch of k_bwt_deep on, a block with more than 1/16 of its rows tied goes to the rank rounds */
-#endif
+#define DEEP_HANDOVER 1u                /* the launch of k_bwt_deep at which a block with too many rows still tied is handed to the rank rounds */
+#define DEEP_BUILD 1u                   /* the rows still tied at the end of this launch of k_bwt_deep get rank entries: later launches may step by ranks */
 #define DEEP_STACK 48u
 #define DEEP_CHUNK 256u                 /* list entries a wave claims at a time in k_bwt_deep */
 #define DEEP_STEP 13u                   /* symbols a text step decides: 2 x 52 bits of the 16 bytes it loads */
@@ -117,9 +116,14 @@
    the launch began, whenever the word was written.                                                           */
 #define ISA_ENTRY(cur, prev, tag) ((u64)(cur) | ((u64)(prev) << 20) | ((u64)(tag) << 40))
 #define ISA_CUR(e) ((u32)(e) & 0x000FFFFFu)
+#define ISA_TAG(e) ((u32)((e) >> 40) & 31u)
+/* the text rounds (k_bwt_deep) also note, in the 19 bits above the tag, how many symbols the rotation's run shared when the
+   entry was written (halved, rounded down: a lower bound) */
+#define ISA_ENTRY_D(cur, prev, tag, depth) (ISA_ENTRY(cur, prev, tag) | ((u64)((depth) >> 1) << 45))
+#define ISA_DEPTH(e) ((u32)((e) >> 45) << 1)
 __device__ __forceinline__ u32 isa_before(u64 e, u32 tag)      /* the rank as of the start of the launch with this tag */
 {
-  return (u32)(e >> 40) == tag ? (u32)(e >> 20) & 0x000FFFFFu : (u32)e & 0x000FFFFFu;
+  return ISA_TAG(e) == tag ? (u32)(e >> 20) & 0x000FFFFFu : (u32)e & 0x000FFFFFu;
 }
 static_assert(BATCH_CAP == LBZ_WG * 4u, "a batch is one 4-rows-per-thread tile");
 
@@ -151,7 +155,7 @@ struct bwt_lds {
   u32 bc[16];
   u32 listn, seglo;                   /* k_bwt_batch: entries in the segment's list of tied rows so far; the segment's first row */
   u32 h0min, lmin;                    /* k_bwt_batch: least depth of a tie left for the rank rounds; of a run in the list */
-  u32 msd_shift, pad2_;               /* 64 - the block's partition depth: rows with equal key >> msd_shift form a group */
+  u32 msd_shift, seghi;               /* 64 - the block's partition depth: rows with equal key >> msd_shift form a group; k_bwt_batch: the segment's end */
   u32 dbg[4];                         /* LDS_SORT_TICKS: whole-workgroup batch sorts (count, ticks), oversized groups (count, ticks) */
   u8 cmap[256];                       /* byte -> dense code */
   u8 inv[256];                        /* dense code -> byte */
@@ -994,7 +998,7 @@ __device__ u32 batch_process(const u8 *T, u32 n, u8 *bwt, lbz_block_meta *meta, 
   const u64 tb0 = wall_clock64();
   if (tid == 0) {
     S->bc[7] = 0; S->bc[5] = 0; S->bc[6] = 0;        /* window claim counter; the barriers below publish it */
-    if (trim) S->bc[1] = lo + cnt < n ? (u32)(s.k0[lo + cnt] >> S->msd_shift) : 0xFFFFFFFFu;   /* partition depth <= 32 bits */
+    if (trim) S->bc[1] = lo + cnt < S->seghi ? (u32)(s.k0[lo + cnt] >> S->msd_shift) : 0xFFFFFFFFu;   /* partition depth <= 32 bits; the segment ends at a group boundary (beyond it a neighbour may be rewriting keys) */
   }
   if (!preloaded) {
     for (u32 i = tid; i < cnt; i += LBZ_WG) { B->kA[i] = s.k0[lo + i]; B->vA[i] = s.v0[lo + i]; }
@@ -1011,7 +1015,7 @@ __device__ u32 batch_process(const u8 *T, u32 n, u8 *bwt, lbz_block_meta *meta, 
     need_sort = false;
   }
   batch_runs(B, B->kA, cnt, need_sort ? S->msd_shift : 0u, &maxrun, S);
-  if (trim && lo + cnt < n && (u32)(B->kA[cnt - 1u] >> S->msd_shift) == S->bc[1]) {
+  if (trim && lo + cnt < S->seghi && (u32)(B->kA[cnt - 1u] >> S->msd_shift) == S->bc[1]) {
     cnt = B->gh[cnt - 1u];                       /* the last group goes on: it waits for the next batch */
     if (cnt == 0u) { __syncthreads(); return 0u; }
   }
@@ -1077,6 +1081,9 @@ __device__ void emit_tied_rows(u8 *bwt, bwt_slot s, bwt_lds *S, u32 lo, u32 hi, 
     if ((v & 0x00FFFFFFu) == 0u) meta->bwt_idx = j;
   }
   if (threadIdx.x == 0) { S->bc[8] = 1u; atomicMin(&S->h0min, depth); }
+#ifdef DEEP_DEBUG
+  if (threadIdx.x == 0) printf("emit_tied_rows [%u,%u) depth %u\n", lo, hi, depth);
+#endif
   __syncthreads();
 }
 
@@ -1174,6 +1181,9 @@ __device__ void big_group(const u8 *T, u32 n, u8 *bwt, lbz_block_meta *meta, bwt
           __syncthreads();
           lev++;
           fhi[lev] = end; fdepth[lev] = depth + c.sy;
+#ifdef DEEP_DEBUG
+          if (tid == 0) printf("  push lev %u [%u,%u) depth %u (group [%u,%u))\n", lev, pos, end, fdepth[lev], lo, hi);
+#endif
           fresh = true; nbits = 64u;
           continue;
         }
@@ -1335,6 +1345,21 @@ __device__ keycfg bwt_setup(const lbz_block_meta *meta, bwt_lds *S)
 }
 
 
+/* segments of a block (see "segments" below): how many, and where one begins */
+__device__ __forceinline__ u32 bwt_nseg(u32 n, u32 segs)          /* segs: the launch's workgroups per block (<= LBZ_BWT_MAXSEGS) */
+{
+  const u32 p = n / (4u * SMALL_BLOCK);             /* SMALL_BLOCK = a batch of k_bwt_batch, in either build of this file */
+  return p < 1u ? 1u : (p > segs ? segs : p);
+}
+
+/* first row at or behind x that starts a group of the partition; n if there is none */
+__device__ u32 seg_cut(const u64 *k0, u32 x, u32 n, bwt_lds *S)
+{
+  if (x == 0u) return 0u;
+  if (x >= n) return n;
+  return find_run_end(k0, x - 1u, x, n, S->msd_shift, S);
+}
+
 /* ---- kernel 1: partition on the key's top 24 bits: k0 <- text, k1 <- k0, k0 <- k1 ---- */
 /* the partition only needs the sorter's part of the LDS layout: 80 KB */
 struct part_lds {
@@ -1342,7 +1367,7 @@ struct part_lds {
   u32 bc[16];
   u32 listn, seglo;
   u32 h0min, lmin;
-  u32 msd_shift, pad2_;
+  u32 msd_shift, seghi;
   u32 dbg[4];
   u8 cmap[256];
   u8 inv[256];
@@ -1352,7 +1377,7 @@ static_assert(offsetof(part_lds, X) == offsetof(bwt_lds, u), "same layout up to 
 static_assert(sizeof(part_lds) <= 81920, "two per CU");
 
 __device__ __forceinline__ void part_block(bwt_lds &S, const u8 *Tbase, lbz_block_meta *meta, lbz_layout L, u32 first, u32 count,
-                                           u8 *ws, u64 slot_bytes, u8 *ws_spill, u64 spill_bytes, const u32 *slabs)
+                                           u8 *ws, u64 slot_bytes, u8 *ws_spill, u64 spill_bytes, const u32 *slabs, u32 segs)
 {
   const u32 tid = threadIdx.x;
   const u32 blk = lbz_round_block(first, count, blockIdx.x, slabs);
@@ -1366,7 +1391,10 @@ __device__ __forceinline__ void part_block(bwt_lds &S, const u8 *Tbase, lbz_bloc
     for (u32 i = 0; i < 16u; i++) M->fticks[i] = 0;
     for (u32 i = 0; i < LBZ_BWT_MAXSEGS; i++) M->seg_m[i] = 0;
   }
-  if (n <= SMALL_BLOCK) return;               /* small blocks are sorted whole by k_bwt_batch */
+  if (n <= SMALL_BLOCK) {                     /* small blocks are sorted whole by k_bwt_batch: one segment */
+    if (tid == 0) { meta[blk].nseg = 1u; meta[blk].seg_lo[0] = 0u; meta[blk].seg_lo[1] = n; }
+    return;
+  }
   const bwt_slot s = round_slot(ws, slot_bytes, ws_spill, spill_bytes, count, L, blockIdx.x);
   const u8 *T = Tbase + lbz_elem_off(L, blk);
   const u64 tk0 = wall_clock64();
@@ -1401,16 +1429,30 @@ __device__ __forceinline__ void part_block(bwt_lds &S, const u8 *Tbase, lbz_bloc
     msd_array_pass(kb[cur], vb[cur], n, 32u + 8u * j, kb[cur ^ 1u], vb[cur ^ 1u], &S);
     cur ^= 1u;
   }
-  if (tid == 0) meta[blk].ticks[2] = (u32)(wall_clock64() - tk0);
+  /* The segments' bounds, fixed HERE: group boundaries of the partition nearest to the even cuts.  The segment workgroups of
+     k_bwt_batch rewrite keys while they work (an oversized group trades its keys for later symbols), so a neighbour
+     must not be searching the key column for its bounds at that time. */
+  __syncthreads();
+  if (tid == 0) S.msd_shift = 64u - bits;
+  __syncthreads();
+  const u32 nseg = bwt_nseg(n, segs);
+  for (u32 g = 1; g < nseg; g++) {
+    const u32 cut = seg_cut(s.k0, (u32)((u64)g * n / nseg), n, &S);
+    if (tid == 0) meta[blk].seg_lo[g] = cut;
+  }
+  if (tid == 0) {
+    meta[blk].nseg = nseg; meta[blk].seg_lo[0] = 0u; meta[blk].seg_lo[nseg] = n;
+    meta[blk].ticks[2] = (u32)(wall_clock64() - tk0);
+  }
 }
 
 /* 256 threads in the main build (four workgroups per CU beside the sorting kernels' own), 1024 in the wide one */
 __global__ void __launch_bounds__(LBZ_WG, 4)
 k_bwt_part(const u8 *Tbase, lbz_block_meta *meta, lbz_layout L, u32 first, u32 count,
-           u8 *ws, u64 slot_bytes, u8 *ws_spill, u64 spill_bytes, const u32 *slabs)
+           u8 *ws, u64 slot_bytes, u8 *ws_spill, u64 spill_bytes, const u32 *slabs, u32 segs)
 {
   __shared__ part_lds S_;
-  part_block(*reinterpret_cast<bwt_lds *>(&S_), Tbase, meta, L, first, count, ws, slot_bytes, ws_spill, spill_bytes, slabs);
+  part_block(*reinterpret_cast<bwt_lds *>(&S_), Tbase, meta, L, first, count, ws, slot_bytes, ws_spill, spill_bytes, slabs, segs);
 }
 
 #ifndef LBZ_BWT_WIDE
@@ -1423,12 +1465,6 @@ k_bwt_part(const u8 *Tbase, lbz_block_meta *meta, lbz_layout L, u32 first, u32 c
  * waves of workgroups, the last one 17 % full), an input of a hundred blocks fills the chip, and a block's
  * chain of stages is short enough for the work-unit interface.  The segment workgroups of a block share its
  * workspace slot; what they share beyond that is isa[]: see k_bwt_fixr.                                       */
-__device__ __forceinline__ u32 bwt_nseg(u32 n, u32 segs)          /* segs: the launch's workgroups per block (<= LBZ_BWT_MAXSEGS) */
-{
-  const u32 p = n / (4u * BATCH_CAP);
-  return p < 1u ? 1u : (p > segs ? segs : p);
-}
-
 /* (block of the round, segment) of this workgroup.  Hardware deals workgroup j to XCD j mod 8: the segment
  * workgroups of one block sit on ONE XCD (they share the block's text and ranks in that L2) and within 64
  * positions of each other in dispatch order.  Grid = ceil(nblk / 8) * 8 * segs.                                 */
@@ -1438,14 +1474,6 @@ __device__ __forceinline__ bool seg_item(u32 nblk, u32 segs, u32 *i, u32 *seg)
   *i = (k / segs) * 8u + (j & 7u);
   *seg = k % segs;
   return *i < nblk;
-}
-
-/* first row at or behind x that starts a group of the partition; n if there is none */
-__device__ u32 seg_cut(const u64 *k0, u32 x, u32 n, bwt_lds *S)
-{
-  if (x == 0u) return 0u;
-  if (x >= n) return n;
-  return find_run_end(k0, x - 1u, x, n, S->msd_shift, S);
 }
 
 /* ---- kernel 2: LDS batches of whole groups; emits BWT bytes + rows; flags deep ties ---- */
@@ -1461,7 +1489,7 @@ k_bwt_batch(const u8 *Tbase, u8 *Bbase, lbz_block_meta *meta, lbz_layout L, u32 
   lbz_block_meta *M = &meta[blk];
   const u32 n = M->n;
   if (n == 0u) return;
-  const u32 nseg = n <= BATCH_CAP ? 1u : bwt_nseg(n, segs);
+  const u32 nseg = n == 1u ? 1u : M->nseg;    /* k_bwt_part fixed the segments (blocks of one byte never reach it: n == 1 below) */
   if (seg >= nseg) return;
   const bwt_slot s = round_slot(ws, slot_bytes, ws_spill, spill_bytes, count, L, bi);
   const size_t off = lbz_elem_off(L, blk);
@@ -1474,16 +1502,10 @@ k_bwt_batch(const u8 *Tbase, u8 *Bbase, lbz_block_meta *meta, lbz_layout L, u32 
   const u64 tk0 = wall_clock64();
   const keycfg c = bwt_setup(M, &S);
   u32 lo = 0, hi = n;
-  if (nseg > 1u) {
-    lo = seg_cut(s.k0, (u32)((u64)seg * n / nseg), n, &S);
-    hi = seg + 1u == nseg ? n : seg_cut(s.k0, (u32)((u64)(seg + 1u) * n / nseg), n, &S);
-  }
+  if (nseg > 1u) { lo = M->seg_lo[seg]; hi = M->seg_lo[seg + 1u]; }
   if (tid == 0) {
-    S.listn = 0; S.seglo = lo; S.h0min = 0xFFFFFFFFu; S.lmin = 0xFFFFFFFFu;
+    S.listn = 0; S.seglo = lo; S.seghi = hi; S.h0min = 0xFFFFFFFFu; S.lmin = 0xFFFFFFFFu;
     for (u32 i = 0; i < 4; i++) S.dbg[i] = 0;
-    M->seg_lo[seg] = lo;
-    if (seg + 1u == nseg) M->seg_lo[nseg] = n;
-    if (seg == 0u) M->nseg = nseg;
   }
   __syncthreads();
   if (n <= BATCH_CAP) {
@@ -1503,7 +1525,7 @@ k_bwt_batch(const u8 *Tbase, u8 *Bbase, lbz_block_meta *meta, lbz_layout L, u32 
 #ifdef LDS_SORT_TICKS
         const u64 tg0 = wall_clock64();
 #endif
-        const u32 end = find_run_end(s.k0, pos, pos + want, n, S.msd_shift, &S);
+        const u32 end = find_run_end(s.k0, pos, pos + want, hi, S.msd_shift, &S)   /* inside the segment: a neighbour may be rewriting its keys */;
         big_group(T, n, bwt, M, s, &S, c, pos, end);
 #ifdef LDS_SORT_TICKS
         if (tid == 0) { S.dbg[3] += (u32)(wall_clock64() - tg0); S.dbg[2] += end - pos; }
@@ -1573,9 +1595,9 @@ struct deep_lds {
   deep_wave w[LBZ_NW];
 };
 
-/* steps a strip may take in launch r: 2 2 2 8 64 1024.  A step decides 13 symbols, or skips 16 to 64 that all its runs
-   share -- the last launches follow what is left (pairs of long repeats as a rule) for up to 64 KB */
-__device__ __forceinline__ u32 deep_kmax(u32 round) { return round < 3u ? 2u : (round == 3u ? 8u : (round == 4u ? 64u : 1024u)); }
+/* steps a strip may take in launch r: 2 2 4 8 16 32 256 256.  A text step decides 13 symbols, or skips 16 to 64 that all
+   its runs share; a rank step (from launch DEEP_BUILD + 1 on) as many as the run it looks up shares */
+__device__ __forceinline__ u32 deep_kmax(u32 round) { return round < 2u ? 2u : (round + 2u < DEEP_ROUNDS ? 2u << (round - 1u) : 256u); }
 
 /* Sort the strip inside its runs on `slice` (52 bits).  val and k2 move with their rows; hl (first lane of the lane's
  * run) and tied describe places, and are refined.  Lanes >= nv are not part of the strip.                         */
@@ -1635,6 +1657,21 @@ __device__ __forceinline__ u64x2 deep_load16(const u8 *T, u32 n, u32 idx, u32 d)
   return x;
 }
 
+/* Ranks for the rows the text has not ordered by launch DEEP_BUILD (on text a quarter of a block: repeats of 35 symbols and
+ * more).  What is left then is mostly LONG repeats -- passages that occur twice -- and walking those symbol by symbol costs
+ * their length squared; a run x, y tied for d symbols is ordered by the ranks of x + d and y + d instead (prefix doubling).
+ * The rank rounds (k_bwt_fix*) keep a rank for EVERY rotation, 7 MB per block written and gathered across HBM; here only
+ * the rows in the lists have entries (isa[], same 8-byte {rank, rank before, tag} words, so that a launch reads the ranks
+ * as they stood when it began whatever its other workgroups are writing), and a bit map of the block's rotations says
+ * which: a target without an entry became unique before launch DEEP_BUILD ended, so the text decides within the few dozen
+ * symbols those launches covered, and the strip takes a text step instead.  From then on every change of rank is stored.  */
+struct deep_ranks { u64 *isa; u32 *map; u32 tag, hcur; bool build, live; };
+__device__ __forceinline__ void deep_publish(deep_ranks R, u32 idx, u32 rank, u32 depth)
+{
+  R.isa[idx] = ISA_ENTRY_D(rank, rank, 0u, depth);
+  atomicOr(&R.map[idx >> 5], 1u << (idx & 31u));
+}
+
 struct deep_lists { const u32 *sin, *gin, *din; u32 *sout, *gout, *dout; };
 
 /* A run of g >= 64 tied rows (list entries [p, p + g)): too long for a strip.  Its wave takes it apart symbol by symbol:
@@ -1648,7 +1685,7 @@ struct deep_lists { const u32 *sin, *gin, *din; u32 *sout, *gout, *dout; };
  * after two or three; a template that a hundred rows share for 60 symbols costs four 16-byte steps.  A piece that shares
  * 64 further symbols (or overflows the stack) goes to the next list as it is, deeper, and the next launch carries on.    */
 __device__ void deep_big_run(deep_wave *W, u32 lane, u32 p, u32 g, deep_lists Ls, u32 *ping, u32 *pong, const u8 *T, u32 n,
-                             u32 *sa, u8 *bwt, const u8 *inv, lbz_block_meta *M, u32 *outn, u32 &hmin, bool late)
+                             u32 *sa, u8 *bwt, const u8 *inv, lbz_block_meta *M, u32 *outn, u32 &hmin, bool late, deep_ranks R)
 {
   const u32 rank0 = Ls.gin[p];
   const u32 d0 = Ls.din[p];
@@ -1691,7 +1728,16 @@ __device__ void deep_big_run(deep_wave *W, u32 lane, u32 p, u32 g, deep_lists Ls
       /* nothing to split on yet (64 more symbols shared, or tied all the way round), or no room on the stack: the piece
          goes on as it is, deeper */
       const u32 ob = wave_reserve(outn, len);
-      for (u32 k = lane; k < len; k += 64u) { Ls.sout[ob + k] = src[k]; Ls.gout[ob + k] = r0; Ls.dout[ob + k] = d; }
+      for (u32 k = lane; k < len; k += 64u) {
+        const u32 val = src[k];
+        Ls.sout[ob + k] = val; Ls.gout[ob + k] = r0; Ls.dout[ob + k] = d;
+        if (late) {                                     /* the rows may have moved inside the run since the suffix array was written */
+          sa[r0 + k] = val | (k ? TIE_FLAG : 0u);
+          if (SA_IDX(val) == 0u) M->bwt_idx = r0 + k;
+        }
+        if (R.build) deep_publish(R, SA_IDX(val), r0, d);
+        else if (R.live && off) R.isa[SA_IDX(val)] = ISA_ENTRY_D(r0, rank0, R.tag, d);
+      }
       hmin = d < hmin ? d : hmin;
       wave_sync();
       continue;
@@ -1753,9 +1799,13 @@ __device__ void deep_big_run(deep_wave *W, u32 lane, u32 p, u32 g, deep_lists Ls
         }
         if (c > BIG_RUN) {
           dst[b0 + slot] = val;
-        } else if (c > 1u) {
-          const u32 o = ob + (u32)W->obase[by] + slot;
-          Ls.sout[o] = val; Ls.gout[o] = r0 + b0; Ls.dout[o] = d + 1u;
+        } else {
+          if (c > 1u) {
+            const u32 o = ob + (u32)W->obase[by] + slot;
+            Ls.sout[o] = val; Ls.gout[o] = r0 + b0; Ls.dout[o] = d + 1u;
+            if (R.build) deep_publish(R, SA_IDX(val), r0 + b0, d + 1u);
+          }
+          if (R.live && off + b0) R.isa[SA_IDX(val)] = ISA_ENTRY_D(r0 + b0, rank0, R.tag, d + 1u);   /* final for this launch: its rank changed */
         }
       }
     }
@@ -1778,22 +1828,32 @@ k_bwt_deep(const u8 *Tbase, u8 *Bbase, lbz_block_meta *meta, lbz_layout L, u32 f
   if (n < 2u || seg >= M->nseg) return;
   const u32 tot = M->deep_tot[round];            /* the block's tied rows that are left for this round, all segments */
   if (tot == 0u) return;
-  /* Blocks the text cannot finish cheaply go to the rank rounds as they are: long runs left over by k_bwt_batch, or --
-     from the fourth launch on -- more than a sixteenth of the rows still tied (source trees, logs: repeats of hundreds of
-     symbols, which ranks double through and text steps walk through).  Every segment decides the same.              */
+  /* a block in which k_bwt_batch left long runs tied (more than a batch of equal keys, BIG_LEVELS deep) goes to the rank
+     rounds as it is */
 #ifdef DEEP_DEBUG
   if (seg == 0u && threadIdx.x == 0u) printf("blk %u round %u tot %u hmin %u skip %u n %u\n", blk, round, tot, M->deep_hmin[round], M->deep_skip, n);
 #endif
-  if (M->deep_skip || (round >= DEEP_HANDOVER && (u64)tot * 16ull > n)) {
-    if (seg == 0u && threadIdx.x == 0u) { atomicMax(&M->periodic, 2u); atomicMin(&M->deep_h0, M->deep_hmin[round]); }
+  /* ... and so does a block of which two fifths are still tied after the first launch (source trees, logs: repeats of
+     hundreds of symbols under most rows).  Ranks double through those, but a run can only step by ranks if the rotations it
+     looks up have entries, and giving every rotation one is what the rank rounds do.  Every segment decides the same.  */
+  if (M->deep_skip || (round == DEEP_HANDOVER && (u64)tot * 5ull > (u64)n * 2ull)) {
+    if (seg == 0u && threadIdx.x == 0u) {
+      atomicMax(&M->periodic, 2u); atomicMin(&M->deep_h0, M->deep_hmin[round]);
+    }
     return;
+  }
+  const bwt_slot s = round_slot(ws, slot_bytes, ws_spill, spill_bytes, count, L, bi);
+  if (round == 0u) {                              /* the bit map of rotations with a rank entry: every segment clears its share */
+    u32 *map = reinterpret_cast<u32 *>(s.k0);
+    const u32 words = (n + 31u) / 32u, nsg = M->nseg;
+    const u32 w0 = (u32)((u64)words * seg / nsg), w1 = (u32)((u64)words * (seg + 1u) / nsg);
+    for (u32 i = w0 + threadIdx.x; i < w1; i += LBZ_WG) map[i] = 0u;
   }
   const u32 m = M->seg_m[seg];
   if (m == 0u) return;
   const u64 tk0 = wall_clock64();
   const u32 tid = threadIdx.x, lane = lane_id();
   const u32 lo = M->seg_lo[seg];
-  const bwt_slot s = round_slot(ws, slot_bytes, ws_spill, spill_bytes, count, L, bi);
   const u32 cap = bi < count ? L.cap_a : L.cap_b;
   const size_t off = lbz_elem_off(L, blk);
   const u8 *T = Tbase + off;
@@ -1814,6 +1874,10 @@ k_bwt_deep(const u8 *Tbase, u8 *Bbase, lbz_block_meta *meta, lbz_layout L, u32 f
   }
   deep_wave *W = &S.w[wave_id()];
   const deep_lists Ls = { sin, gin, din, sout, gout, dout };
+  deep_ranks R;
+  R.isa = s.isa; R.map = reinterpret_cast<u32 *>(s.k0);          /* the partition's key column is free since k_bwt_batch */
+  R.tag = round + 1u; R.hcur = M->deep_hmin[round];
+  R.build = round == DEEP_BUILD; R.live = round > DEEP_BUILD;
 #ifdef DEEP_TICKS
   u64 tkb = 0, tks = 0, tkp = 0, tko = 0, tkn = 0;          /* long runs, strip set-up, steps, output; strips */
 #define DT_MARK(v) const u64 v = wall_clock64()
@@ -1823,6 +1887,7 @@ k_bwt_deep(const u8 *Tbase, u8 *Bbase, lbz_block_meta *meta, lbz_layout L, u32 f
 #define DT_ADD(acc, a, b)
 #endif
   const u32 kmax = deep_kmax(round);
+  const bool late = round + 1u == DEEP_ROUNDS || round + 1u == DEEP_HANDOVER;   /* what is tied after this launch may be for the rank rounds: they read the suffix array */
   const u32 chunk = m < 16u * DEEP_CHUNK ? 64u : DEEP_CHUNK;    /* a short list (the late launches: long repeats, a strip's steps are a chain of
                                                                    round trips) is dealt out a strip at a time */
   u32 hmin = 0xFFFFFFFFu;
@@ -1862,7 +1927,7 @@ k_bwt_deep(const u8 *Tbase, u8 *Bbase, lbz_block_meta *meta, lbz_layout L, u32 f
           if (df) { len += (u32)__ffsll((long long)df) - 1u; break; }
           len += 64u;
         }
-        deep_big_run(W, lane, p, len, Ls, const_cast<u32 *>(sin), s.v0 + lo, T, n, s.sa, bwt, S.inv, M, &S.outn, hmin, round + 1u >= DEEP_HANDOVER);
+        deep_big_run(W, lane, p, len, Ls, const_cast<u32 *>(sin), s.v0 + lo, T, n, s.sa, bwt, S.inv, M, &S.outn, hmin, late, R);
         p += len;
         DT_MARK(t9); DT_ADD(tkb, t0, t9);
         continue;
@@ -1874,11 +1939,51 @@ k_bwt_deep(const u8 *Tbase, u8 *Bbase, lbz_block_meta *meta, lbz_layout L, u32 f
       u64 k2 = 0;
       DT_MARK(t1); DT_ADD(tks, t0, t1);
       for (u32 step = 0; step < kmax; step++) {
+        u32 at = SA_IDX(val) + d;
+        if (at >= n) at -= n;
+        if (R.live) {
+          /* Runs whose rows all look up rotations WITH an entry step by ranks; the others by 13 symbols of text (the
+             rotation without an entry was unique by the end of launch DEEP_BUILD: the text decides soon). */
+          const bool canr = tied && d < n;
+          const bool has = canr && ((R.map[at >> 5] >> (at & 31u)) & 1u);
+          const u64 hm = __ballot(hl == lane);                              /* first lanes of the runs as they stand */
+          const u64 above = lane == 63u ? 0ull : hm >> (lane + 1u);
+          const u32 he = above ? lane + 1u + (u32)__builtin_ctzll(above) : 64u;
+          const u64 runmask = (he == 64u ? ~0ull : (1ull << he) - 1ull) & ~((1ull << hl) - 1ull);
+          const u64 noentry = __ballot(canr && !has);
+          const bool useR = canr && !(noentry & runmask);
+          const bool useT = tied && !useR && d + 16u <= n;
+          const u64 um = __ballot(useR || useT);
+          if (!um || (round + 2u < DEEP_ROUNDS && step >= 2u && 2u * (u32)__popcll(um) < cut)) break;
+          u64 s1 = 0;
+          k2 = 0;
+          if (useR) {
+            const u64 e = R.isa[at];
+            const bool fresh = ISA_TAG(e) == R.tag;
+            s1 = (u64)isa_before(e, R.tag);
+            k2 = (u64)(fresh ? R.hcur : (ISA_DEPTH(e) > R.hcur ? ISA_DEPTH(e) : R.hcur));      /* travels with the row */
+          } else if (useT) {
+            const u64x2 x = deep_load16(T, n, SA_IDX(val), d);
+            const u64 hi = __builtin_bswap64(x.x), lw = __builtin_bswap64(x.y);
+            s1 = hi >> 12;
+            k2 = ((hi & 0xFFFull) << 40) | (lw >> 24);
+          }
+          deep_stage(W, lane, cut, s1, val, k2, hl, tied);
+          if (__ballot(tied && useT))                   /* useR, useT belong to the place: runs only split */
+            deep_stage(W, lane, cut, useT ? k2 : 0ull, val, k2, hl, tied);
+          /* rows that stay tied after a rank step looked up rotations of ONE run: either's note of its depth is a lower
+             bound of that run's */
+          W->val[lane] = (u32)k2;
+          wave_sync();
+          const u32 dh = W->val[hl];
+          wave_sync();
+          if (useR) d = d + dh < n ? d + dh : n;
+          else if (useT) d += DEEP_STEP;
+          continue;
+        }
         const bool can = tied && d + 16u <= n;          /* d + 16 > n: tied nearly all the way round (tiny or periodic blocks) */
         const u64 cm = __ballot(can);
         if (!cm || (round + 2u < DEEP_ROUNDS && step >= 2u && 2u * (u32)__popcll(cm) < cut)) break;   /* thinned out: the next launch packs the rest */
-        u32 at = SA_IDX(val) + d;
-        if (at >= n) at -= n;
         u64 xa = 0, xb = 0;
         const bool mate = can && hl != lane;            /* has a row of its run in the lane below */
         if (longmode && !__ballot(can && (at + 64u > n || d + 64u > n))) {
@@ -1925,19 +2030,21 @@ k_bwt_deep(const u8 *Tbase, u8 *Bbase, lbz_block_meta *meta, lbz_layout L, u32 f
 #endif
       DT_MARK(t2); DT_ADD(tkp, t1, t2);
       /* a row that became unique is final: its BWT byte and its suffix-array entry.  A row that is still tied is written
-         again by whoever orders it -- the suffix array (what the rank rounds rebuild their lists from, should the block be
-         handed to them: from launch DEEP_HANDOVER on) only has to be current from the launch before that one on */
-      if (in && (!tied || round + 1u >= DEEP_HANDOVER)) {
+         again by whoever orders it; only the last launch leaves the suffix array current for the rank rounds */
+      if (in && (!tied || late)) {
         s.sa[row] = val | ((tied && hl != lane) ? TIE_FLAG : 0u);
         if (!tied) bwt[row] = S.inv[SA_CODE(val)];
         if (SA_IDX(val) == 0u) M->bwt_idx = row;
       }
+      const u32 newrank = row - (lane - hl);
+      if (in && R.live && newrank != g) R.isa[SA_IDX(val)] = ISA_ENTRY_D(newrank, g, R.tag, d);
       const u64 tm = __ballot(tied);
       if (tm) {
         const u32 base = wave_reserve(&S.outn, (u32)__popcll(tm));
         if (tied) {
           const u32 o = base + (u32)__popcll(tm & lanes_below());
-          sout[o] = val; gout[o] = row - (lane - hl); dout[o] = d;
+          sout[o] = val; gout[o] = newrank; dout[o] = d;
+          if (R.build) deep_publish(R, SA_IDX(val), newrank, d);
           hmin = d < hmin ? d : hmin;
         }
       }

@@ -255,10 +255,10 @@ static void launch_sort(lbzamd_ctx *c, hipStream_t q, u32 first, u32 count, u32 
   if (phase == 0) {
     if (count <= c->ncus)      /* fewer blocks than CUs: sixteen waves per block instead of four (k_bwt_wide.o) */
       hipLaunchKernelGGL(k_bwt_part_w, dim3(nblk), dim3(1024), 0, q, (const u8 *)c->T, c->meta, c->L,
-                         first, count, ws, (u64)c->slot_bytes, wsp, (u64)c->spill_bytes, lst);
+                         first, count, ws, (u64)c->slot_bytes, wsp, (u64)c->spill_bytes, lst, segs);
     else
       hipLaunchKernelGGL(k_bwt_part, dim3(nblk), dim3(LBZ_BWT_WG), 0, q, (const u8 *)c->T, c->meta, c->L,
-                         first, count, ws, (u64)c->slot_bytes, wsp, (u64)c->spill_bytes, lst);
+                         first, count, ws, (u64)c->slot_bytes, wsp, (u64)c->spill_bytes, lst, segs);
   } else if (phase == 1) {
     hipLaunchKernelGGL(k_bwt_batch, dim3(lbz_seg_grid(nblk, segs)), dim3(LBZ_BWT_WG), 0, q, (const u8 *)c->T, c->B, c->meta, c->L,
                        first, count, nblk, segs, ws, (u64)c->slot_bytes, wsp, (u64)c->spill_bytes, lst);

@@ -45,7 +45,7 @@
 #ifndef LBZ_BWT_SEGS
 #define LBZ_BWT_SEGS 16u    /* segments of a block's sorted rows = workgroups per block in k_bwt_batch / k_bwt_fix* (8: -5 %, 32: -2 %) */
 #endif
-#define LBZ_DEEP_ROUNDS 6u  /* launches of k_bwt_deep (the text rounds) per round of blocks */
+#define LBZ_DEEP_ROUNDS 8u  /* launches of k_bwt_deep (the text rounds) per round of blocks */
 #define LBZ_BWT_MAXSEGS 32u /* ... and in rounds of fewer blocks than CUs, where a block's chain of launches is what the caller waits for */
 
 /* Per-block record in HBM.  Blocks are numbered 2*slab (primary) and 2*slab+1 (spill). */

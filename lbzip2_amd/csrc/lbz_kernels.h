@@ -60,10 +60,10 @@ __global__ void k_seq_tiles(const u8 *in, u64 in_len, u32 *last_head, u32 *first
 __global__ void k_seq_prefix(const u32 *last_head, const u32 *first_head, const u32 *emits, u32 ntiles, u32 a0,
                              unsigned long long *carry, unsigned long long *gpre);
 __global__ void k_bwt_part(const u8 *Tbase, lbz_block_meta *meta, lbz_layout L, u32 first, u32 count,
-                           u8 *ws, u64 slot_bytes, u8 *ws_spill, u64 spill_bytes, const u32 *slabs);
+                           u8 *ws, u64 slot_bytes, u8 *ws_spill, u64 spill_bytes, const u32 *slabs, u32 segs);
 /* the same kernel with 1024-thread workgroups (k_bwt.hip built a second time with LBZ_BWT_WIDE): rounds of few blocks */
 __global__ void k_bwt_part_w(const u8 *Tbase, lbz_block_meta *meta, lbz_layout L, u32 first, u32 count,
-                             u8 *ws, u64 slot_bytes, u8 *ws_spill, u64 spill_bytes, const u32 *slabs);
+                             u8 *ws, u64 slot_bytes, u8 *ws_spill, u64 spill_bytes, const u32 *slabs, u32 segs);
 /* from here on a block's sorted rows are dealt over LBZ_BWT_SEGS segment workgroups (k_bwt.hip, "segments"):
  * grid = lbz_seg_grid(nblk), nblk = blocks of the round (2 * count, or count when only primaries are listed) */
 __global__ void k_bwt_batch(const u8 *Tbase, u8 *Bbase, lbz_block_meta *meta, lbz_layout L, u32 first,

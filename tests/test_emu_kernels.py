@@ -171,3 +171,24 @@ def test_c_side_multi_device(emu, tmp_path):
     r = subprocess.run([exe, "-1", "-f", str(src), "-o", str(dst), "-g", "2"], env=dict(os.environ, LBZ_EMU_DEVICES="1"),
                        capture_output=True, timeout=900)
     assert r.returncode == 0 and dst.read_bytes() == want           # more devices asked for than there are: clamped
+
+
+def test_oversized_runs_at_segment_bounds(emu):
+    """Case 10 of the decoder fuzz (seed 41: tests/test_decode.py::test_fuzz_on_the_gpu): three byte values, nearly
+    periodic, so that groups of more than a batch of EQUAL keys lie on both sides of a segment bound.  Such a group trades
+    its keys for later symbols (k_bwt.hip, big_group) while the neighbouring segment workgroup is still looking at the key
+    column: nothing of a segment's may be read from outside it (round 4: the group-end search ran to the block's end)."""
+    import random
+
+    import fuzz_gpu
+    rng = random.Random(41)
+    fuzz_gpu.BIG = fuzz_gpu.SMALL = False
+    for i in range(11):
+        data = fuzz_gpu.make(rng)
+        level = rng.choice([1, 1, 2, 9])
+        rng.random()
+        if rng.random() < 0.3:
+            fuzz_gpu.make(rng)
+            rng.choice([1, 9])
+    assert (len(data), level) == (79835, 1)
+    assert emu.compress(data, level) == L.orc_compress(data, level)
