@@ -100,6 +100,7 @@
 #define DEEP_HANDOVER 1u                /* the launch of k_bwt_deep at which a block with too many rows still tied is handed to the rank rounds */
 #define DEEP_BUILD 1u                   /* the rows still tied at the end of this launch of k_bwt_deep get rank entries: later launches may step by ranks */
 #define DEEP_STACK 48u
+#define DEEP_LEVELS 4u                  /* symbols a long run is split on in one launch */
 #define DEEP_CHUNK 256u                 /* list entries a wave claims at a time in k_bwt_deep */
 #define DEEP_STEP 13u                   /* symbols a text step decides: 2 x 52 bits of the 16 bytes it loads */
 #define TIE_FLAG 0x80000000u
@@ -890,6 +891,7 @@ __device__ void wave_finish_chunk(batch_lds *B, u32 cs, u32 ce, bool need_sort, 
   const bwt_slot ls = seg_view(s, S->seglo);
   /* the chunk's tied runs take ONE stretch of the list: the rows of a run must lie side by side there */
   u32 lbase = ntied ? wave_reserve(&S->listn, ntied) : 0u;
+  u32 nlong = 0;
   for (u32 j0 = cs; j0 < ce; j0 += 64u) {
     const u32 j = j0 + lane;
     const bool ok = j < ce;
@@ -903,6 +905,7 @@ __device__ void wave_finish_chunk(batch_lds *B, u32 cs, u32 ce, bool need_sort, 
       if (idx == 0u) meta->bwt_idx = lo + j;
     }
     const u64 mask = __ballot(td);
+    nlong += (u32)__popcll(__ballot(td && (u32)B->gend[head] - head > BIG_RUN));
     if (td) {
       const u32 o = lbase + (u32)__popcll(mask & lanes_below());
       ls.sufx[o] = SA_ENTRY(idx, v >> 24);
@@ -911,7 +914,7 @@ __device__ void wave_finish_chunk(batch_lds *B, u32 cs, u32 ce, bool need_sort, 
     }
     lbase += (u32)__popcll(mask);
   }
-  if (ntied && lane == 0u) atomicMin(&S->lmin, depth);
+  if (ntied && lane == 0u) { atomicMin(&S->lmin, depth); if (nlong) atomicAdd(&S->bc[9], nlong); }
   if (lane == 0u) {
     const u64 tw2 = wall_clock64();
     atomicAdd(&S->bc[13], (u32)(tw2 - tw0));
@@ -1131,69 +1134,57 @@ __device__ u32 find_run_end(const K *keys, u32 pos, u32 from, u32 hi, u32 sh, bw
   return b < hi ? b : hi;
 }
 
+/* rows [lo,hi) share one 64-bit key and are more than a batch, but few enough for one wave of k_bwt_deep to take apart
+ * symbol by symbol (deep_big_run): they join the segment's list as one run */
+#ifndef LONG_RUN_MAX
+#define LONG_RUN_MAX 4096u
+#endif
+__device__ void list_tied_rows(u8 *bwt, bwt_slot s, bwt_lds *S, u32 lo, u32 hi, lbz_block_meta *meta, u32 depth)
+{
+  if (threadIdx.x == 0) { S->bc[1] = atomicAdd(&S->listn, hi - lo); atomicMin(&S->lmin, depth); S->bc[9] += hi - lo; }
+  __syncthreads();
+  const u32 base = S->bc[1];
+  const bwt_slot ls = seg_view(s, S->seglo);
+  for (u32 j = lo + threadIdx.x; j < hi; j += LBZ_WG) {
+    const u32 v = s.v0[j];
+    const u32 e = SA_ENTRY(v & 0x00FFFFFFu, v >> 24);
+    bwt[j] = S->inv[v >> 24];
+    s.sa[j] = e | (j > lo ? TIE_FLAG : 0u);
+    if ((v & 0x00FFFFFFu) == 0u) meta->bwt_idx = j;
+    ls.sufx[base + (j - lo)] = e; ls.grp[base + (j - lo)] = lo; ls.pos[base + (j - lo)] = depth;
+  }
+  __syncthreads();
+}
+
 /* An oversized group [lo,hi) (> BATCH_CAP rows with equal top MSD_BITS): HBM radix sort on the remaining key bits, then
  * batches cut at key boundaries.  A run of more than a batch of EQUAL keys (" of the ": thousands of rows of a text
- * block) trades its keys for the next sy symbols of its rotations and is sorted again the same way -- a frame on a
- * small stack: the rows of the frame, the symbols they are known to share -- up to BIG_LEVELS deep; what is still
- * more than a batch of equal keys then (long runs of one or two byte values: "abababab") is left to the rank rounds. */
-#ifndef BIG_LEVELS
-#define BIG_LEVELS 4u
-#endif
+ * block) goes to the text rounds' list as it is; beyond LONG_RUN_MAX rows (long runs of one or two byte values,
+ * "abababab") to the rank rounds.                                                                                   */
 __device__ void big_group(const u8 *T, u32 n, u8 *bwt, lbz_block_meta *meta, bwt_slot s,
                           bwt_lds *S, keycfg c, u32 lo, u32 hi)
 {
   const u32 tid = threadIdx.x;
-  u32 fhi[BIG_LEVELS + 1u], fdepth[BIG_LEVELS + 1u];
-  u32 lev = 0, pos = lo;
-  fhi[0] = hi; fdepth[0] = c.sy;
-  bool fresh = true;                                   /* rows [pos, fhi[lev]) have new keys: sort them */
-  u32 nbits = S->msd_shift;
-  for (;;) {
-    if (pos >= fhi[lev]) {
-      if (lev == 0u) break;
-      lev--;
-      continue;
-    }
-    if (fresh) {
-      const u32 m = fhi[lev] - pos;
-      const u32 which = wg_radix_sort(s.k0 + pos, s.v0 + pos, s.k1 + pos, s.v1 + pos, m, nbits, S);
-      if (which) {
-        for (u32 i = tid; i < m; i += LBZ_WG) { s.k0[pos + i] = s.k1[pos + i]; s.v0[pos + i] = s.v1[pos + i]; }
-        __syncthreads();
-      }
-      fresh = false;
-    }
-    const u32 top = fhi[lev];
-    u32 e = pos + BATCH_CAP < top ? pos + BATCH_CAP : top;
-    if (e < top) {
+  const u32 m = hi - lo;
+  const u32 which = wg_radix_sort(s.k0 + lo, s.v0 + lo, s.k1 + lo, s.v1 + lo, m, S->msd_shift, S);
+  if (which) {
+    for (u32 i = tid; i < m; i += LBZ_WG) { s.k0[lo + i] = s.k1[lo + i]; s.v0[lo + i] = s.v1[lo + i]; }
+    __syncthreads();
+  }
+  u32 pos = lo;
+  while (pos < hi) {
+    u32 e = pos + BATCH_CAP < hi ? pos + BATCH_CAP : hi;
+    if (e < hi) {
       const u32 cut = find_cut(s.k0, pos, e, 0u, S);
       if (!cut) {
-        /* a run of > BATCH_CAP equal keys */
-        const u32 end = find_run_end(s.k0, pos, e, top, 0u, S);
-        const u32 depth = fdepth[lev];
-        if (lev < BIG_LEVELS && depth + c.sy < n) {
-          __syncthreads();
-          for (u32 i = pos + tid; i < end; i += LBZ_WG) {
-            u32 t = (s.v0[i] & 0x00FFFFFFu) + depth;
-            if (t >= n) t -= n;
-            s.k0[i] = key_from_text(T, n, t, S->cmap, c);
-          }
-          __syncthreads();
-          lev++;
-          fhi[lev] = end; fdepth[lev] = depth + c.sy;
-#ifdef DEEP_DEBUG
-          if (tid == 0) printf("  push lev %u [%u,%u) depth %u (group [%u,%u))\n", lev, pos, end, fdepth[lev], lo, hi);
-#endif
-          fresh = true; nbits = 64u;
-          continue;
-        }
-        emit_tied_rows(bwt, s, S, pos, end, meta, depth);
+        const u32 end = find_run_end(s.k0, pos, e, hi, 0u, S);
+        if (end - pos <= LONG_RUN_MAX) list_tied_rows(bwt, s, S, pos, end, meta, c.sy);
+        else emit_tied_rows(bwt, s, S, pos, end, meta, c.sy);
         pos = end;
         continue;
       }
       e = cut;
     }
-    batch_process(T, n, bwt, meta, s, S, c, pos, e - pos, true, false, false, fdepth[lev]);
+    batch_process(T, n, bwt, meta, s, S, c, pos, e - pos, true, false);
     pos = e;
   }
 }
@@ -1384,7 +1375,7 @@ __device__ __forceinline__ void part_block(bwt_lds &S, const u8 *Tbase, lbz_bloc
   const u32 n = meta[blk].n;
   if (tid == 0) {                             /* the sorter's part of the block record: the segment workgroups add to it */
     lbz_block_meta *M = &meta[blk];
-    M->periodic = 0; M->rounds = 0; M->sort_elems = 0; M->deep_rows = 0; M->nseg = 0; M->deep_h0 = 0xFFFFFFFFu; M->deep_skip = 0;
+    M->periodic = 0; M->rounds = 0; M->sort_elems = 0; M->deep_rows = 0; M->nseg = 0; M->deep_h0 = 0xFFFFFFFFu; M->deep_skip = 0; M->deep_long = 0;
     for (u32 i = 0; i <= LBZ_DEEP_ROUNDS; i++) { M->deep_tot[i] = 0; M->deep_hmin[i] = 0xFFFFFFFFu; }
     M->msd_bits = MSD_BITS;
     for (u32 i = 0; i < 8u; i++) M->ticks[i] = 0;
@@ -1541,6 +1532,7 @@ k_bwt_batch(const u8 *Tbase, u8 *Bbase, lbz_block_meta *meta, lbz_layout L, u32 
     if (S.bc[8]) { atomicMax(&M->periodic, 2u); atomicMin(&M->deep_h0, S.h0min); M->deep_skip = 1u; }  /* 2 = ties left for the rank rounds: long runs BIG_ROUNDS did not split */
     M->seg_m[seg] = S.listn;                   /* short runs: the text rounds' list */
     if (S.listn) { atomicAdd(&M->deep_tot[0], S.listn); atomicMin(&M->deep_hmin[0], S.lmin); }
+    if (S.bc[9]) atomicAdd(&M->deep_long, S.bc[9]);
     atomicAdd(&M->deep_rows, S.listn);
     atomicAdd(&M->sort_elems, hi - lo);
     /* diagnostics, summed over the block's segments (tests/tools/quickperf.py) */
@@ -1694,7 +1686,7 @@ __device__ void deep_big_run(deep_wave *W, u32 lane, u32 p, u32 g, deep_lists Ls
   for (;;) {
     const u32 sp = W->sp;
     if (sp == 0u) break;
-    const u32 off = W->st_off[sp - 1u], len = W->st_len[sp - 1u], buf = W->st_buf[sp - 1u];
+    const u32 off = W->st_off[sp - 1u], len = W->st_len[sp - 1u], buf = W->st_buf[sp - 1u] & 1u, level = W->st_buf[sp - 1u] >> 1;
     u32 d = W->st_dep[sp - 1u];
     wave_sync();
     if (lane == 0u) W->sp = sp - 1u;
@@ -1724,9 +1716,10 @@ __device__ void deep_big_run(deep_wave *W, u32 lane, u32 p, u32 g, deep_lists Ls
       d += lc;
       if (lc < 16u) { split = true; break; }
     }
-    if (!split || d >= n || sp + 16u > DEEP_STACK) {
-      /* nothing to split on yet (64 more symbols shared, or tied all the way round), or no room on the stack: the piece
-         goes on as it is, deeper */
+    if (!split || d >= n || level >= DEEP_LEVELS) {
+      /* nothing to split on yet (64 more symbols shared, or tied all the way round), or enough for one launch (a run that
+         sheds a few rows with every symbol -- counters, tables -- would keep its wave for as many passes as it is deep):
+         the piece goes on as it is, deeper */
       const u32 ob = wave_reserve(outn, len);
       for (u32 k = lane; k < len; k += 64u) {
         const u32 val = src[k];
@@ -1757,11 +1750,18 @@ __device__ void deep_big_run(deep_wave *W, u32 lane, u32 p, u32 g, deep_lists Ls
     u32 shorttot;
     {
       u32 c[4], t[4];
+      bool pushed[4];
       u32 sum = 0, tsum = 0;
 #pragma unroll
       for (u32 q = 0; q < 4u; q++) {
         c[q] = W->cnt[4u * lane + q];
-        t[q] = (c[q] > 1u && c[q] <= BIG_RUN) ? c[q] : 0u;
+        pushed[q] = false;
+        if (c[q] > BIG_RUN) {                           /* a piece again, if the stack has room: else it goes to the next list as a long run */
+          const u32 at = atomicAdd(&W->sp, 1u);
+          pushed[q] = at < DEEP_STACK;
+          if (pushed[q]) { W->st_len[at] = c[q]; W->st_dep[at] = d + 1u; W->st_buf[at] = (buf ^ 1u) | ((level + 1u) << 1); W->st_off[at] = 4u * lane + q; /* the value: its offset follows */ }
+        }
+        t[q] = (c[q] > 1u && !pushed[q]) ? c[q] : 0u;
         sum += c[q]; tsum += t[q];
       }
       const u32 tin = wave_incl_add(tsum);
@@ -1769,13 +1769,19 @@ __device__ void deep_big_run(deep_wave *W, u32 lane, u32 p, u32 g, deep_lists Ls
       shorttot = (u32)__builtin_amdgcn_readlane((int)tin, 63);
 #pragma unroll
       for (u32 q = 0; q < 4u; q++) {
-        W->base[4u * lane + q] = (u16)ex; W->obase[4u * lane + q] = (u16)tex;
-        if (c[q] > BIG_RUN) {                           /* a piece again: at most len / 64 <= 16 of them */
-          const u32 at = atomicAdd(&W->sp, 1u);
-          W->st_off[at] = off + ex; W->st_len[at] = c[q]; W->st_dep[at] = d + 1u; W->st_buf[at] = buf ^ 1u;
-        }
+        W->base[4u * lane + q] = (u16)ex;
+        W->obase[4u * lane + q] = pushed[q] ? (u16)0xFFFFu : (u16)tex;
         ex += c[q]; tex += t[q];
       }
+    }
+    wave_sync();
+    {
+      /* the pieces' offsets: the stack entries above this piece's own hold the value they were made for */
+      u32 top = W->sp;
+      top = top < DEEP_STACK ? top : DEEP_STACK;
+      for (u32 i = sp - 1u + lane; i < top; i += 64u) W->st_off[i] = off + (u32)W->base[W->st_off[i]];
+      wave_sync();
+      if (lane == 0u) W->sp = top;
     }
     wave_sync();
     const u32 ob = shorttot ? wave_reserve(outn, shorttot) : 0u;
@@ -1797,7 +1803,7 @@ __device__ void deep_big_run(deep_wave *W, u32 lane, u32 p, u32 g, deep_lists Ls
           if (c == 1u) bwt[row] = inv[SA_CODE(val)];
           if (SA_IDX(val) == 0u) M->bwt_idx = row;
         }
-        if (c > BIG_RUN) {
+        if (W->obase[by] == 0xFFFFu) {
           dst[b0 + slot] = val;
         } else {
           if (c > 1u) {
@@ -1836,7 +1842,7 @@ k_bwt_deep(const u8 *Tbase, u8 *Bbase, lbz_block_meta *meta, lbz_layout L, u32 f
   /* ... and so does a block of which two fifths are still tied after the first launch (source trees, logs: repeats of
      hundreds of symbols under most rows).  Ranks double through those, but a run can only step by ranks if the rotations it
      looks up have entries, and giving every rotation one is what the rank rounds do.  Every segment decides the same.  */
-  if (M->deep_skip || (round == DEEP_HANDOVER && (u64)tot * 5ull > (u64)n * 2ull)) {
+  if (M->deep_skip || (u64)M->deep_long * 2ull > n || (round == DEEP_HANDOVER && (u64)tot * 5ull > (u64)n * 2ull)) {
     if (seg == 0u && threadIdx.x == 0u) {
       atomicMax(&M->periodic, 2u); atomicMin(&M->deep_h0, M->deep_hmin[round]);
     }
@@ -1962,15 +1968,51 @@ k_bwt_deep(const u8 *Tbase, u8 *Bbase, lbz_block_meta *meta, lbz_layout L, u32 f
             const bool fresh = ISA_TAG(e) == R.tag;
             s1 = (u64)isa_before(e, R.tag);
             k2 = (u64)(fresh ? R.hcur : (ISA_DEPTH(e) > R.hcur ? ISA_DEPTH(e) : R.hcur));      /* travels with the row */
-          } else if (useT) {
-            const u64x2 x = deep_load16(T, n, SA_IDX(val), d);
-            const u64 hi = __builtin_bswap64(x.x), lw = __builtin_bswap64(x.y);
-            s1 = hi >> 12;
-            k2 = ((hi & 0xFFFull) << 40) | (lw >> 24);
           }
+          bool tsort = useT;                            /* the text runs take a slice of their next 16 bytes -- unless all agree on them */
+          if (__ballot(useT)) {
+            const bool mate = useT && hl != lane;
+            u64 xa = 0, xb = 0;
+            if (longmode && !__ballot(useT && (at + 64u > n || d + 64u > n))) {
+              u64 ya[4], yb[4];
+#pragma unroll
+              for (u32 q = 0; q < 4u; q++) {
+                ya[q] = 0; yb[q] = 0;
+                if (useT) { const lbz_text16 *t16 = reinterpret_cast<const lbz_text16 *>(T + at + 16u * q); ya[q] = t16->a; yb[q] = t16->b; }
+              }
+              u32 same = 0;
+#pragma unroll
+              for (u32 q = 0; q < 4u; q++) {
+                const u64 a0 = (u64)lane_from_below((u32)ya[q]) | (u64)lane_from_below((u32)(ya[q] >> 32)) << 32;
+                const u64 b0 = (u64)lane_from_below((u32)yb[q]) | (u64)lane_from_below((u32)(yb[q] >> 32)) << 32;
+                const bool differs = mate && (a0 != ya[q] || b0 != yb[q]);
+                if (same == q && !__ballot(differs)) same = q + 1u;
+              }
+              if (useT) d += 16u * same;
+              if (same == 4u) tsort = false;
+              xa = same == 0u ? ya[0] : (same == 1u ? ya[1] : (same == 2u ? ya[2] : ya[3]));
+              xb = same == 0u ? yb[0] : (same == 1u ? yb[1] : (same == 2u ? yb[2] : yb[3]));
+              longmode = same != 0u;
+            } else {
+              if (useT) { const u64x2 x = deep_load16(T, n, SA_IDX(val), d); xa = x.x; xb = x.y; }
+              const u64 a0 = (u64)lane_from_below((u32)xa) | (u64)lane_from_below((u32)(xa >> 32)) << 32;
+              const u64 b0 = (u64)lane_from_below((u32)xb) | (u64)lane_from_below((u32)(xb >> 32)) << 32;
+              if (!__ballot(mate && (a0 != xa || b0 != xb))) {
+                if (useT) d += 16u;
+                longmode = true;
+                tsort = false;
+              }
+            }
+            if (tsort) {
+              const u64 hi = __builtin_bswap64(xa), lw = __builtin_bswap64(xb);
+              s1 = hi >> 12;
+              k2 = ((hi & 0xFFFull) << 40) | (lw >> 24);
+            }
+          }
+          if (!__ballot(useR || tsort)) continue;       /* every run agreed on its text: nothing to order */
           deep_stage(W, lane, cut, s1, val, k2, hl, tied);
-          if (__ballot(tied && useT))                   /* useR, useT belong to the place: runs only split */
-            deep_stage(W, lane, cut, useT ? k2 : 0ull, val, k2, hl, tied);
+          if (__ballot(tied && tsort))                  /* useR, tsort belong to the place: runs only split */
+            deep_stage(W, lane, cut, tsort ? k2 : 0ull, val, k2, hl, tied);
           /* rows that stay tied after a rank step looked up rotations of ONE run: either's note of its depth is a lower
              bound of that run's */
           W->val[lane] = (u32)k2;
@@ -1978,7 +2020,7 @@ k_bwt_deep(const u8 *Tbase, u8 *Bbase, lbz_block_meta *meta, lbz_layout L, u32 f
           const u32 dh = W->val[hl];
           wave_sync();
           if (useR) d = d + dh < n ? d + dh : n;
-          else if (useT) d += DEEP_STEP;
+          else if (tsort) d += DEEP_STEP;
           continue;
         }
         const bool can = tied && d + 16u <= n;          /* d + 16 > n: tied nearly all the way round (tiny or periodic blocks) */

@@ -70,6 +70,7 @@ typedef struct lbz_block_meta {
   uint32_t msd_bits;    /* key bits the block was partitioned on in HBM (k_bwt_part decides: 32, or 16 for incompressible data) */
   uint32_t deep_h0;     /* depth every tie that is left for the rank rounds (k_bwt_fix*) is known to reach: they double from here.
                            0xFFFFFFFF while nothing is left (k_bwt_batch and the last k_bwt_deep launch lower it) */
+  uint32_t deep_long;   /* tied rows of the block in runs of more than 63 (k_bwt_batch counts them): a block that is mostly such runs skips the text rounds */
   uint32_t deep_skip;   /* k_bwt_batch left long runs tied (BIG_ROUNDS refinements did not split them): the block goes to the rank rounds as it is */
   uint32_t deep_tot[LBZ_DEEP_ROUNDS + 1];   /* tied rows of the block that enter text round r (its segments' lists together); [LBZ_DEEP_ROUNDS]: left over */
   uint32_t deep_hmin[LBZ_DEEP_ROUNDS + 1];  /* ... and the least depth any of them is known to share */
