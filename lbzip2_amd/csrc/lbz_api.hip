@@ -108,6 +108,28 @@ static int ctx_free(lbzamd_ctx *c)
 
 extern "C" void lbzamd_destroy(lbzamd_ctx *c) { ctx_free(c); }
 
+/* Devices as the callers count them.  LBZAMD_FAKE_DEVICES=N shows N logical devices whatever the box holds, logical device
+ * i living on physical device i mod (devices present): every N > 1 branch of the host side -- contexts dealt over devices
+ * (lbzamd_compress -g), one work-unit pool per device (LBZAMD_DEVICES), lbzamd_device_count -- runs on the real kernels
+ * of a one-GPU box that way (tests/test_gpu_parity.py: test_n_devices_on_one_gpu).  Unset: the devices present.   */
+static int physical_devices()
+{
+  int n = 0;
+  return hipGetDeviceCount(&n) == hipSuccess ? n : 0;
+}
+static int logical_devices()
+{
+  const int have = physical_devices();
+  const char *env = getenv("LBZAMD_FAKE_DEVICES");
+  const int fake = env ? atoi(env) : 0;
+  return have < 1 ? 0 : (fake > 0 ? (fake > 64 ? 64 : fake) : have);
+}
+static int physical_of(int logical)
+{
+  const int have = physical_devices();
+  return have > 0 ? logical % have : 0;
+}
+
 static int ctx_create(lbzamd_ctx **out, int device, unsigned bs100k, unsigned max_slabs, unsigned nslots, unsigned force_streams);
 
 extern "C" int lbzamd_create(lbzamd_ctx **out, int device, unsigned bs100k, unsigned max_slabs, unsigned nslots)
@@ -120,10 +142,11 @@ extern "C" int lbzamd_create(lbzamd_ctx **out, int device, unsigned bs100k, unsi
 static int ctx_create(lbzamd_ctx **out, int device, unsigned bs100k, unsigned max_slabs, unsigned nslots, unsigned force_streams)
 {
   if (!out || bs100k < 1 || bs100k > 9 || max_slabs < 1) { g_err = "lbzamd_create: bad argument"; return -1; }
-  int ndev = 0;
-  HIPCHK(hipGetDeviceCount(&ndev));
+  const int ndev = logical_devices();
   if (ndev < 1) { g_err = "lbzamd_create: no HIP device (this library has no CPU path)"; return -1; }
   if (device < 0) HIPCHK(hipGetDevice(&device));
+  if (device >= ndev) { g_err = "lbzamd_create: no such device"; return -1; }
+  device = physical_of(device);                  /* from here on the physical device (LBZAMD_FAKE_DEVICES) */
   HIPCHK(hipSetDevice(device));
   hipDeviceProp_t prop;
   HIPCHK(hipGetDeviceProperties(&prop, device));
@@ -683,8 +706,7 @@ extern "C" void *lbzamd_pinned_alloc(size_t bytes)
 }
 extern "C" int lbzamd_device_count(void)
 {
-  int n = 0;
-  return hipGetDeviceCount(&n) == hipSuccess ? n : 0;
+  return logical_devices();
 }
 extern "C" void lbzamd_pinned_free(void *p) { if (p) (void)hipHostFree(p); }
 
@@ -779,10 +801,11 @@ extern "C" void lbzamd_ddestroy(lbzamd_dctx *c)
 extern "C" int lbzamd_dcreate(lbzamd_dctx **out, int device, unsigned max_blocks)
 {
   if (!out || max_blocks < 1) { g_err = "lbzamd_dcreate: bad argument"; return -1; }
-  int ndev = 0;
-  HIPCHK(hipGetDeviceCount(&ndev));
+  const int ndev = logical_devices();
   if (ndev < 1) { g_err = "lbzamd_dcreate: no HIP device (this library has no CPU path)"; return -1; }
   if (device < 0) HIPCHK(hipGetDevice(&device));
+  if (device >= ndev) { g_err = "lbzamd_dcreate: no such device"; return -1; }
+  device = physical_of(device);
   HIPCHK(hipSetDevice(device));
   lbzamd_dctx *c = new lbzamd_dctx;
   c->device = device;
@@ -1170,8 +1193,8 @@ static wu_pool *pool_for(unsigned bs100k)
     std::lock_guard<std::mutex> lk(g_pools_mu);
     if (!g_pool_devs) {
       const char *env = getenv("LBZAMD_DEVICES");
-      int have = 0;
-      if (hipGetDeviceCount(&have) != hipSuccess || have < 1) { g_err = "no HIP device (this library has no CPU path)"; die("work-unit pool"); }
+      const int have = logical_devices();
+      if (have < 1) { g_err = "no HIP device (this library has no CPU path)"; die("work-unit pool"); }
       int want = env ? (!strcmp(env, "all") ? have : atoi(env)) : 1;
       if (want < 1) want = 1;
       if (want > have) want = have;
@@ -1191,7 +1214,9 @@ static wu_pool *pool_on(int device, unsigned bs100k)
   if (g_pools[device][bs100k]) return g_pools[device][bs100k];
   wu_pool *p = new wu_pool;
   const char *env = getenv("LBZAMD_POOL_SLABS");
-  p->P = env ? (uint32_t)atoi(env) : 1024u;
+  p->P = env ? (uint32_t)atoi(env) : 256u;      /* states in flight per pool: 256 slabs are 16 GB of HBM and 0.5 GB of page-locked memory at -9
+                                                   (1024, the default until round 4: 35 GB and 2 GB on the first collect() whatever the number of
+                                                   threads); callers beyond that wait for a slab */
   if (p->P < 1u) p->P = 1u;
   /* one slot set: encode rounds run one at a time, up to 512 blocks (two per CU) each */
   if (ctx_create(&p->c, device, bs100k, p->P, p->P < 512u ? p->P : 512u, 1u)) die("cannot create the work-unit pool");

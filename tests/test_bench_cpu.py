@@ -51,3 +51,25 @@ def test_reference_driver_equals_single_thread_driver():
         assert a == L.ref_compress(data, 1)
         assert a == L.orc_compress_mt(data, 1, 3)[0]
     assert L.orc_compress_mt(data, 1, 2)[0] == L.orc_compress(data, 1)
+
+
+def test_real_file_leg_input():
+    """bench.py's real-data legs compress a tar built from files of the image: the same bytes every time it is built
+    (sorted members, zeroed owner and time), a valid archive, cut at the size asked for, no member twice."""
+    import io
+    import tarfile
+    roots, suf = ["/usr/lib/python3.10", "/usr/lib/python3"], (".py",)
+    a = bench.real_tar(3_000_000, roots, suf)
+    if a is None:
+        import pytest
+        pytest.skip("the file set is not in this container")
+    b = bench.real_tar(3_000_000, roots, suf)
+    assert a[1:] == b[1:] and bytes(a[0]) == bytes(b[0]) and len(a[0]) == 3_000_000
+    names = []
+    with tarfile.open(fileobj=io.BytesIO(bytes(a[0]) + bytes(1024)), mode="r:") as tf:      # (cut mid-member: pad so that the reader ends cleanly)
+        try:
+            for m in tf:
+                names.append(m.name)
+        except (tarfile.ReadError, EOFError):
+            pass
+    assert len(names) >= a[1] - 1 and len(set(names)) == len(names) and names == sorted(names)

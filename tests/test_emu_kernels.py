@@ -171,6 +171,12 @@ def test_c_side_multi_device(emu, tmp_path):
     r = subprocess.run([exe, "-1", "-f", str(src), "-o", str(dst), "-g", "2"], env=dict(os.environ, LBZ_EMU_DEVICES="1"),
                        capture_output=True, timeout=900)
     assert r.returncode == 0 and dst.read_bytes() == want           # more devices asked for than there are: clamped
+    # LBZAMD_FAKE_DEVICES: two logical devices on the ONE device present (what the GPU suite uses on its one-GPU box)
+    one = dict(os.environ, LBZ_EMU_DEVICES="1", LBZAMD_FAKE_DEVICES="2")
+    r = subprocess.run([exe, "-1", "-f", str(src), "-o", str(dst), "-c", "2", "-p", "1", "-g", "2", "-t"], env=one, capture_output=True, timeout=900)
+    assert r.returncode == 0 and dst.read_bytes() == want and b"on 2 device(s)" in r.stderr, r.stderr[-300:]
+    r = subprocess.run([exe, "-1", "-w", "4"], input=data, env=dict(one, LBZAMD_DEVICES="2", LBZAMD_POOL_SLABS="3"), capture_output=True, timeout=900)
+    assert r.returncode == 0 and r.stdout == want, r.stderr[-400:]
 
 
 def test_oversized_runs_at_segment_bounds(emu):

@@ -284,6 +284,74 @@ def test_c_side_multi_gpu(lib, tmp_path):
     assert len(p.stdout) == rec["out_len"] and hashlib.md5(p.stdout).hexdigest() == rec["ref_md5"]
 
 
+def test_n_devices_on_one_gpu(lib, tmp_path):
+    """N > 1 on the real kernels of a ONE-GPU box: LBZAMD_FAKE_DEVICES=2 shows two logical devices (both on the device
+    present), so that `lbzamd_compress -g 2 -p 2` deals its pipelines' contexts over two devices and LBZAMD_DEVICES=2
+    keeps two work-unit pools with their own leaders, streams and staging behind the reference's five symbols.  Both
+    must write the reference's stream.  (With the emulator the same branches run on fake devices: test_emu_kernels.py.)"""
+    import hashlib
+    import subprocess
+    exe = os.path.join(os.path.dirname(lib.path), "..", "host", "lbzamd_compress")
+    if not os.path.exists(exe):
+        pytest.skip("C driver not built")
+    assert lib.lib.lbzamd_device_count() >= 1
+    rec = [r for r in bench_fixtures() if r["kind"] == "tar" and r["n"] == 175_000_000][0]
+    data = bytes(gen(rec["kind"], rec["n"], rec["seed"]))
+    src, dst = tmp_path / "tar.bin", tmp_path / "tar.bz2"
+    src.write_bytes(data)
+    env = dict(os.environ, LD_LIBRARY_PATH="/opt/rocm/lib:" + os.environ.get("LD_LIBRARY_PATH", ""), LBZAMD_FAKE_DEVICES="2")
+    p = subprocess.run([exe, "-9", "-f", str(src), "-o", str(dst), "-c", "48", "-p", "2", "-g", "2", "-t"], capture_output=True, env=env, timeout=300)
+    assert p.returncode == 0 and b"2 device(s)" in p.stderr, p.stderr[-500:]
+    out = dst.read_bytes()
+    assert len(out) == rec["out_len"] and hashlib.md5(out).hexdigest() == rec["ref_md5"]
+    p = subprocess.run([exe, "-9", "-w", "64"], input=data, capture_output=True,
+                       env=dict(env, LBZAMD_DEVICES="2", LBZAMD_POOL_SLABS="48"), timeout=300)
+    assert p.returncode == 0, p.stderr[-500:]
+    assert len(p.stdout) == rec["out_len"] and hashlib.md5(p.stdout).hexdigest() == rec["ref_md5"]
+
+
+GLOO_WORKER = r'''
+import os, sys, hashlib
+sys.path.insert(0, {root!r}); sys.path.insert(0, os.path.join({root!r}, "tests"))
+import torch, torch.distributed as dist
+import lbzip2_amd
+from lbzip2_amd.shard import compress_sharded
+from golden_util import gen, bench_fixtures
+dist.init_process_group("gloo")
+rank, world = dist.get_rank(), dist.get_world_size()
+torch.cuda.set_device(0)
+lib = lbzip2_amd.library()                      # the product library: HIP kernels on cuda:0 in every rank
+rec = [r for r in bench_fixtures() if r["kind"] == "wiki" and r["n"] == 100_000_000][0]
+data = bytes(gen(rec["kind"], rec["n"], rec["seed"]))
+whole = compress_sharded(lib, data, rec["level"], dist, "cpu")      # bodies leave the device, gloo carries them
+if rank == 0:
+    assert len(whole) == rec["out_len"] and hashlib.md5(whole).hexdigest() == rec["ref_md5"], (len(whole), rec["out_len"])
+    print("GLOO_MUX_OK", world, len(whole))
+dist.barrier()
+dist.destroy_process_group()
+'''
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_stream_mux_over_gloo_on_the_real_kernels(tmp_path, world):
+    """lbzip2_amd.shard.StreamMux with `world` ranks whose compressors are the HIP kernels (all on the one GPU of the test
+    box): slab ranges of wiki(10^8) -> body-only bytes + 12-byte CRC partials -> ONE stream on rank 0, which must be the
+    reference's.  The transport is gloo (RCCL does not take two ranks on one device: test_rccl_leg_of_the_stream_mux);
+    everything else -- shard_plan, lbzamd_compress_*_body on the GPU, the fold of the partials, header and trailer -- is
+    the code bench.py --scaling strong runs."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / "worker.py"
+    script.write_text(GLOO_WORKER.format(root=root))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}",
+                          "--master-addr", "127.0.0.1", "--master-port", str(29641 + world), str(script)],
+                         env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    assert "GLOO_MUX_OK" in out.stdout
+
+
 def test_rccl_leg_of_the_stream_mux(tmp_path):
     """lbzip2_amd.shard.StreamMux over RCCL (all_gather of the partials, grouped send/recv of the bodies between device
     buffers): two ranks of `bench.py --scaling strong`.  The test box has ONE GPU; RCCL may refuse two ranks on one
