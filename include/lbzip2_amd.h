@@ -90,10 +90,11 @@ typedef struct lbzamd_stats {
   uint32_t nblocks;
   uint32_t nperiodic;   /* exactly periodic blocks (origin pointer = smallest equal row) */
   /* Device time from HIP events.  ms_total is wall time on the context's stream.  The per-kernel
-     figures are sums over launches on the stream each launch went to; rounds of blocks run on two
+     figures are sums over launches on the stream each launch went to; rounds of blocks run on three
      streams, so launches overlap and the sums exceed ms_total (LBZAMD_STREAMS=1: no overlap). */
   float ms_collect, ms_bwt, ms_mtf, ms_encode, ms_finish, ms_total;
-  float ms_bwt_part, ms_bwt_batch, ms_bwt_fix;   /* the BWT stage's three kernels (sum = ms_bwt) */
+  float ms_bwt_part, ms_bwt_batch, ms_bwt_fix;   /* the BWT stage's launches: partition, batches, ties (k_bwt_deep's text rounds + the
+                                                    rank rounds k_bwt_fix0 / k_bwt_fixr / k_bwt_fixend); sum = ms_bwt */
   uint32_t seq_fast_links;   /* sequential mode: blocks whose start was found through the step tables (the others walked) */
 } lbzamd_stats;
 
@@ -101,18 +102,17 @@ typedef struct lbzamd_stats {
  * streamed through in chunks).  nslots: slabs per round (a round = one launch of every kernel,
  * one workgroup per block; each round owns one BWT workspace slot per slab); 0 = max_slabs dealt
  * evenly over the streams, at least one per CU, at most half of the free device memory.
- * Environment: LBZAMD_STREAMS (1..8, default 2), LBZAMD_SLOTS (default for nslots = 0).        */
+ * Environment: LBZAMD_STREAMS (1..8, default 3), LBZAMD_SLOTS (default for nslots = 0).        */
 int  lbzamd_create(lbzamd_ctx **ctx, int device, unsigned bs100k, unsigned max_slabs, unsigned nslots);
 void lbzamd_destroy(lbzamd_ctx *ctx);
 const char *lbzamd_last_error(void);
 
 /* d_in/d_out are device pointers.  Writes a complete .bz2 stream; *out_len = its size.
  * Work is enqueued on the context's stream and waited for.  0 on success.
- * Alignment: none required, but the kernels read whole 16-byte vectors (the decoder: 4-byte words) around the
- * buffer's ends -- up to 15 bytes in front of d_in and up to 15 behind d_in + len may be READ (their values are
- * masked out, nothing outside [d_out, d_out + out_cap) is written).  Base pointers of hipMalloc / torch allocations
- * satisfy this by themselves; a pointer into the middle of an allocation does too; one that ends exactly at the last
- * byte of an allocation next to an unmapped page does not -- leave 16 bytes of slack there.                          */
+ * Alignment: none required.  The kernels read aligned 16-byte vectors (the decoder: aligned 4- and 8-byte words); the only
+ * bytes outside [d_in, d_in + len) they ever touch lie in the aligned vector that holds the buffer's first or its last
+ * byte -- in one page with a byte of the buffer, so no access can fault whatever lies behind the allocation -- and are
+ * masked out.  Nothing outside [d_out, d_out + out_cap) is written.                                                  */
 /* The reference's -u / --sequential (main.c; compress.c:129-198 do_collect_seq): with on != 0 the context's
  * following calls cut blocks where they are FULL (a continuous RLE1 over the input, bzip2's own blocking) instead
  * of at every bs100k * 100000 input bytes; the stream is byte-identical to `lbzip2 -u`.  A block's start is known

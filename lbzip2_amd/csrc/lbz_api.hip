@@ -955,6 +955,7 @@ extern "C" int lbzamd_decompress_device(lbzamd_dctx *c, const void *d_in_v, size
     }
     /* the walk: marks in stream order, up to the last candidate of this batch */
     const bool last_batch = b0 + nb >= hb.size();
+    const uint64_t before = total;                             /* bytes the earlier passes have put in place */
     for (; mi < marks.size(); mi++) {
       const long ci = cand_of[mi];
       if (ci >= (long)(b0 + nb)) break;                     /* not decoded yet */
@@ -998,7 +999,8 @@ extern "C" int lbzamd_decompress_device(lbzamd_dctx *c, const void *d_in_v, size
     if (c->grow_out && nb && total > out_cap) {
       /* the size is known only now (the blocks of this pass are decoded, their bytes not yet in place): a larger buffer,
          sized for the passes still to come as the blocks so far suggest, keeps what the earlier passes have written */
-      const uint64_t prev = hb[b0].out_off;
+      const uint64_t prev = before;                           /* (not hb[b0].out_off: the batch's first candidate may be off the chain -- a
+                                                                  magic inside a payload -- and never get an offset) */
       uint64_t want = total + total / 16u + 4096u;
       if (b0 + nb < hb.size()) want = (uint64_t)((double)total * (double)hb.size() / (double)(b0 + nb) * 1.0625) + 4096u;
       u8 *bigger = nullptr;
