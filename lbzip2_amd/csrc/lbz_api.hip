@@ -335,10 +335,14 @@ static int run_chunk(lbzamd_ctx *c, const u8 *d_in, size_t len, uint32_t nsl, in
     if (fin) {
       uint32_t at = 0;
       if (host_in && nsl > 4u * head && nsl > c->nslots) {
-        if (!c->head_q) HIPCHK(hipStreamCreate(&c->head_q));
-        if (!c->head_ev) HIPCHK(hipEventCreateWithFlags(&c->head_ev, hipEventDisableTiming));
-        if (!c->ws_head) HIPCHK(hipMalloc((void **)&c->ws_head, (size_t)head * (c->slot_bytes + c->spill_bytes)));
-        plan.push_back({ 0u, head }); at = head; has_head = true;
+        /* the head round's lane and workspaces (5 GB at -9, outside the budget that sized the slots): without them -- a
+           small or busy device -- the call simply has no head round */
+        bool ok = true;
+        if (!c->head_q) ok = hipStreamCreate(&c->head_q) == hipSuccess;
+        if (ok && !c->head_ev) ok = hipEventCreateWithFlags(&c->head_ev, hipEventDisableTiming) == hipSuccess;
+        if (ok && !c->ws_head) ok = hipMalloc((void **)&c->ws_head, (size_t)head * (c->slot_bytes + c->spill_bytes)) == hipSuccess;
+        if (ok) { plan.push_back({ 0u, head }); at = head; has_head = true; }
+        else (void)hipGetLastError();
       }
       const uint32_t rem = nsl - at, nr = (rem + c->nslots - 1u) / c->nslots, per = nr ? (rem + nr - 1u) / nr : 0u;
       for (uint32_t k = 0; k < nr; k++) {
@@ -358,6 +362,14 @@ static int run_chunk(lbzamd_ctx *c, const u8 *d_in, size_t len, uint32_t nsl, in
     const bool two = c->nstreams > 1 && nrounds > 1;
     if (two) for (unsigned k = 0; k + 1 < c->nstreams; k++) HIPCHK(hipStreamWaitEvent(c->side[k], c->ev[1], 0));
     if (has_head) HIPCHK(hipStreamWaitEvent(c->head_q, c->ev[1], 0));
+    bool pinned_in = true;
+    auto issue_copy = [&](uint32_t i) -> int {
+      const size_t o = (size_t)plan[i].first * c->L.M;
+      const size_t nb = (size_t)plan[i].second * c->L.M < len - o ? (size_t)plan[i].second * c->L.M : len - o;
+      HIPCHK(hipMemcpyAsync(const_cast<u8 *>(d_in) + o, c->h2d_host + (d_in - c->d_in) + o, nb, hipMemcpyHostToDevice, c->copy_q));
+      HIPCHK(hipEventRecord(c->cev[i], c->copy_q));
+      return 0;
+    };
     if (host_in) {
       if (!c->copy_q) HIPCHK(hipStreamCreate(&c->copy_q));
       while (c->cev.size() < nrounds) {
@@ -366,12 +378,15 @@ static int run_chunk(lbzamd_ctx *c, const u8 *d_in, size_t len, uint32_t nsl, in
         c->cev.push_back(e);
       }
       HIPCHK(hipStreamWaitEvent(c->copy_q, c->ev[1], 0));
-      for (uint32_t i = 0; i < nrounds; i++) {
-        const size_t o = (size_t)plan[i].first * c->L.M;
-        const size_t nb = (size_t)plan[i].second * c->L.M < len - o ? (size_t)plan[i].second * c->L.M : len - o;
-        HIPCHK(hipMemcpyAsync(const_cast<u8 *>(d_in) + o, c->h2d_host + (d_in - c->d_in) + o, nb, hipMemcpyHostToDevice, c->copy_q));
-        HIPCHK(hipEventRecord(c->cev[i], c->copy_q));
-      }
+      /* Page-locked input: every round's copy is issued now, in round order, on the one copy stream (copies on several
+         streams share the link and all arrive late).  Pageable input (bytes, numpy arrays): hipMemcpyAsync stages such a
+         copy and holds the calling thread until it is done, so a round's copy is issued next to the launches of the round
+         before it -- the device works on round i while round i + 1 crosses the link.                                 */
+      hipPointerAttribute_t pa;
+      pinned_in = hipPointerGetAttributes(&pa, c->h2d_host) == hipSuccess && pa.type == hipMemoryTypeHost;
+      if (!pinned_in) (void)hipGetLastError();
+      for (uint32_t i = 0; i < (pinned_in ? nrounds : (nrounds ? 1u : 0u)); i++)
+        if (issue_copy(i)) return -1;
     }
     while (fin && c->fev.size() < nrounds) {
       hipEvent_t e;
@@ -422,6 +437,7 @@ static int run_chunk(lbzamd_ctx *c, const u8 *d_in, size_t len, uint32_t nsl, in
                            (const lbz_block_meta *)(c->meta + 2u * (size_t)first), c->L, (const u64 *)(c->offs + 2u * (size_t)first),
                            (const lbz_stream_state *)c->st, fin->out, count);
       }
+      if (host_in && !pinned_in && i + 1u < nrounds && issue_copy(i + 1u)) return -1;
     }
     if (has_head) {
       HIPCHK(hipEventRecord(c->head_ev, c->head_q));
@@ -904,7 +920,10 @@ extern "C" int lbzamd_decompress_device(lbzamd_dctx *c, const void *d_in_v, size
       }
       lbz_dblock b{};
       b.bit_start = bit + 48;
-      b.max_block = lvl * 100000u;
+      b.max_block = 900000u;                /* the most a block may hold: which stream a candidate belongs to (a mark inside a payload
+                                               may have passed for a stream's end in front of it) is known only on the chain, where
+                                               the block's length is held against its stream's size */
+      (void)lvl;
       cand_of[i] = (long)hb.size();
       hb.push_back(b);
     }
@@ -982,7 +1001,7 @@ extern "C" int lbzamd_decompress_device(lbzamd_dctx *c, const void *d_in_v, size
         continue;
       }
       lbz_dblock &b = hb[ci];
-      if (b.max_block != level * 100000u) { g_err = "lbzamd_decompress: block decoded for another stream's block size (crafted input?)"; return -3; }
+      if (!b.err && b.nblock > level * 100000u) b.err = 8;     /* more bytes than the stream's block size allows (decode.c: the same check) */
       if (b.err) {
         char buf[128];
         snprintf(buf, sizeof buf, "lbzamd_decompress: block %u: %s (code %u)", nblocks, b.err == 11 ? "CRC mismatch" : "malformed block", b.err);

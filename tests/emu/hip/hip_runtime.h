@@ -166,6 +166,15 @@ template <class T> static inline hipError_t hipHostMalloc(T **p, size_t n, unsig
 static inline hipError_t hipHostFree(void *p) { free(p); return hipSuccess; }
 /* every emulated allocation is host memory; LBZ_EMU_NO_HOSTPTR makes the runtime take its staging path instead */
 static inline hipError_t hipHostGetDevicePointer(void **d, void *h, unsigned) { if (getenv("LBZ_EMU_NO_HOSTPTR")) return hipErrorInvalidValue; *d = h; return hipSuccess; }
+/* every host pointer counts as page-locked unless LBZ_EMU_PAGEABLE is set (the host-buffer calls then take the path of
+   pageable input: a round's copy issued next to the launches of the round before it) */
+enum hipMemoryType { hipMemoryTypeHost = 1, hipMemoryTypeDevice = 2, hipMemoryTypeUnregistered = 3 };
+struct hipPointerAttribute_t { hipMemoryType type; };
+static inline hipError_t hipPointerGetAttributes(hipPointerAttribute_t *a, const void *)
+{
+  a->type = getenv("LBZ_EMU_PAGEABLE") ? hipMemoryTypeUnregistered : hipMemoryTypeHost;
+  return hipSuccess;
+}
 static inline hipError_t hipMemcpy(void *d, const void *s, size_t n, hipMemcpyKind) { memcpy(d, s, n); return hipSuccess; }
 static inline hipError_t hipMemcpyAsync(void *d, const void *s, size_t n, hipMemcpyKind, hipStream_t = nullptr) { memcpy(d, s, n); return hipSuccess; }
 static inline hipError_t hipMemset(void *d, int v, size_t n) { memset(d, v, n); return hipSuccess; }

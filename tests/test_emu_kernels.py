@@ -91,6 +91,12 @@ def test_host_output_paths(emu, monkeypatch):
             with emu.context(1, max_slabs, nslots) as ctx:
                 assert ctx.compress(data) == want, (no_direct, max_slabs, nslots)
     monkeypatch.delenv("LBZ_EMU_NO_HOSTPTR")
+    # pageable input: a round's copy is issued next to the launches of the round before it (lbz_api.hip: run_chunk)
+    monkeypatch.setenv("LBZ_EMU_PAGEABLE", "1")
+    for max_slabs, nslots in ((5, 2), (5, 1)):
+        with emu.context(1, max_slabs, nslots) as ctx:
+            assert ctx.compress(data) == want, ("pageable", max_slabs, nslots)
+    monkeypatch.delenv("LBZ_EMU_PAGEABLE")
     import ctypes as C
     with emu.context(1, 5, 2) as ctx:
         small = C.create_string_buffer(len(want) - 7)
