@@ -1,43 +1,45 @@
 /*
- * k_bwt.hip -- stage 2: Burrows-Wheeler transform of the CYCLIC rotations of one block,
- * one block per workgroup, three kernels per round of blocks (lbz_kernels.h).
+ * k_bwt.hip -- stage 2: Burrows-Wheeler transform of the CYCLIC rotations of a block.
  *
- * Replaces divbwt() (reference src/divbwt.c:1706-1726; its sort_typeBstar/sssort/trsort/
- * construct_BWT machinery, divbwt.c:1488-1699, is a serial induced-sorting design with no
- * data-parallel analogue).  The BWT byte string is mathematically unique, so any correct
- * rotation sorter reproduces it.  This one is a most-significant-digit string sort staged
- * through LDS:
+ * Replaces divbwt() (reference src/divbwt.c:1706-1726; its sort_typeBstar/sssort/trsort/construct_BWT machinery,
+ * divbwt.c:1488-1699, is a serial induced-sorting design with no data-parallel analogue).  The BWT byte string is
+ * mathematically unique, so any correct rotation sorter reproduces it.  This one is a most-significant-digit string sort:
  *
- *   keys      every rotation i gets a 64-bit key: the dense codes (b = ceil(log2 #used bytes)
- *             bits each) of its first S = 64/b symbols, plus a 32-bit value
- *             (code of the preceding byte << 24 | i) -- the BWT output byte rides along.
- *   k_bwt_part   three stable 8-bit radix passes in HBM on the key's top 24 bits.  Keys are
- *             built on the fly from the block text streamed through an LDS tile (the first
- *             pass never reads a key array); per-wave digit counters live in LDS, ranks inside
- *             a wave come from 8 ballots per row, a tile is regrouped by digit in LDS so that
- *             every write is a run of equal-digit rows.
- *   k_bwt_batch  consecutive whole 24-bit groups of <= 4096 rows are pulled into LDS.  Waves
- *             claim chunks of groups (longest first) from a ticket counter; rows of a short
- *             group are placed by counting smaller keys, long groups are radix-sorted by their
- *             wave; every run of equal 64-bit keys is refined IN LDS by fetching the rotations'
- *             next S symbols from the text and re-sorting the run (bounded: REFINE_ROUNDS, a
- *             no-progress rule and a block-wide budget).  A finished batch writes 1 B (BWT
- *             byte) + 4 B (row) per rotation.  A 24-bit group larger than a batch is sorted on
- *             its remaining 40 key bits by the HBM radix sorter and cut at key boundaries.
- *   k_bwt_fix    rows still tied (long repeats, periodic blocks) are finished by prefix
- *             doubling on ranks, in LDS batches of whole runs (doubling_round); it ends when
- *             every row is unique or h >= n.  In the latter case the block is exactly
- *             periodic (T = u^k), equal rows stay tied and the origin pointer is the smallest
- *             equal row (the reference's choice among the k equal rows is an artefact of its
- *             unstable quicksort, SURVEY.md 8a-4 -- documented divergence, identical BWT bytes).
+ *   keys         rotation i gets a 64-bit key: the dense codes (b = ceil(log2 #used bytes) bits each; the bytes themselves
+ *                when more than 128 values are in use) of its first S = 64/b symbols, and a 32-bit value
+ *                (code of the preceding byte << 24 | i): the BWT output byte rides along with the index.
+ *   k_bwt_part   one workgroup per block: stable 8-bit radix passes in HBM on the key's top 32 bits (16 for a block whose
+ *                byte histogram is flat).  Keys are built on the fly from the block text streamed through an LDS tile (the
+ *                first pass never reads a key array); per-wave digit counters in LDS, ranks inside a wave from 8 ballots
+ *                per row, a tile regrouped by digit in LDS so that every write is a run of equal-digit rows.  It also fixes
+ *                the SEGMENTS: 16 or 32 cuts of the sorted rows at group boundaries -- from here on every (block,
+ *                segment) is a workgroup.
+ *   k_bwt_batch  consecutive whole groups of <= 1024 rows are pulled into LDS.  Waves claim chunks of groups (longest
+ *                first); rows of a short group are placed by counting smaller keys, long groups are radix-sorted by their
+ *                wave.  A finished batch writes 1 B (BWT byte) + 4 B (suffix-array entry) per rotation; rows whose 64-bit
+ *                keys tie (two thirds of a text block) go, run by run, to the segment's LIST: (suffix, rank = first row of
+ *                the run, symbols shared).  A group larger than a batch is sorted on its remaining key bits by the HBM
+ *                radix sorter first; more than a batch of EQUAL keys joins the list as one long run.
+ *   k_bwt_deep   the text rounds, LBZ_DEEP_ROUNDS launches: the listed runs are ordered by the text itself (0.9 MB per
+ *                block, read-only) -- runs of up to 63 rows a 64-lane strip at a time in registers (all-pairs counting on
+ *                52-bit slices of the next 16 bytes), longer runs taken apart symbol by symbol by a counting split.  From
+ *                the third launch on the rows still tied (long repeats) have rank entries and step by ranks (prefix
+ *                doubling over a SPARSE rank table: only tied rows have entries, a bit map says which).
+ *   k_bwt_fix0, k_bwt_fixr x 17, k_bwt_fixend   the rank rounds, the fall-back: blocks the text rounds are not made for
+ *                (mostly long runs, or two fifths of the rows still tied after the first launch: source trees, tables,
+ *                periodic data) or did not finish.  Full prefix doubling: a rank for EVERY rotation (isa[], 8-byte
+ *                {rank, rank before, tag} entries so that a launch reads the ranks as they stood when it began), one
+ *                launch per doubling depth starting at the depth the block's ties are known to share (deep_h0).  Rows
+ *                tied at depth >= n belong to an exactly periodic block (T = u^k): the origin pointer is the smallest
+ *                equal row (the reference's choice among the k equal rows is an artefact of its unstable quicksort,
+ *                SURVEY.md 8a-4 -- documented divergence, identical BWT bytes).
  *
- * Algorithmic traffic of the stage as priced in SURVEY.md 8(d): read T (1) + write SA (4) +
- * read SA (4) + gather T (1) + write BWT (1) = 11 B per block byte; measured HBM traffic is in
- * profiles/README.md.  ticks[] in the block record are diagnostics (tests/tools/quickperf.py).
+ * Algorithmic traffic of the stage as priced in SURVEY.md 8(d): read T (1) + write SA (4) + read SA (4) + gather T (1) +
+ * write BWT (1) = 11 B per block byte; measured HBM traffic is in profiles/README.md.  ticks[] / fticks[] in the block
+ * record are diagnostics (tests/tools/quickperf.py, diag_deep.py).
  */
-/* The kernels' geometry is their own constant.  One 1024-thread workgroup per CU (16 waves) is
- * what the 149 KB of LDS of a batch allow; 512 threads with 2048-row batches (two workgroups per
- * CU, the same 16 waves) measured the same.                                                */
+/* The kernels' geometry is their own constant: 256 threads (four workgroups per CU, 1024-row batches); the partition also in
+ * a 1024-thread build (k_bwt_wide.o) for rounds of fewer blocks than the device has CUs.                                */
 #ifdef LBZ_BWT_WIDE
 /* Second build of this file (k_bwt_wide.o): the partition kernel with 1024-thread workgroups, under its own name.  The
    partition is one workgroup per block whatever the input size; when a round has fewer blocks than the device has CUs
@@ -2119,20 +2121,21 @@ k_bwt_deep(const u8 *Tbase, u8 *Bbase, lbz_block_meta *meta, lbz_layout L, u32 f
   }
 }
 
-/* ---- kernels 3: blocks with ties deeper than the LDS refinements: prefix doubling, ONE LAUNCH PER ROUND ----
- * k_bwt_fix0   every segment of a block that has ties left builds its list of tied rows (suffix, rank, row) in
- *              row order -- in its own stretch [seg_lo, ..) of the slot's list columns -- and writes the ranks
- *              k_bwt_batch did not write.
- * k_bwt_fixr   round r, depth h = sy << r: every segment re-sorts its runs on isa[suffix + h] (doubling_round).
- *              The kernel boundary is the only synchronisation the segments of a block need: a round reads
- *              ranks of ANY rotation of the block, i.e. ranks that another workgroup may be refining in the same
- *              launch.  That is harmless: a rank is the first row of the rotation's run, a refined rank orders at
- *              least as deep as the one it replaces and never contradicts it (runs only split), 4-byte stores do
- *              not tear, and at the next launch every rank is at least 2h deep -- which is all the next round
- *              assumes.  A launch whose segment has nothing tied (or whose h has passed n) exits at once; the
- *              host enqueues the log2(M / 8) launches a block can need without looking.
- * k_bwt_fixend origin pointer and "exactly periodic" flag, the bytes of rows that stay tied for good.           */
-
+/* ---- kernels 3: the rank rounds (fall-back): prefix doubling, ONE LAUNCH PER ROUND ----
+ * k_bwt_fix0   every segment of a block that has ties left builds its list of tied rows (suffix, rank, row) in row order
+ *              from the suffix array's tie flags -- in its own stretch [seg_lo, ..) of the slot's list columns -- and
+ *              writes a rank entry for EVERY rotation of its rows.
+ * k_bwt_fixr   round r, depth h = deep_h0 << r: every segment re-sorts its runs on isa[suffix + h] (doubling_round).
+ *              The kernel boundary is the only synchronisation the segments of a block need: a round reads ranks of ANY
+ *              rotation of the block, i.e. entries that another workgroup of the same launch may be replacing.  The
+ *              invariant that makes this safe: an entry is written at most once per launch, as ONE aligned 64-bit store
+ *              {rank now, rank before, tag of the launch}, and a reader takes `rank before` when the tag is the current
+ *              launch's (isa_before) -- every workgroup sees the ranks as they stood when the launch began, so no run is
+ *              ever ordered by a mixture of ranks from before and after a split.  A launch whose segment has nothing tied
+ *              (or whose h has passed n) exits at once; the host enqueues the log2(M / 8) launches a block can need
+ *              without looking.
+ * k_bwt_fixend origin pointer and "exactly periodic" flag, the bytes of rows that stay tied for good.                  */
+static_assert(sizeof(u64) == 8 && alignof(u64) == 8, "a rank entry is one aligned 64-bit word");
 __global__ void __launch_bounds__(LBZ_WG, 4)
 k_bwt_fix0(const u8 *Tbase, u8 *Bbase, lbz_block_meta *meta, lbz_layout L, u32 first, u32 count, u32 nblk, u32 segs,
            u8 *ws, u64 slot_bytes, u8 *ws_spill, u64 spill_bytes, const u32 *slabs)
