@@ -8,12 +8,14 @@
  *   keys         rotation i gets a 64-bit key: the dense codes (b = ceil(log2 #used bytes) bits each; the bytes themselves
  *                when more than 128 values are in use) of its first S = 64/b symbols, and a 32-bit value
  *                (code of the preceding byte << 24 | i): the BWT output byte rides along with the index.
- *   k_bwt_part   one workgroup per block: stable 8-bit radix passes in HBM on the key's top 32 bits (16 for a block whose
- *                byte histogram is flat).  Keys are built on the fly from the block text streamed through an LDS tile (the
- *                first pass never reads a key array); per-wave digit counters in LDS, ranks inside a wave from 8 ballots
- *                per row, a tile regrouped by digit in LDS so that every write is a run of equal-digit rows.  It also fixes
- *                the SEGMENTS: 16 or 32 cuts of the sorted rows at group boundaries -- from here on every (block,
- *                segment) is a workgroup.
+ *   k_bwt_hist, k_bwt_scat x 4, k_bwt_segs   the partition: stable 8-bit radix passes in HBM on the key's top 32 bits (16
+ *                for a block whose byte histogram is flat), one launch per pass, a block's rows dealt over up to 16
+ *                workgroups (ranges of the pass's input; a pass counts the next pass's digits per range while it
+ *                scatters).  Keys are built on the fly from the block text streamed through an LDS tile (the first pass
+ *                never reads a key array); per-wave digit counters in LDS, ranks inside a wave from 8 ballots per row, a
+ *                tile regrouped by digit in LDS so that every write is a run of equal-digit rows.  k_bwt_segs fixes the
+ *                SEGMENTS: 16 or 32 cuts of the sorted rows at group boundaries -- from here on every (block, segment)
+ *                is a workgroup.
  *   k_bwt_batch  consecutive whole groups of <= 1024 rows are pulled into LDS.  Waves claim chunks of groups (longest
  *                first); rows of a short group are placed by counting smaller keys, long groups are radix-sorted by their
  *                wave.  A finished batch writes 1 B (BWT byte) + 4 B (suffix-array entry) per rotation; rows whose 64-bit
@@ -38,29 +40,13 @@
  * write BWT (1) = 11 B per block byte; measured HBM traffic is in profiles/README.md.  ticks[] / fticks[] in the block
  * record are diagnostics (tests/tools/quickperf.py, diag_deep.py).
  */
-/* The kernels' geometry is their own constant: 256 threads (four workgroups per CU, 1024-row batches); the partition also in
- * a 1024-thread build (k_bwt_wide.o) for rounds of fewer blocks than the device has CUs.                                */
-#ifdef LBZ_BWT_WIDE
-/* Second build of this file (k_bwt_wide.o): the partition kernel with 1024-thread workgroups, under its own name.  The
-   partition is one workgroup per block whatever the input size; when a round has fewer blocks than the device has CUs
-   (small inputs, the work-unit interface) a block is better served by sixteen waves than by four.                  */
-#define LBZ_WIDE_WG 1024
-#define k_bwt_part k_bwt_part_w
-#endif
+/* The kernels' geometry is their own constant: 256 threads (four workgroups per CU, 1024-row batches). */
 #include "lbz_common.h"
 #undef LBZ_WG
-#ifdef LBZ_BWT_WIDE
-#define LBZ_WG LBZ_WIDE_WG
-#else
 #define LBZ_WG LBZ_BWT_WG
-#endif
 #undef LBZ_NW
 #define LBZ_NW (LBZ_WG / 64)
 #include "lbz_kernels.h"
-#if defined(LBZ_BWT_WIDE) && defined(LBZ_EMULATED)
-#undef __device__
-#define __device__ static        /* the emulator links both builds of this file into one host library */
-#endif
 
 #define SORT_IPT 4u
 #define SORT_TILE (LBZ_WG * SORT_IPT)
@@ -76,6 +62,7 @@
    the block record (msd_bits) and, as a shift, in every sorting kernel's LDS header (msd_shift).                      */
 #define MSD_BITS_FLAT 16u
 #define PART_HALO 48u
+#define PART_MAX 16u                    /* workgroups a block's rows are dealt over in the partition kernels (ranges of its input order) */
 #define BATCH_CAP (LBZ_WG * 4u)
 #define SMALL_BLOCK (LBZ_BWT_WG * 4u)    /* blocks of at most one batch of k_bwt_batch are sorted whole in LDS, without a partition */
 #ifndef COUNT_GROUP
@@ -172,6 +159,7 @@ struct bwt_slot {
   u64 *k0, *k1;
   u32 *v0, *v1, *sufx, *grp, *pos, *sa;
   u64 *isa;
+  u32 *ph;                              /* the partition's per-range digit histograms: 4 tables of PART_MAX x 256 (64 KB of the slot's tail) */
 };
 
 struct keycfg {
@@ -192,7 +180,8 @@ __device__ __forceinline__ bwt_slot slot_carve(u8 *ws, u32 cap)
   s.grp = (u32 *)p; p += (size_t)cap * 4u;
   s.pos = (u32 *)p; p += (size_t)cap * 4u;
   s.sa = (u32 *)p; p += (size_t)cap * 4u;
-  s.isa = (u64 *)p;
+  s.isa = (u64 *)p; p += (size_t)cap * 8u;
+  s.ph = (u32 *)p;
   return s;
 }
 
@@ -212,9 +201,11 @@ __device__ __forceinline__ bwt_slot seg_view(bwt_slot s, u32 lo)
 }
 
 struct sort_lds;
+template <bool NEXT = false>
 __device__ __forceinline__ void radix_tile_scatter_hbm(sort_lds *X, const unsigned long long (&key)[4], const unsigned int (&val)[4],
                                                        unsigned int okmask, unsigned int shift,
-                                                       unsigned long long *kout, unsigned int *vout);
+                                                       unsigned long long *kout, unsigned int *vout,
+                                                       unsigned int (*nh)[256] = nullptr, unsigned int nshift = 0u);
 
 /* ======================================================================= HBM radix sorter
  * Stable LSD radix sort of m (key,value) pairs on key bits [0, nbits).  Input in (k0,v0);
@@ -446,9 +437,10 @@ __device__ __forceinline__ void radix_tile_scatter(u32 (*wcnt)[256], u32 *dbase,
 /* The same step for an HBM destination: ranks as above, then the tile is regrouped by digit
  * in LDS and written out by consecutive threads, so that each wave store covers a few runs of
  * consecutive addresses instead of 64 scattered rows.                                      */
+template <bool NEXT>
 __device__ __forceinline__ void radix_tile_scatter_hbm(sort_lds *X, const u64 (&key)[SORT_IPT],
                                                        const u32 (&val)[SORT_IPT], u32 okmask, u32 shift,
-                                                       u64 *kout, u32 *vout)
+                                                       u64 *kout, u32 *vout, u32 (*nh)[256], u32 nshift)
 {
   const u32 tid = threadIdx.x, lane = lane_id(), w = wave_id();
   u32 rnk[SORT_IPT];
@@ -508,6 +500,7 @@ __device__ __forceinline__ void radix_tile_scatter_hbm(sort_lds *X, const u64 (&
       const u32 dst = X->gdelta[(u32)(kk >> shift) & 255u] + i;
       kout[dst] = kk;
       vout[dst] = X->stage_v[i];
+      if (NEXT) atomicAdd(&nh[dst >> nshift][(u32)(kk >> (shift + 8u)) & 255u], 1u);    /* the NEXT pass's digit, by the range of its input the row lands in */
     }
   }
   wg_lds_barrier();
@@ -520,14 +513,15 @@ __device__ __forceinline__ void radix_tile_scatter_hbm(sort_lds *X, const u64 (&
  * SCATTER = true : first partition pass (digit at `shift`) straight from the text, counting the digits above it on
  *                  the way if `count_above` (hist[j]: the digit at bit 32 + 8 j).  Values carry the CODE of the
  *                  preceding byte; the emitters map it back.                                 */
-template <bool SCATTER>
-__device__ void msd_text_pass(const u8 *T, u32 n, keycfg c, u64 *kout, u32 *vout, bwt_lds *S, u32 shift = 0u, bool count_above = false)
+template <bool SCATTER, bool NEXT = false>
+__device__ void msd_text_pass(const u8 *T, u32 n, keycfg c, u64 *kout, u32 *vout, bwt_lds *S, u32 shift, u32 r0, u32 r1,
+                              u32 (*nh)[256] = nullptr, u32 nshift = 0u)      /* rotations [r0, r1), r0 a multiple of the tile */
 {
   sort_lds *P = &S->u.X;
   const u32 tid = threadIdx.x;
   u32 *tile32 = P->tile;        /* code of position t0 + j at byte 4 + j */
   const u64 keep = (c.b * c.sy >= 64u) ? ~0ull : ((1ull << (c.b * c.sy)) - 1ull);
-  for (u32 t0 = 0; t0 < n; t0 += SORT_TILE) {
+  for (u32 t0 = r0; t0 < r1; t0 += SORT_TILE) {
     const u32 q0 = t0 + 4u * tid;
     {
       u32 raw;
@@ -562,7 +556,7 @@ __device__ void msd_text_pass(const u8 *T, u32 n, keycfg c, u64 *kout, u32 *vout
         key[k] = win << c.pad;
         val[k] = (prev << 24) | (q0 + k);
         prev = (w0 >> (8u * k)) & 255u;
-        if (q0 + k < n) okmask |= 1u << k;
+        if (q0 + k < r1) okmask |= 1u << k;
       }
     } else {
 #pragma unroll
@@ -572,23 +566,20 @@ __device__ void msd_text_pass(const u8 *T, u32 n, keycfg c, u64 *kout, u32 *vout
         for (u32 q = 0; q < c.sy; q++) kk = (kk << c.b) | reinterpret_cast<const u8 *>(P->tile)[4u + j + q];
         key[k] = kk << c.pad;
         val[k] = ((u32)reinterpret_cast<const u8 *>(P->tile)[3u + j] << 24) | (q0 + k);
-        if (q0 + k < n) okmask |= 1u << k;
+        if (q0 + k < r1) okmask |= 1u << k;
       }
     }
     if (SCATTER) {
-      if (count_above) {
-#pragma unroll
-        for (u32 k = 0; k < SORT_IPT; k++)
-          if ((okmask >> k) & 1u) {
-#pragma unroll
-            for (u32 p = 1; p < 4u; p++) atomicAdd(&P->hist[p][(u32)(key[k] >> (32u + 8u * p)) & 255u], 1u);
-          }
-      }
-      radix_tile_scatter_hbm(P, key, val, okmask, shift, kout, vout);
+      radix_tile_scatter_hbm<NEXT>(P, key, val, okmask, shift, kout, vout, nh, nshift);
     } else {
+      /* the first pass's digit of every rotation of the range, for either depth of partition: hist[0] the key byte at bit 32
+         (32-bit partition), hist[2] the one at bit 48 (16-bit) */
 #pragma unroll
       for (u32 k = 0; k < SORT_IPT; k++)
-        if ((okmask >> k) & 1u) atomicAdd(&P->hist[0][(u32)(key[k] >> 32u) & 255u], 1u);
+        if ((okmask >> k) & 1u) {
+          atomicAdd(&P->hist[0][(u32)(key[k] >> 32u) & 255u], 1u);
+          atomicAdd(&P->hist[2][(u32)(key[k] >> 48u) & 255u], 1u);
+        }
       __syncthreads();
     }
   }
@@ -596,7 +587,9 @@ __device__ void msd_text_pass(const u8 *T, u32 n, keycfg c, u64 *kout, u32 *vout
 
 /* A partition pass from (kin,vin) to (kout,vout) on the digit at `shift`; the next tile's rows
  * are requested before the current tile is ranked.                                        */
-__device__ void msd_array_pass(const u64 *kin, const u32 *vin, u32 n, u32 shift, u64 *kout, u32 *vout, bwt_lds *S)
+template <bool NEXT>
+__device__ void msd_array_pass(const u64 *kin, const u32 *vin, u32 shift, u64 *kout, u32 *vout, bwt_lds *S, u32 r0, u32 r1,
+                               u32 (*nh)[256], u32 nshift)                     /* rows [r0, r1) */
 {
   sort_lds *P = &S->u.X;
   const u32 lane = lane_id(), w = wave_id();
@@ -604,11 +597,11 @@ __device__ void msd_array_pass(const u64 *kin, const u32 *vin, u32 n, u32 shift,
   u32 nval[SORT_IPT];
 #pragma unroll
   for (u32 k = 0; k < SORT_IPT; k++) {
-    const u32 i = w * 64u * SORT_IPT + k * 64u + lane;
-    nkey[k] = i < n ? kin[i] : 0ull;
-    nval[k] = i < n ? vin[i] : 0u;
+    const u32 i = r0 + w * 64u * SORT_IPT + k * 64u + lane;
+    nkey[k] = i < r1 ? kin[i] : 0ull;
+    nval[k] = i < r1 ? vin[i] : 0u;
   }
-  for (u32 t0 = 0; t0 < n; t0 += SORT_TILE) {
+  for (u32 t0 = r0; t0 < r1; t0 += SORT_TILE) {
     u64 key[SORT_IPT];
     u32 val[SORT_IPT], okmask = 0;
     const u32 wbase = t0 + w * 64u * SORT_IPT;
@@ -616,12 +609,12 @@ __device__ void msd_array_pass(const u64 *kin, const u32 *vin, u32 n, u32 shift,
     for (u32 k = 0; k < SORT_IPT; k++) {
       key[k] = nkey[k];
       val[k] = nval[k];
-      if (wbase + k * 64u + lane < n) okmask |= 1u << k;
+      if (wbase + k * 64u + lane < r1) okmask |= 1u << k;
       const u32 i = wbase + SORT_TILE + k * 64u + lane;
-      nkey[k] = i < n ? kin[i] : 0ull;
-      nval[k] = i < n ? vin[i] : 0u;
+      nkey[k] = i < r1 ? kin[i] : 0ull;
+      nval[k] = i < r1 ? vin[i] : 0u;
     }
-    radix_tile_scatter_hbm(P, key, val, okmask, shift, kout, vout);
+    radix_tile_scatter_hbm<NEXT>(P, key, val, okmask, shift, kout, vout, nh, nshift);
   }
 }
 
@@ -1353,8 +1346,17 @@ __device__ u32 seg_cut(const u64 *k0, u32 x, u32 n, bwt_lds *S)
   return find_run_end(k0, x - 1u, x, n, S->msd_shift, S);
 }
 
-/* ---- kernel 1: partition on the key's top 24 bits: k0 <- text, k1 <- k0, k0 <- k1 ---- */
-/* the partition only needs the sorter's part of the LDS layout: 80 KB */
+/* ---- kernels 1: the partition, several workgroups per block ----------------------------------------------------------
+ * Stable least-significant-digit-first radix passes on the key's top 32 (16) bits, as before -- but a block's rows are dealt
+ * over up to PART_MAX workgroups: workgroup j of a pass takes the j-th RANGE of the pass's input order (ranges of 2^k rows,
+ * whole tiles) and scatters it in order, starting for every digit behind the rows of that digit in the ranges before it.
+ * What it needs for that -- the digit histogram of every range of its pass -- is counted by the pass BEFORE it while it
+ * scatters: a row's place in the output says which range of the next pass it will be read in, its next digit is in the
+ * key, so the histogram of the next pass grows in LDS ([range][digit], 16 KB) and is added to the block's table in HBM
+ * when the workgroup is done.  One launch per pass, no workgroup waits for another; the kernel boundary is the
+ * synchronisation.  k_bwt_hist counts for the first pass (from the text), k_bwt_segs fixes the segments at the end.
+ * Until round 4 one workgroup took a block through all its passes: 14 ms per block whatever the device was doing, two
+ * waves of workgroups for 1112 blocks on 1024 slots, and the whole of a small input's latency.                          */
 struct part_lds {
   wg_scratch sc;
   u32 bc[16];
@@ -1365,90 +1367,287 @@ struct part_lds {
   u8 cmap[256];
   u8 inv[256];
   sort_lds X;
+  u32 nh[PART_MAX][256];                /* digit histogram of the NEXT pass, per range of its input (= this pass's output rows) */
 };
 static_assert(offsetof(part_lds, X) == offsetof(bwt_lds, u), "same layout up to the union");
-static_assert(sizeof(part_lds) <= 81920, "two per CU");
+static_assert(sizeof(part_lds) <= 54 * 1024, "three per CU");
 
-__device__ __forceinline__ void part_block(bwt_lds &S, const u8 *Tbase, lbz_block_meta *meta, lbz_layout L, u32 first, u32 count,
-                                           u8 *ws, u64 slot_bytes, u8 *ws_spill, u64 spill_bytes, const u32 *slabs, u32 segs)
+/* ranges of 2^shift rows (whole tiles), at most `parts` of them */
+__device__ __forceinline__ u32 part_shift(u32 n, u32 parts)
 {
+  u32 sh = 10u;                                  /* SORT_TILE = 1024 rows in the main build */
+  while (((n + (1u << sh) - 1u) >> sh) > parts) sh++;
+  return sh;
+}
+/* the block's four histogram tables: [table][range][digit] */
+__device__ __forceinline__ u32 *part_table(bwt_slot s, u32 t) { return s.ph + (size_t)t * PART_MAX * 256u; }
+
+/* (block of the round, part) of this workgroup: the parts of a block on one XCD (seg_item's dealing) */
+__device__ __forceinline__ bool part_item(u32 nblk, u32 parts, u32 *i, u32 *j)
+{
+  const u32 g = blockIdx.x, k = g >> 3;
+  *i = (k / parts) * 8u + (g & 7u);
+  *j = k % parts;
+  return *i < nblk;
+}
+
+/* the first pass's digits, counted per range of the text: tables 0 (32-bit partition: the key byte at bit 32) and 1 (16-bit:
+   at bit 48); also the sorter's part of the block record */
+__global__ void __launch_bounds__(LBZ_WG, 3)
+k_bwt_hist(const u8 *Tbase, lbz_block_meta *meta, lbz_layout L, u32 first, u32 count, u32 nblk, u32 parts,
+           u8 *ws, u64 slot_bytes, u8 *ws_spill, u64 spill_bytes, const u32 *slabs)
+{
+  __shared__ part_lds S_;
+  bwt_lds &S = *reinterpret_cast<bwt_lds *>(&S_);
   const u32 tid = threadIdx.x;
-  const u32 blk = lbz_round_block(first, count, blockIdx.x, slabs);
-  const u32 n = meta[blk].n;
-  if (tid == 0) {                             /* the sorter's part of the block record: the segment workgroups add to it */
-    lbz_block_meta *M = &meta[blk];
+  u32 bi, j;
+  if (!part_item(nblk, parts, &bi, &j)) return;
+  const u32 blk = lbz_round_block(first, count, bi, slabs);
+  lbz_block_meta *M = &meta[blk];
+  const u32 n = M->n;
+  if (j == 0u && tid == 0) {                  /* the segment workgroups add to these */
     M->periodic = 0; M->rounds = 0; M->sort_elems = 0; M->deep_rows = 0; M->nseg = 0; M->deep_h0 = 0xFFFFFFFFu; M->deep_skip = 0; M->deep_long = 0;
     for (u32 i = 0; i <= LBZ_DEEP_ROUNDS; i++) { M->deep_tot[i] = 0; M->deep_hmin[i] = 0xFFFFFFFFu; }
     M->msd_bits = MSD_BITS;
     for (u32 i = 0; i < 8u; i++) M->ticks[i] = 0;
     for (u32 i = 0; i < 16u; i++) M->fticks[i] = 0;
     for (u32 i = 0; i < LBZ_BWT_MAXSEGS; i++) M->seg_m[i] = 0;
+    if (n <= SMALL_BLOCK) { M->nseg = 1u; M->seg_lo[0] = 0u; M->seg_lo[1] = n; }     /* small blocks are sorted whole by k_bwt_batch */
   }
-  if (n <= SMALL_BLOCK) {                     /* small blocks are sorted whole by k_bwt_batch: one segment */
-    if (tid == 0) { meta[blk].nseg = 1u; meta[blk].seg_lo[0] = 0u; meta[blk].seg_lo[1] = n; }
-    return;
-  }
-  const bwt_slot s = round_slot(ws, slot_bytes, ws_spill, spill_bytes, count, L, blockIdx.x);
+  if (n <= SMALL_BLOCK) return;
+  const u32 sh = part_shift(n, parts);
+  const u32 r0 = j << sh;
+  if (r0 >= n) return;
+  const u32 r1 = r0 + (1u << sh) < n ? r0 + (1u << sh) : n;
+  const bwt_slot s = round_slot(ws, slot_bytes, ws_spill, spill_bytes, count, L, bi);
   const u8 *T = Tbase + lbz_elem_off(L, blk);
-  const u64 tk0 = wall_clock64();
-  const keycfg c = bwt_setup(&meta[blk], &S);
+  const keycfg c = bwt_setup(M, &S);
   sort_lds *P = &S.u.X;
   for (u32 i = tid; i < 4u * 256u; i += LBZ_WG) (&P->hist[0][0])[i] = 0;
   __syncthreads();
-  msd_text_pass<false>(T, n, c, nullptr, nullptr, &S);         /* hist[0]: the key byte at bit 32 */
-  /* With 8-bit symbols a key byte is one symbol of the rotation, and every position of the text is the k-th symbol of
-     exactly one rotation: the four digit histograms are the SAME histogram (the text's), so the other three need not be
-     counted -- and it tells how deep to partition: no byte value in more than 1/128 of the positions (incompressible
-     data) -> 16 bits, else MSD_BITS.  Narrower symbols straddle the key bytes: their digits are counted during the
-     first scatter pass, as before, and the depth stays MSD_BITS.                                                    */
-  const bool bytes = c.b == 8u;
-  u32 bits = MSD_BITS;
-  if (bytes) {
-    const u32 h0 = tid < 256u ? P->hist[0][tid] : 0u;
-    if (tid < 256u) { P->hist[1][tid] = h0; P->hist[2][tid] = h0; P->hist[3][tid] = h0; }
-    const u32 top = wg_max(h0, &S.sc);
-    if (MSD_BITS > MSD_BITS_FLAT && top <= n / 128u) bits = MSD_BITS_FLAT;
+  msd_text_pass<false>(T, n, c, nullptr, nullptr, &S, 0u, r0, r1);
+  if (tid < 256u) {
+    part_table(s, 0)[j * 256u + tid] = P->hist[0][tid];
+    part_table(s, 1)[j * 256u + tid] = P->hist[2][tid];
+    part_table(s, 2)[j * 256u + tid] = 0u;                    /* the first pass adds the second pass's counts here */
   }
-  if (tid == 0) meta[blk].msd_bits = bits;
-  const u32 passes = bits / 8u, j0 = 4u - passes;             /* digits j0 .. 3, least significant first */
-  load_digit_offsets(P->hist[j0], P->dbase, &S);
+}
+
+/* pass `pass` of the block's 2 or 4: range j of the pass's input */
+__global__ void __launch_bounds__(LBZ_WG, 3)
+k_bwt_scat(const u8 *Tbase, lbz_block_meta *meta, lbz_layout L, u32 first, u32 count, u32 nblk, u32 parts,
+           u8 *ws, u64 slot_bytes, u8 *ws_spill, u64 spill_bytes, const u32 *slabs, u32 pass)
+{
+  __shared__ part_lds S_;
+  bwt_lds &S = *reinterpret_cast<bwt_lds *>(&S_);
+  const u32 tid = threadIdx.x;
+  u32 bi, j;
+  if (!part_item(nblk, parts, &bi, &j)) return;
+  const u32 blk = lbz_round_block(first, count, bi, slabs);
+  lbz_block_meta *M = &meta[blk];
+  const u32 n = M->n;
+  if (n <= SMALL_BLOCK) return;
+  const u32 sh = part_shift(n, parts);
+  const u32 nr = (n + (1u << sh) - 1u) >> sh;                  /* ranges in use */
+  const u32 r0 = j << sh;
+  if (r0 >= n) return;
+  const u32 r1 = r0 + (1u << sh) < n ? r0 + (1u << sh) : n;
+  const u64 tk0 = wall_clock64();
+  const bwt_slot s = round_slot(ws, slot_bytes, ws_spill, spill_bytes, count, L, bi);
+  const u8 *T = Tbase + lbz_elem_off(L, blk);
+  const keycfg c = bwt_setup(M, &S);
+  sort_lds *P = &S.u.X;
+  /* How deep to partition (every workgroup of the block works it out the same way from the first pass's table, part 0
+     notes it): with 8-bit symbols the digit histogram is the text's histogram, and no byte value in more than 1/128 of
+     the positions (incompressible data) -> 16 bits, its groups are a dozen rows then; else MSD_BITS.                 */
+  u32 bits = M->msd_bits;                                      /* passes behind the first: what the first one noted (table 0 is in use again) */
+  if (pass == 0u) {
+    u32 tot0 = 0;
+    if (tid < 256u) for (u32 i = 0; i < nr; i++) tot0 += part_table(s, 0)[i * 256u + tid];
+    const u32 top = wg_max(tot0, &S.sc);
+    bits = (c.b == 8u && MSD_BITS > MSD_BITS_FLAT && top <= n / 128u) ? MSD_BITS_FLAT : MSD_BITS;
+  }
+  const u32 passes = bits / 8u;
+  if (pass >= passes) return;
+  if (pass == 0u && j == 0u && tid == 0) M->msd_bits = bits;
+  const u32 dj = 4u - passes + pass;                           /* digits 4 - passes .. 3, least significant first */
+  /* tables: the first pass reads 0 or 1; from then on pass p reads what pass p - 1 added up, adds to the next and clears
+     the one after that (its own range's rows) for the pass after it */
+  const u32 tin = pass == 0u ? (bits == MSD_BITS ? 0u : 1u) : (pass == 1u ? 2u : (pass == 2u ? 3u : 0u));
+  const u32 tout = pass == 0u ? 2u : (pass == 1u ? 3u : 0u);
+  const u32 tzero = pass == 0u ? 3u : (pass == 1u ? 0u : 1u);
+  const bool next = pass + 1u < passes;
+  {
+    const u32 *H = part_table(s, tin);
+    u32 tot = 0, before = 0;
+    if (tid < 256u)
+      for (u32 i = 0; i < nr; i++) {
+        const u32 h = H[i * 256u + tid];
+        if (i < j) before += h;
+        tot += h;
+      }
+    u32 all;
+    const u32 ex = wg_excl_add(tot, &all, &S.sc);
+    if (tid < 256u) P->dbase[tid] = ex + before;
+    for (u32 i = tid; i < PART_MAX * 256u; i += LBZ_WG) (&S_.nh[0][0])[i] = 0;
+    if (tid < 256u && pass + 2u < passes) part_table(s, tzero)[j * 256u + tid] = 0u;
+    __syncthreads();
+  }
   /* buffers alternate so that the last pass lands in (k0,v0) */
   u64 *kb[2] = { s.k0, s.k1 };
   u32 *vb[2] = { s.v0, s.v1 };
-  u32 cur = (passes - 1u) & 1u;
-  msd_text_pass<true>(T, n, c, kb[cur], vb[cur], &S, 32u + 8u * j0, !bytes);
-  for (u32 j = j0 + 1u; j < 4u; j++) {
-    load_digit_offsets(P->hist[j], P->dbase, &S);
-    msd_array_pass(kb[cur], vb[cur], n, 32u + 8u * j, kb[cur ^ 1u], vb[cur ^ 1u], &S);
-    cur ^= 1u;
+  const u32 dst = (passes - 1u - pass) & 1u;                  /* pass p writes buffer (passes - 1 - p) & 1 */
+  const u32 shift = 32u + 8u * dj;
+  if (pass == 0u) {
+    if (next) msd_text_pass<true, true>(T, n, c, kb[dst], vb[dst], &S, shift, r0, r1, S_.nh, sh);
+    else msd_text_pass<true, false>(T, n, c, kb[dst], vb[dst], &S, shift, r0, r1);
+  } else {
+    if (next) msd_array_pass<true>(kb[dst ^ 1u], vb[dst ^ 1u], shift, kb[dst], vb[dst], &S, r0, r1, S_.nh, sh);
+    else msd_array_pass<false>(kb[dst ^ 1u], vb[dst ^ 1u], shift, kb[dst], vb[dst], &S, r0, r1, nullptr, 0u);
   }
-  /* The segments' bounds, fixed HERE: group boundaries of the partition nearest to the even cuts.  The segment workgroups of
-     k_bwt_batch rewrite keys while they work (an oversized group trades its keys for later symbols), so a neighbour
-     must not be searching the key column for its bounds at that time. */
+  if (next) {
+    __syncthreads();
+    u32 *O = part_table(s, tout);
+    for (u32 i = tid; i < nr * 256u; i += LBZ_WG) {
+      const u32 v = (&S_.nh[0][0])[i];
+      if (v) atomicAdd(&O[i], v);
+    }
+  }
+  if (tid == 0) atomicAdd(&M->ticks[2], (u32)(wall_clock64() - tk0));
+}
+
+/* The partition as ONE workgroup per block, all passes in one launch (the only form until round 4).  Where rounds of
+ * several hundred blocks overlap on several streams it is still the better one -- a long kernel of few waves that the other
+ * streams' kernels fill in around (7.97 against 7.5-7.8 GB/s for the launch-per-pass form on wiki(10^9), three streams,
+ * same box) -- while a single round, or a round of few blocks, waits for a block's 14 ms of passes; lbz_api.hip picks.  */
+struct part1_lds {
+  wg_scratch sc;
+  u32 bc[16];
+  u32 listn, seglo;
+  u32 h0min, lmin;
+  u32 msd_shift, seghi;
+  u32 dbg[4];
+  u8 cmap[256];
+  u8 inv[256];
+  sort_lds X;
+  u32 nh[1][256];                       /* digit histogram of the next pass (symbols narrower than a byte: counted while scattering) */
+};
+static_assert(offsetof(part1_lds, X) == offsetof(bwt_lds, u), "same layout up to the union");
+__global__ void __launch_bounds__(LBZ_WG, 4)
+k_bwt_part(const u8 *Tbase, lbz_block_meta *meta, lbz_layout L, u32 first, u32 count,
+           u8 *ws, u64 slot_bytes, u8 *ws_spill, u64 spill_bytes, const u32 *slabs, u32 segs)
+{
+  __shared__ part1_lds S_;
+  bwt_lds &S = *reinterpret_cast<bwt_lds *>(&S_);
+  const u32 tid = threadIdx.x;
+  const u32 blk = lbz_round_block(first, count, blockIdx.x, slabs);
+  lbz_block_meta *M = &meta[blk];
+  const u32 n = M->n;
+  if (tid == 0) {                             /* the sorter's part of the block record: the segment workgroups add to it */
+    M->periodic = 0; M->rounds = 0; M->sort_elems = 0; M->deep_rows = 0; M->nseg = 0; M->deep_h0 = 0xFFFFFFFFu; M->deep_skip = 0; M->deep_long = 0;
+    for (u32 i = 0; i <= LBZ_DEEP_ROUNDS; i++) { M->deep_tot[i] = 0; M->deep_hmin[i] = 0xFFFFFFFFu; }
+    M->msd_bits = MSD_BITS;
+    for (u32 i = 0; i < 8u; i++) M->ticks[i] = 0;
+    for (u32 i = 0; i < 16u; i++) M->fticks[i] = 0;
+    for (u32 i = 0; i < LBZ_BWT_MAXSEGS; i++) M->seg_m[i] = 0;
+    if (n <= SMALL_BLOCK) { M->nseg = 1u; M->seg_lo[0] = 0u; M->seg_lo[1] = n; }
+  }
+  if (n <= SMALL_BLOCK) return;               /* small blocks are sorted whole by k_bwt_batch */
+  const bwt_slot s = round_slot(ws, slot_bytes, ws_spill, spill_bytes, count, L, blockIdx.x);
+  const u8 *T = Tbase + lbz_elem_off(L, blk);
+  const u64 tk0 = wall_clock64();
+  const keycfg c = bwt_setup(M, &S);
+  sort_lds *P = &S.u.X;
+  for (u32 i = tid; i < 4u * 256u; i += LBZ_WG) (&P->hist[0][0])[i] = 0;
+  __syncthreads();
+  msd_text_pass<false>(T, n, c, nullptr, nullptr, &S, 0u, 0u, n);           /* hist[0], hist[2]: the key bytes at bits 32 and 48 */
+  /* With 8-bit symbols a key byte is one symbol of the rotation, and every position of the text is the k-th symbol of
+     exactly one rotation: every digit's histogram is the text's, so none but the first is counted -- and it tells how
+     deep to partition (k_bwt_scat).  Narrower symbols straddle the key bytes: a pass counts the next pass's digits.  */
+  const bool bytes = c.b == 8u;
+  const u32 top = wg_max(tid < 256u ? P->hist[0][tid] : 0u, &S.sc);
+  const u32 bits = (bytes && MSD_BITS > MSD_BITS_FLAT && top <= n / 128u) ? MSD_BITS_FLAT : MSD_BITS;
+  if (tid == 0) M->msd_bits = bits;
+  const u32 passes = bits / 8u;
+  u64 *kb[2] = { s.k0, s.k1 };
+  u32 *vb[2] = { s.v0, s.v1 };
+  load_digit_offsets(passes == 4u ? P->hist[0] : P->hist[2], P->dbase, &S);
+  for (u32 pass = 0; pass < passes; pass++) {
+    const u32 dst = (passes - 1u - pass) & 1u;               /* the last pass lands in (k0,v0) */
+    const u32 shift = 32u + 8u * (4u - passes + pass);
+    const bool next = pass + 1u < passes && !bytes;
+    if (next) {
+      for (u32 i = tid; i < 256u; i += LBZ_WG) S_.nh[0][i] = 0;
+      __syncthreads();
+    }
+    if (pass == 0u) {
+      if (next) msd_text_pass<true, true>(T, n, c, kb[dst], vb[dst], &S, shift, 0u, n, S_.nh, 31u);
+      else msd_text_pass<true, false>(T, n, c, kb[dst], vb[dst], &S, shift, 0u, n);
+    } else {
+      if (next) msd_array_pass<true>(kb[dst ^ 1u], vb[dst ^ 1u], shift, kb[dst], vb[dst], &S, 0u, n, S_.nh, 31u);
+      else msd_array_pass<false>(kb[dst ^ 1u], vb[dst ^ 1u], shift, kb[dst], vb[dst], &S, 0u, n, nullptr, 0u);
+    }
+    if (pass + 1u < passes) {
+      __syncthreads();
+      load_digit_offsets(bytes ? P->hist[0] : S_.nh[0], P->dbase, &S);
+    }
+  }
+  /* the segments' bounds (k_bwt_segs) */
   __syncthreads();
   if (tid == 0) S.msd_shift = 64u - bits;
   __syncthreads();
   const u32 nseg = bwt_nseg(n, segs);
   for (u32 g = 1; g < nseg; g++) {
     const u32 cut = seg_cut(s.k0, (u32)((u64)g * n / nseg), n, &S);
-    if (tid == 0) meta[blk].seg_lo[g] = cut;
+    if (tid == 0) M->seg_lo[g] = cut;
   }
-  if (tid == 0) {
-    meta[blk].nseg = nseg; meta[blk].seg_lo[0] = 0u; meta[blk].seg_lo[nseg] = n;
-    meta[blk].ticks[2] = (u32)(wall_clock64() - tk0);
-  }
+  if (tid == 0) { M->nseg = nseg; M->seg_lo[0] = 0u; M->seg_lo[nseg] = n; M->ticks[2] = (u32)(wall_clock64() - tk0); }
 }
 
-/* 256 threads in the main build (four workgroups per CU beside the sorting kernels' own), 1024 in the wide one */
+/* The segments' bounds: group boundaries of the partition nearest to the even cuts.  Fixed here, before k_bwt_batch: its
+   segment workgroups must not search the key column of a neighbour at work.  One workgroup per block.               */
+struct segs_lds {                       /* bwt_lds up to its union: all the boundary searches touch */
+  wg_scratch sc;
+  u32 bc[16];
+  u32 listn, seglo;
+  u32 h0min, lmin;
+  u32 msd_shift, seghi;
+  u32 dbg[4];
+  u8 cmap[256];
+  u8 inv[256];
+};
+static_assert(sizeof(segs_lds) == offsetof(bwt_lds, u), "same layout up to the union");
 __global__ void __launch_bounds__(LBZ_WG, 4)
-k_bwt_part(const u8 *Tbase, lbz_block_meta *meta, lbz_layout L, u32 first, u32 count,
-           u8 *ws, u64 slot_bytes, u8 *ws_spill, u64 spill_bytes, const u32 *slabs, u32 segs)
+k_bwt_segs(lbz_block_meta *meta, lbz_layout L, u32 first, u32 count, u32 segs,
+           u8 *ws, u64 slot_bytes, u8 *ws_spill, u64 spill_bytes, const u32 *slabs)
 {
-  __shared__ part_lds S_;
-  part_block(*reinterpret_cast<bwt_lds *>(&S_), Tbase, meta, L, first, count, ws, slot_bytes, ws_spill, spill_bytes, slabs, segs);
+  __shared__ segs_lds S_;
+  bwt_lds &S = *reinterpret_cast<bwt_lds *>(&S_);
+  const u32 tid = threadIdx.x;
+  const u32 blk = lbz_round_block(first, count, blockIdx.x, slabs);
+  lbz_block_meta *M = &meta[blk];
+  const u32 n = M->n;
+  if (n <= SMALL_BLOCK) return;
+  const bwt_slot s = round_slot(ws, slot_bytes, ws_spill, spill_bytes, count, L, blockIdx.x);
+  if (tid == 0) S.msd_shift = 64u - M->msd_bits;
+  __syncthreads();
+#ifdef DEEP_DEBUG
+  if (tid == 0) {
+    u32 bad = 0;
+    for (u32 i = 1; i < n && bad < 5u; i++)
+      if ((s.k0[i] >> S.msd_shift) < (s.k0[i - 1u] >> S.msd_shift)) { printf("part: blk %u row %u out of order: %llx after %llx (bits %u)\n", blk, i, s.k0[i], s.k0[i - 1u], M->msd_bits); bad++; }
+    u64 sum = 0; for (u32 i = 0; i < n; i++) sum += s.v0[i] & 0xFFFFFFu;
+    printf("part: blk %u n %u index sum %llu (want %llu)\n", blk, n, sum, (u64)n * (n - 1u) / 2u);
+  }
+#endif
+  const u32 nseg = bwt_nseg(n, segs);
+  for (u32 g = 1; g < nseg; g++) {
+    const u32 cut = seg_cut(s.k0, (u32)((u64)g * n / nseg), n, &S);
+    if (tid == 0) M->seg_lo[g] = cut;
+  }
+  if (tid == 0) { M->nseg = nseg; M->seg_lo[0] = 0u; M->seg_lo[nseg] = n; }
 }
 
-#ifndef LBZ_BWT_WIDE
 /* ---- segments -------------------------------------------------------------------------------------------
  * After the partition the rows of a block are grouped by their top MSD_BITS and the groups are independent of
  * each other, so the rest of the sort does not need one workgroup per block: the rows are cut into up to
@@ -2226,4 +2425,3 @@ k_bwt_fixend(u8 *Bbase, lbz_block_meta *meta, lbz_layout L, u32 first, u32 count
     M->periodic = left > 0u ? 1u : 0u;
   }
 }
-#endif   /* !LBZ_BWT_WIDE */

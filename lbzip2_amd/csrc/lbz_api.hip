@@ -270,18 +270,28 @@ static int timed_end(lbzamd_ctx *c, size_t *nbev, hipStream_t s)
  * listed primaries only): partition (one workgroup per block), then batches, tie lists, the deep-tie rounds --
  * one launch per doubling depth, every (block, segment) a workgroup (k_bwt.hip) -- and the origin pointers.     */
 static void launch_sort(lbzamd_ctx *c, hipStream_t q, u32 first, u32 count, u32 nblk, u8 *ws, u8 *wsp, const u32 *lst,
-                        int phase /* 0 = partition, 1 = batches, 2 = deep ties */)
+                        int phase /* 0 = partition, 1 = batches, 2 = deep ties */, bool overlapped = false /* other rounds run beside this one */)
 {
   /* workgroups per block in the sorting kernels: more of them when the round has fewer blocks than the device has CUs -- the
      caller then waits for a block's chain of launches, and every launch is as long as its longest segment */
   const u32 segs = count <= c->ncus ? LBZ_BWT_MAXSEGS : LBZ_BWT_SEGS;
-  if (phase == 0) {
-    if (count <= c->ncus)      /* fewer blocks than CUs: sixteen waves per block instead of four (k_bwt_wide.o) */
-      hipLaunchKernelGGL(k_bwt_part_w, dim3(nblk), dim3(1024), 0, q, (const u8 *)c->T, c->meta, c->L,
-                         first, count, ws, (u64)c->slot_bytes, wsp, (u64)c->spill_bytes, lst, segs);
-    else
-      hipLaunchKernelGGL(k_bwt_part, dim3(nblk), dim3(LBZ_BWT_WG), 0, q, (const u8 *)c->T, c->meta, c->L,
-                         first, count, ws, (u64)c->slot_bytes, wsp, (u64)c->spill_bytes, lst, segs);
+  if (phase == 0 && overlapped && count > c->ncus && !getenv("LBZAMD_PARTS")) {
+    /* big rounds side by side on several streams: one workgroup per block, every pass in one launch (k_bwt.hip) */
+    hipLaunchKernelGGL(k_bwt_part, dim3(nblk), dim3(LBZ_BWT_WG), 0, q, (const u8 *)c->T, c->meta, c->L,
+                       first, count, ws, (u64)c->slot_bytes, wsp, (u64)c->spill_bytes, lst, segs);
+  } else if (phase == 0) {
+    /* the partition: more workgroups per block the fewer blocks the round has (a block's passes are what a small input
+       waits for; a full device needs only enough workgroups to fill it evenly) */
+    static const int forced = getenv("LBZAMD_PARTS") ? atoi(getenv("LBZAMD_PARTS")) : 0;      /* (tuning) */
+    const u32 parts = forced > 0 && forced <= 16 ? (u32)forced : (count <= c->ncus / 2u ? 16u : (count <= 2u * c->ncus ? 8u : 4u));
+    const dim3 g(lbz_seg_grid(nblk, parts));
+    hipLaunchKernelGGL(k_bwt_hist, g, dim3(LBZ_BWT_WG), 0, q, (const u8 *)c->T, c->meta, c->L,
+                       first, count, nblk, parts, ws, (u64)c->slot_bytes, wsp, (u64)c->spill_bytes, lst);
+    for (u32 pass = 0; pass < 4u; pass++)
+      hipLaunchKernelGGL(k_bwt_scat, g, dim3(LBZ_BWT_WG), 0, q, (const u8 *)c->T, c->meta, c->L,
+                         first, count, nblk, parts, ws, (u64)c->slot_bytes, wsp, (u64)c->spill_bytes, lst, pass);
+    hipLaunchKernelGGL(k_bwt_segs, dim3(nblk), dim3(LBZ_BWT_WG), 0, q, c->meta, c->L,
+                       first, count, segs, ws, (u64)c->slot_bytes, wsp, (u64)c->spill_bytes, lst);
   } else if (phase == 1) {
     hipLaunchKernelGGL(k_bwt_batch, dim3(lbz_seg_grid(nblk, segs)), dim3(LBZ_BWT_WG), 0, q, (const u8 *)c->T, c->B, c->meta, c->L,
                        first, count, nblk, segs, ws, (u64)c->slot_bytes, wsp, (u64)c->spill_bytes, lst);
@@ -410,7 +420,7 @@ static int run_chunk(lbzamd_ctx *c, const u8 *d_in, size_t len, uint32_t nsl, in
         if (timed_end(c, &nbev, q)) return -1;
       }
       if (timed_begin(c, &nbev, 0, q)) return -1;
-      launch_sort(c, q, first, count, grid, ws, wsp, nullptr, 0);
+      launch_sort(c, q, first, count, grid, ws, wsp, nullptr, 0, two);
       if (timed_end(c, &nbev, q) || timed_begin(c, &nbev, 1, q)) return -1;
       launch_sort(c, q, first, count, grid, ws, wsp, nullptr, 1);
       if (timed_end(c, &nbev, q) || timed_begin(c, &nbev, 2, q)) return -1;

@@ -59,11 +59,17 @@ __global__ void k_collect_seq(const u8 *in, u64 in_len, lbz_layout L, u8 *Tbase,
 __global__ void k_seq_tiles(const u8 *in, u64 in_len, u32 *last_head, u32 *first_head, u32 *emits);
 __global__ void k_seq_prefix(const u32 *last_head, const u32 *first_head, const u32 *emits, u32 ntiles, u32 a0,
                              unsigned long long *carry, unsigned long long *gpre);
+/* the partition: a block's rows dealt over `parts` workgroups (ranges of a pass's input), one launch per pass; grid =
+ * lbz_seg_grid(nblk, parts).  k_bwt_segs (one workgroup per block) fixes the segments for the kernels behind it. */
+__global__ void k_bwt_hist(const u8 *Tbase, lbz_block_meta *meta, lbz_layout L, u32 first, u32 count, u32 nblk, u32 parts,
+                           u8 *ws, u64 slot_bytes, u8 *ws_spill, u64 spill_bytes, const u32 *slabs);
+__global__ void k_bwt_scat(const u8 *Tbase, lbz_block_meta *meta, lbz_layout L, u32 first, u32 count, u32 nblk, u32 parts,
+                           u8 *ws, u64 slot_bytes, u8 *ws_spill, u64 spill_bytes, const u32 *slabs, u32 pass);
+/* ... and the same partition as one workgroup per block, every pass in one launch: rounds that overlap on several streams */
 __global__ void k_bwt_part(const u8 *Tbase, lbz_block_meta *meta, lbz_layout L, u32 first, u32 count,
                            u8 *ws, u64 slot_bytes, u8 *ws_spill, u64 spill_bytes, const u32 *slabs, u32 segs);
-/* the same kernel with 1024-thread workgroups (k_bwt.hip built a second time with LBZ_BWT_WIDE): rounds of few blocks */
-__global__ void k_bwt_part_w(const u8 *Tbase, lbz_block_meta *meta, lbz_layout L, u32 first, u32 count,
-                             u8 *ws, u64 slot_bytes, u8 *ws_spill, u64 spill_bytes, const u32 *slabs, u32 segs);
+__global__ void k_bwt_segs(lbz_block_meta *meta, lbz_layout L, u32 first, u32 count, u32 segs,
+                           u8 *ws, u64 slot_bytes, u8 *ws_spill, u64 spill_bytes, const u32 *slabs);
 /* from here on a block's sorted rows are dealt over LBZ_BWT_SEGS segment workgroups (k_bwt.hip, "segments"):
  * grid = lbz_seg_grid(nblk), nblk = blocks of the round (2 * count, or count when only primaries are listed) */
 __global__ void k_bwt_batch(const u8 *Tbase, u8 *Bbase, lbz_block_meta *meta, lbz_layout L, u32 first,

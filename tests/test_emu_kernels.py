@@ -58,11 +58,13 @@ def test_streams_multi_slab_spill_chunked(emu):
 
 
 def test_rounds_of_many_and_of_few_blocks(emu):
-    """Rounds with more blocks than the (emulated, 8-CU) device has CUs take 16 segment workgroups per block and the
-    256-thread partition; smaller rounds 32 and the 1024-thread partition (lbz_api.hip: launch_sort).  Same stream."""
-    data = bytes(gen("wiki", 1_130_000, 6))                       # 12 slabs at -1
+    """Rounds with more blocks than the (emulated, 8-CU) device has CUs take 16 segment workgroups per block, smaller
+    rounds 32; the partition runs a launch per pass with 4-16 workgroups per block (k_bwt_hist / k_bwt_scat / k_bwt_segs),
+    or -- rounds of more blocks than CUs side by side on several streams -- as one workgroup per block (k_bwt_part)
+    (lbz_api.hip: launch_sort).  Same stream."""
+    data = bytes(gen("wiki", 1_130_000, 6) + gen("text", 520_000, 8) + gen("rand", 400_000, 9))       # 21 slabs at -1
     want = L.orc_compress(data, 1)
-    for max_slabs, nslots in ((12, 12), (12, 4)):
+    for max_slabs, nslots in ((21, 21), (21, 4), (21, 10)):
         with emu.context(1, max_slabs, nslots) as ctx:
             assert ctx.compress(data) == want, (max_slabs, nslots)
 

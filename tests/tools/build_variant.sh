@@ -7,7 +7,6 @@ mkdir -p variants/$1
 for f in k_collect k_bwt k_mtf k_encode k_finish k_decode lbz_api; do
   /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -I. -I../../include -Wno-unused-function -Wno-inline-asm $2 -c $f.hip -o variants/$1/$f.o &
 done
-/opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -I. -I../../include -Wno-unused-function -Wno-inline-asm $2 -DLBZ_BWT_WIDE -c k_bwt.hip -o variants/$1/k_bwt_wide.o &
 wait
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o variants/$1.so variants/$1/*.o
 rm -rf variants/$1
