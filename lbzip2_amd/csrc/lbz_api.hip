@@ -275,8 +275,10 @@ static void launch_sort(lbzamd_ctx *c, hipStream_t q, u32 first, u32 count, u32 
   /* workgroups per block in the sorting kernels: more of them when the round has fewer blocks than the device has CUs -- the
      caller then waits for a block's chain of launches, and every launch is as long as its longest segment */
   const u32 segs = count <= c->ncus ? LBZ_BWT_MAXSEGS : LBZ_BWT_SEGS;
-  if (phase == 0 && overlapped && count > c->ncus && !getenv("LBZAMD_PARTS")) {
-    /* big rounds side by side on several streams: one workgroup per block, every pass in one launch (k_bwt.hip) */
+  if (phase == 0 && (count > 2u * c->ncus || (overlapped && count > c->ncus)) && !getenv("LBZAMD_PARTS")) {
+    /* rounds that fill the device by their number of blocks, or big rounds side by side on several streams: one workgroup
+       per block, every pass in one launch (k_bwt.hip: 27.5 ms for 1112 blocks against 35 for the launch-per-pass form, which
+       pays its wider LDS footprint and a second read of the text; 371 blocks alone: 14.0 against 10.7) */
     hipLaunchKernelGGL(k_bwt_part, dim3(nblk), dim3(LBZ_BWT_WG), 0, q, (const u8 *)c->T, c->meta, c->L,
                        first, count, ws, (u64)c->slot_bytes, wsp, (u64)c->spill_bytes, lst, segs);
   } else if (phase == 0) {
