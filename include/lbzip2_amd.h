@@ -33,6 +33,7 @@
 #define LBZIP2_AMD_H
 
 #include <stddef.h>
+#include <stdbool.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -187,6 +188,56 @@ int  lbzamd_decompress_alloc(lbzamd_dctx *ctx, const uint8_t *in, size_t len, ui
 void lbzamd_free(void *p);
 int  lbzamd_decompress_host(lbzamd_dctx *ctx, const uint8_t *in, size_t len, uint8_t *out, size_t out_cap, size_t *out_len);
 int  lbzamd_dget_stats(lbzamd_dctx *ctx, lbzamd_dstats *st);
+
+/* ------------------------------------------------------------------ (D) the inverse path's work-unit interface
+ * reference src/decode.h:38-81, verbatim in its types and prototypes: one compressed block of one worker thread --
+ * what src/expand.c:547-690 (do_retrieve / do_emit) drives.  Link the reference's expand.c, parse.c and the rest of
+ * its program against this library instead of decode.c and `lbzip2 -d` decodes its blocks on the GPU
+ * (tests/test_dropin_link.py).
+ *   retrieve()  takes the block's bits out of the caller's bitstream (src/decode.c:519).  Where a block ends is known
+ *               only once it is decoded, so the bits the caller has are gathered and the block is decoded on the device
+ *               (prefix codes, move-to-front, inverse BWT, inverse RLE1: k_dblock, k_demit); if they run out before the
+ *               block does, MORE is returned as the reference does and the next call carries on with more input.  On
+ *               OK the bitstream stands behind the block's last code.
+ *   decode()    (src/decode.c:852: the counting sort of the inverse BWT) has nothing left to do.
+ *   emit()      hands the decoded bytes out, as many as the caller's buffer takes per call (MORE until the last), and
+ *               leaves the block's CRC in ds->crc (src/decode.c:944-1146).
+ * Error values are the reference's enum error (src/common.h:54-76).                                                  */
+struct in_blk;
+struct bitstream {                  /* decode.h:38-45 */
+  unsigned live;
+  uint64_t buff;
+  struct in_blk *block;
+  const uint32_t *data;
+  const uint32_t *limit;
+  bool eof;
+};
+struct retriever_internal_state;
+struct decoder_state {              /* decode.h:48-66 */
+  struct retriever_internal_state *internal_state;
+  bool rand;
+  unsigned bwt_idx;
+  unsigned block_size;
+  uint32_t crc;
+  uint32_t ftab[256];
+  uint32_t *tt;
+  int rle_state;
+  uint32_t rle_crc;
+  uint32_t rle_index;
+  uint32_t rle_avail;
+  uint8_t rle_char;
+  uint8_t rle_prev;
+};
+void decoder_init(struct decoder_state *ds);
+void decoder_free(struct decoder_state *ds);
+int  retrieve(struct decoder_state *ds, struct bitstream *bs);
+void decode(struct decoder_state *ds);
+int  emit(struct decoder_state *ds, void *buf, size_t *buf_sz);
+void lbzamd_decoder_init(struct decoder_state *ds);
+void lbzamd_decoder_free(struct decoder_state *ds);
+int  lbzamd_retrieve(struct decoder_state *ds, struct bitstream *bs);
+void lbzamd_decode(struct decoder_state *ds);
+int  lbzamd_emit(struct decoder_state *ds, void *buf, size_t *buf_sz);
 
 /* ---- stage access for parity tests (valid for the last chunk of the last call) ---- */
 typedef struct lbzamd_block_info {

@@ -1495,3 +1495,175 @@ extern "C" void encoder_init(encoder_state *e, unsigned long mbs, unsigned cf) {
 extern "C" int collect(encoder_state *e, const uint8_t *buf, size_t *buf_sz) { return lbzamd_collect(e, buf, buf_sz); }
 extern "C" size_t encode(encoder_state *e, uint32_t *crc) { return lbzamd_encode(e, crc); }
 extern "C" void *transmit(encoder_state *e, void *buf) { return lbzamd_transmit(e, buf); }
+
+/* ===================================================================== (D) decode.h's work-unit interface
+ * retrieve / decode / emit on ONE block of one worker thread, as src/expand.c:547-690 drives them.  A state leases a
+ * one-block decoder context (its own stream and arrays) from a free list, so the worker threads' blocks decode side by
+ * side on the device.                                                                                               */
+#include <arpa/inet.h>
+namespace {
+enum {                                    /* src/common.h:54-76 */
+  WD_OK = 0, WD_MORE, WD_FINISH, WD_ERR_MAGIC, WD_ERR_HEADER, WD_ERR_BITMAP, WD_ERR_TREES, WD_ERR_GROUPS, WD_ERR_SELECTOR,
+  WD_ERR_DELTA, WD_ERR_PREFIX, WD_ERR_INCOMPLT, WD_ERR_EMPTY, WD_ERR_UNTERM, WD_ERR_RUNLEN, WD_ERR_BLKCRC, WD_ERR_STRMCRC,
+  WD_ERR_OVERFLOW, WD_ERR_BWTIDX, WD_ERR_EOF
+};
+struct wd_state {
+  lbzamd_dctx *c = nullptr;
+  std::vector<uint8_t> bits;              /* 4 zero bytes (where k_dblock reads a stored CRC) + the block's bits, first bit in the top of byte 4 */
+  uint64_t nbits = 0;                     /* the block's bits gathered so far */
+  uint64_t acc = 0;
+  unsigned nacc = 0;                      /* bits of acc not yet in `bits` (< 8) */
+  std::vector<uint8_t> out;               /* the decoded block */
+  size_t pos = 0;                         /* bytes emit() has handed out */
+  uint32_t crc = 0;
+};
+std::mutex g_wd_mu;
+std::vector<lbzamd_dctx *> g_wd_free;
+
+void wd_put(wd_state *st, uint64_t v, unsigned n)       /* n <= 32 bits, right-aligned in v */
+{
+  st->acc = (st->acc << n) | (v & ((n < 64u ? (1ull << n) : 0ull) - 1ull));
+  st->nacc += n;
+  st->nbits += n;
+  while (st->nacc >= 8u) { st->bits.push_back((uint8_t)(st->acc >> (st->nacc - 8u))); st->nacc -= 8u; }
+}
+int wd_error(uint32_t code, uint32_t nblock)
+{
+  switch (code) {
+    case 1: return WD_ERR_BITMAP;
+    case 2: return WD_ERR_TREES;
+    case 3: return WD_ERR_SELECTOR;
+    case 4: return WD_ERR_DELTA;
+    case 5: return WD_ERR_UNTERM;
+    case 6: return WD_ERR_PREFIX;
+    case 8: return WD_ERR_OVERFLOW;
+    case 9: return nblock == 0u ? WD_ERR_EMPTY : WD_ERR_BWTIDX;
+    default: return WD_ERR_PREFIX;
+  }
+}
+}  // namespace
+
+extern "C" void lbzamd_decoder_init(struct decoder_state *ds)
+{
+  wd_state *st = new wd_state;
+  {
+    std::lock_guard<std::mutex> lk(g_wd_mu);
+    if (!g_wd_free.empty()) { st->c = g_wd_free.back(); g_wd_free.pop_back(); }
+  }
+  if (!st->c && lbzamd_dcreate(&st->c, -1, 1u)) die("decoder_init");
+  st->bits.assign(4u, 0u);
+  memset(ds, 0, sizeof *ds);
+  ds->internal_state = reinterpret_cast<struct retriever_internal_state *>(st);
+}
+
+extern "C" void lbzamd_decoder_free(struct decoder_state *ds)
+{
+  wd_state *st = reinterpret_cast<wd_state *>(ds->internal_state);
+  if (!st) return;
+  if (st->c) { std::lock_guard<std::mutex> lk(g_wd_mu); g_wd_free.push_back(st->c); }
+  delete st;
+  ds->internal_state = nullptr;
+}
+
+extern "C" int lbzamd_retrieve(struct decoder_state *ds, struct bitstream *bs)
+{
+  wd_state *st = reinterpret_cast<wd_state *>(ds->internal_state);
+  if (!st || !bs) { g_err = "retrieve(): bad decoder state"; die("retrieve"); }
+  lbzamd_dctx *c = st->c;
+  HIPDIE(hipSetDevice(c->device), "retrieve");
+  /* everything the caller has: the bits left in its buffer word, then whole words (big-endian in memory: decode.c:404) */
+  const unsigned live0 = bs->live;
+  const uint64_t buff0 = bs->buff;
+  const uint32_t *data0 = bs->data;
+  const uint64_t before = st->nbits;
+  if (live0 > 32u) { wd_put(st, buff0 >> 32, 32u); wd_put(st, (buff0 << 32) >> (64u - (live0 - 32u)), live0 - 32u); }
+  else if (live0) wd_put(st, buff0 >> (64u - live0), live0);
+  for (const uint32_t *p = data0; p != bs->limit; p++) wd_put(st, ntohl(*p), 32u);
+  /* decode what there is */
+  std::vector<uint8_t> in(st->bits);
+  if (st->nacc) in.push_back((uint8_t)(st->acc << (8u - st->nacc)));
+  const uint64_t avail = 32u + st->nbits;
+  in.resize(in.size() + 16u, 0u);
+  if (in.size() + 16u > c->d_in_cap) {
+    (void)hipFree(c->d_in); c->d_in = nullptr; c->d_in_cap = 0;
+    HIPDIE(hipMalloc((void **)&c->d_in, in.size() * 2u + 4096u), "retrieve");
+    c->d_in_cap = in.size() * 2u + 4096u - 16u;
+  }
+  lbz_dblock rec{};
+  rec.bit_start = 0;
+  rec.max_block = LBZ_MAX_BLOCK;
+  HIPDIE(hipMemcpyAsync(c->d_in, in.data(), in.size(), hipMemcpyHostToDevice, c->q), "retrieve");
+  HIPDIE(hipMemcpyAsync(c->blocks, &rec, sizeof rec, hipMemcpyHostToDevice, c->q), "retrieve");
+  hipLaunchKernelGGL(k_dblock_w, dim3(1), dim3(1024), 0, c->q, (const u8 *)c->d_in, (u64)in.size() - 16u, c->blocks, 1u, c->tt8, c->tt, c->W, c->pinfo, c->X, c->cap);
+  HIPDIE(hipMemcpyAsync(&rec, c->blocks, sizeof rec, hipMemcpyDeviceToHost, c->q), "retrieve");
+  HIPDIE(hipStreamSynchronize(c->q), "retrieve");
+  HIPDIE(hipGetLastError(), "retrieve");
+  /* Ran past the bits there are (or stopped on an error within a word of their end, where what it read were pad bits)?
+     Then the block is not all here: decode.c's NEED() -- everything is taken, MORE, or ERR_EOF at the end of the input. */
+  const bool past = rec.bit_used > avail || (rec.err && rec.err != 11u && rec.bit_used + 64u > avail);
+  if (past) {
+    bs->live = 0; bs->buff = 0; bs->data = bs->limit;
+    return bs->eof ? WD_ERR_EOF : WD_MORE;
+  }
+  /* the caller's stream stands behind the block's last code */
+  {
+    const uint64_t used = rec.bit_used - 32u - before;         /* bits of THIS call's input */
+    if (used <= live0) { bs->buff = used < 64u ? buff0 << used : 0ull; bs->live = live0 - (unsigned)used; bs->data = data0; }
+    else {
+      const uint64_t c2 = used - live0;
+      const uint32_t *p = data0 + (c2 >> 5);
+      const unsigned rem = (unsigned)(c2 & 31u);
+      if (rem) { bs->buff = ((uint64_t)ntohl(*p) << 32) << rem; bs->live = 32u - rem; p++; }
+      else { bs->buff = 0; bs->live = 0; }
+      bs->data = p;
+    }
+  }
+  if (rec.err && rec.err != 11u) return wd_error(rec.err, rec.nblock);
+  ds->rand = rec.randomised != 0u;
+  ds->bwt_idx = rec.orig_ptr;
+  ds->block_size = rec.nblock;
+  /* the bytes: k_demit into the context's output buffer, then to the host */
+  const size_t n = rec.out_len;
+  if (n > c->d_out_cap) {
+    (void)hipFree(c->d_out); c->d_out = nullptr; c->d_out_cap = 0;
+    HIPDIE(hipMalloc((void **)&c->d_out, n + n / 2u + 4096u), "retrieve");
+    c->d_out_cap = n + n / 2u + 3840u;
+  }
+  rec.err = 0;                                                 /* (11: the stand-in CRC does not match, of course) */
+  rec.out_off = 0;
+  st->out.resize(n);
+  if (n) {
+    HIPDIE(hipMemcpyAsync(c->blocks, &rec, sizeof rec, hipMemcpyHostToDevice, c->q), "retrieve");
+    hipLaunchKernelGGL(k_demit, dim3(8u), dim3(256), 0, c->q, (const lbz_dblock *)c->blocks, 1u, (const u8 *)c->W, (const u32 *)c->pinfo, c->d_out, (u64)c->d_out_cap, c->cap);
+    HIPDIE(hipMemcpyAsync(st->out.data(), c->d_out, n, hipMemcpyDeviceToHost, c->q), "retrieve");
+    HIPDIE(hipStreamSynchronize(c->q), "retrieve");
+    HIPDIE(hipGetLastError(), "retrieve");
+  }
+  st->crc = rec.computed_crc;
+  st->pos = 0;
+  std::vector<uint8_t>().swap(st->bits);
+  return WD_OK;
+}
+
+extern "C" void lbzamd_decode(struct decoder_state *ds) { (void)ds; }     /* the inverse BWT ran on the device with the codes */
+
+extern "C" int lbzamd_emit(struct decoder_state *ds, void *buf, size_t *buf_sz)
+{
+  wd_state *st = reinterpret_cast<wd_state *>(ds->internal_state);
+  if (!st || !buf || !buf_sz) { g_err = "emit(): bad decoder state"; die("emit"); }
+  const size_t left = st->out.size() - st->pos;
+  const size_t n = left < *buf_sz ? left : *buf_sz;
+  memcpy(buf, st->out.data() + st->pos, n);
+  st->pos += n;
+  *buf_sz -= n;
+  if (st->pos < st->out.size()) return WD_MORE;
+  ds->crc = st->crc;                                           /* decode.c:1141 */
+  return WD_OK;
+}
+
+/* the reference's own symbol names (decode.h:77-81) */
+extern "C" void decoder_init(struct decoder_state *ds) { lbzamd_decoder_init(ds); }
+extern "C" void decoder_free(struct decoder_state *ds) { lbzamd_decoder_free(ds); }
+extern "C" int retrieve(struct decoder_state *ds, struct bitstream *bs) { return lbzamd_retrieve(ds, bs); }
+extern "C" void decode(struct decoder_state *ds) { lbzamd_decode(ds); }
+extern "C" int emit(struct decoder_state *ds, void *buf, size_t *buf_sz) { return lbzamd_emit(ds, buf, buf_sz); }

@@ -33,6 +33,7 @@ def programs():
     subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "tests", "emu"), "WG=1024"])
     _make("stock")
     _make("dropin", "DROPIN=../tests/emu/_build/liblbzamd_emu_1024.so", "OUT=lbzip2_dropin_emu")
+    _make("dropin_d", "DROPIN=../tests/emu/_build/liblbzamd_emu_1024.so", "OUT=lbzip2_dropin_d_emu")
     return os.path.join(REFDIR, "lbzip2_stock"), os.path.join(REFDIR, "lbzip2_dropin_emu")
 
 
@@ -77,6 +78,54 @@ def test_reference_cli_sequential_mode(programs, level, workers, kind, n, seed):
 def test_empty_input_through_the_cli(programs):
     stock, dropin = programs
     assert _run(dropin, ["-9"], b"", env={"LBZAMD_POOL_SLABS": "2"}) == _run(stock, ["-9"], b"")
+
+
+def test_reference_cli_decompresses_through_the_library(programs):
+    """The decoder's work-unit boundary (decode.h:77-81): the reference's program WITHOUT decode.c -- expand.c's scheduler,
+    parse.c's header parser and bit stream -- linked against the library (oracle/Makefile: dropin_d).  `lbzip2 -d` then
+    takes its blocks through decoder_init / retrieve / decode / emit / decoder_free on the (here: emulated) device: same
+    bytes as the stock program for its own streams at several levels and worker counts, for bzip2's (bit-aligned blocks,
+    several streams in a file), for trailing garbage; the same refusal for a damaged block and a truncated file."""
+    import bz2
+    stock = programs[0]
+    dd = os.path.join(REFDIR, "lbzip2_dropin_d_emu")
+    env = {"LBZ_EMU_THREADS": "2"}
+    cases = []
+    for kind, n, seed, lvl in (("wiki", 250000, 2, 1), ("runs", 210000, 9, 2), ("rand", 120000, 3, 9)):
+        data = bytes(gen(kind, n, seed))
+        cases.append((data, _run(stock, [f"-{lvl}", "-n", "2"], data)))
+    d2 = bytes(gen("wiki", 130000, 5))
+    cases.append((d2 + d2[:70000], bz2.compress(d2, 1) + bz2.compress(d2[:70000], 9)))          # bzip2's own encoder, two streams
+    cases.append((d2, bz2.compress(d2, 1) + b"\0garbage behind the stream"))
+    cases.append((b"", _run(stock, ["-9"], b"")))
+    for workers in ("2",):
+        for want, z in cases:
+            p = subprocess.run([dd, "-d", "-n", workers], input=z, capture_output=True, timeout=900, env=dict(os.environ, **env))
+            q = subprocess.run([stock, "-d", "-n", workers], input=z, capture_output=True, timeout=900)
+            assert p.returncode == q.returncode and p.stdout == q.stdout, (workers, len(z), p.stderr[-300:])
+            assert q.stdout == want or q.returncode != 0
+    # damage: a flipped payload bit (block CRC), a truncated file
+    z = bytearray(cases[0][1]); z[len(z) // 2] ^= 0x10
+    for bad in (bytes(z), cases[0][1][:len(cases[0][1]) * 2 // 3]):
+        p = subprocess.run([dd, "-d"], input=bad, capture_output=True, timeout=900, env=dict(os.environ, **env))
+        q = subprocess.run([stock, "-d"], input=bad, capture_output=True, timeout=900)
+        assert q.returncode != 0 and p.returncode == q.returncode, (p.returncode, q.returncode, p.stderr[-300:], q.stderr[-300:])
+
+
+@pytest.mark.gpu
+def test_reference_cli_decompresses_on_the_gpu():
+    """oracle/_ref/lbzip2_dropin_d_gpu = the reference's program without encode.c, divbwt.c AND decode.c, linked against
+    lbzip2_amd/csrc/liblbzamd.so: `lbzip2 -d` with 16 worker threads decodes the enwik8-sized stand-in's stream (the
+    reference fixture, written by the same program's compressor side) block by block on the MI355X."""
+    exe = os.path.join(REFDIR, "lbzip2_dropin_d_gpu")
+    if not os.path.exists(exe):
+        pytest.skip("oracle/_ref/lbzip2_dropin_d_gpu not built (needs the reference sources at build time)")
+    rec = [r for r in bench_fixtures() if r["kind"] == "wiki" and r["n"] == 100_000_000][0]
+    data = bytes(gen(rec["kind"], rec["n"], rec["seed"]))
+    z = _run(exe, ["-9", "-n", "64"], data, timeout=300)
+    assert len(z) == rec["out_len"] and hashlib.md5(z).hexdigest() == rec["ref_md5"]
+    back = _run(exe, ["-d", "-n", "16"], z, timeout=600)
+    assert back == data
 
 
 @pytest.mark.gpu
