@@ -813,6 +813,9 @@ struct lbzamd_dctx {
   size_t d_in_cap = 0, d_out_cap = 0;
   uint32_t marks_cap = 0;
   bool grow_out = false;                     /* lbzamd_decompress_alloc: the output buffer (d_out) grows with what the blocks turn out to hold */
+  u8 *h_in = nullptr, *h_out = nullptr;      /* the work-unit interface: page-locked staging of one block's bits and bytes (copies of pageable
+                                                memory wait for the whole device, i.e. for every other worker thread's block) */
+  size_t h_in_cap = 0, h_out_cap = 0;
   lbzamd_dstats stats{};
 };
 
@@ -823,6 +826,8 @@ extern "C" void lbzamd_ddestroy(lbzamd_dctx *c)
   (void)hipFree(c->pinfo); (void)hipFree(c->nmarks); (void)hipFree(c->marks); (void)hipFree(c->blocks); (void)hipFree(c->d_in); (void)hipFree(c->d_out);
   for (auto &e : c->ev) if (e) (void)hipEventDestroy(e);
   if (c->q) (void)hipStreamDestroy(c->q);
+  if (c->h_in) (void)hipHostFree(c->h_in);
+  if (c->h_out) (void)hipHostFree(c->h_out);
   delete c;
 }
 
@@ -1497,9 +1502,10 @@ extern "C" size_t encode(encoder_state *e, uint32_t *crc) { return lbzamd_encode
 extern "C" void *transmit(encoder_state *e, void *buf) { return lbzamd_transmit(e, buf); }
 
 /* ===================================================================== (D) decode.h's work-unit interface
- * retrieve / decode / emit on ONE block of one worker thread, as src/expand.c:547-690 drives them.  A state leases a
- * one-block decoder context (its own stream and arrays) from a free list, so the worker threads' blocks decode side by
- * side on the device.                                                                                               */
+ * retrieve / decode / emit on ONE block of one worker thread, as src/expand.c:547-690 drives them.  One block per launch --
+ * what the call sequence suggests -- measured 70 MB/s with any number of threads (launches of different host threads'
+ * streams do not overlap the way one launch over many blocks does); so the threads' requests are COMBINED, as the encoder's
+ * are: the first thread to find no leader decodes every posted block in one k_dblock / k_demit pass and wakes the rest. */
 #include <arpa/inet.h>
 namespace {
 enum {                                    /* src/common.h:54-76 */
@@ -1508,7 +1514,6 @@ enum {                                    /* src/common.h:54-76 */
   WD_ERR_OVERFLOW, WD_ERR_BWTIDX, WD_ERR_EOF
 };
 struct wd_state {
-  lbzamd_dctx *c = nullptr;
   std::vector<uint8_t> bits;              /* 4 zero bytes (where k_dblock reads a stored CRC) + the block's bits, first bit in the top of byte 4 */
   uint64_t nbits = 0;                     /* the block's bits gathered so far */
   uint64_t acc = 0;
@@ -1517,12 +1522,27 @@ struct wd_state {
   size_t pos = 0;                         /* bytes emit() has handed out */
   uint32_t crc = 0;
 };
-std::mutex g_wd_mu;
-std::vector<lbzamd_dctx *> g_wd_free;
+struct wd_req {
+  wd_state *st;
+  size_t nbytes;                          /* bytes of st->bits (+ the partial byte) the decoder may read */
+  uint8_t tail;                           /* the partial byte, if st->nacc */
+  uint64_t avail;                         /* bits there are (the 32 stand-in bits included) */
+  lbz_dblock rec;
+  bool past = false, done = false;
+};
+struct wd_pool {
+  std::mutex mu;
+  std::condition_variable cv;
+  std::vector<wd_req *> queue;
+  bool leader = false;
+  lbzamd_dctx *c = nullptr;
+};
+wd_pool g_wd;
+const unsigned WD_BATCH = 256u;
 
 void wd_put(wd_state *st, uint64_t v, unsigned n)       /* n <= 32 bits, right-aligned in v */
 {
-  st->acc = (st->acc << n) | (v & ((n < 64u ? (1ull << n) : 0ull) - 1ull));
+  st->acc = (st->acc << n) | (v & ((1ull << n) - 1ull));
   st->nacc += n;
   st->nbits += n;
   while (st->nacc >= 8u) { st->bits.push_back((uint8_t)(st->acc >> (st->nacc - 8u))); st->nacc -= 8u; }
@@ -1541,16 +1561,116 @@ int wd_error(uint32_t code, uint32_t nblock)
     default: return WD_ERR_PREFIX;
   }
 }
+void wd_grow_host(u8 **p, size_t *cap, size_t want)
+{
+  if (want <= *cap) return;
+  if (*p) (void)hipHostFree(*p);
+  *p = nullptr; *cap = 0;
+  want = (want + want / 2u + 65536u + 255u) & ~(size_t)255u;
+  HIPDIE(hipHostMalloc((void **)p, want, hipHostMallocDefault), "decoder staging");
+  *cap = want;
+}
+void wd_grow_dev(u8 **p, size_t *cap, size_t want)
+{
+  if (want <= *cap) return;
+  (void)hipFree(*p);
+  *p = nullptr; *cap = 0;
+  want = want + want / 2u + 65536u;
+  HIPDIE(hipMalloc((void **)p, want + 256u), "decoder buffers");
+  *cap = want;
+}
+/* one pass over the posted blocks: bits in, k_dblock, the records back; the bytes of those that decoded: k_demit, out */
+void wd_round(const std::vector<wd_req *> &batch)
+{
+  if (!g_wd.c && lbzamd_dcreate(&g_wd.c, -1, WD_BATCH)) die("decoder_init");
+  lbzamd_dctx *c = g_wd.c;
+  HIPDIE(hipSetDevice(c->device), "retrieve");
+  const u32 nb = (u32)batch.size();
+  std::vector<size_t> off(nb);
+  size_t total = 0;
+  for (u32 i = 0; i < nb; i++) { off[i] = total; total += (batch[i]->nbytes + 16u + 15u) & ~(size_t)15u; }
+  const size_t recs = (size_t)nb * sizeof(lbz_dblock);
+  wd_grow_host(&c->h_in, &c->h_in_cap, total + recs + 256u);
+  wd_grow_dev(&c->d_in, &c->d_in_cap, total + 16u);
+  lbz_dblock *hrec = reinterpret_cast<lbz_dblock *>(c->h_in + ((total + 255u) & ~(size_t)255u));
+  for (u32 i = 0; i < nb; i++) {
+    wd_req *r = batch[i];
+    u8 *dst = c->h_in + off[i];
+    const size_t whole = r->st->bits.size();
+    memcpy(dst, r->st->bits.data(), whole);
+    if (r->nbytes > whole) dst[whole] = r->tail;
+    memset(dst + r->nbytes, 0, ((r->nbytes + 16u + 15u) & ~(size_t)15u) - r->nbytes);
+    lbz_dblock rec{};
+    rec.bit_start = (u64)off[i] * 8u;
+    rec.max_block = LBZ_MAX_BLOCK;
+    hrec[i] = rec;
+  }
+  hipStream_t q = c->q;
+  HIPDIE(hipMemcpyAsync(c->d_in, c->h_in, total, hipMemcpyHostToDevice, q), "retrieve");
+  HIPDIE(hipMemcpyAsync(c->blocks, hrec, recs, hipMemcpyHostToDevice, q), "retrieve");
+  if (nb <= c->ncus) hipLaunchKernelGGL(k_dblock_w, dim3(nb), dim3(1024), 0, q, (const u8 *)c->d_in, (u64)total, c->blocks, nb, c->tt8, c->tt, c->W, c->pinfo, c->X, c->cap);
+  else hipLaunchKernelGGL(k_dblock_m, dim3(nb), dim3(512), 0, q, (const u8 *)c->d_in, (u64)total, c->blocks, nb, c->tt8, c->tt, c->W, c->pinfo, c->X, c->cap);
+  HIPDIE(hipMemcpyAsync(hrec, c->blocks, recs, hipMemcpyDeviceToHost, q), "retrieve");
+  HIPDIE(hipStreamSynchronize(q), "retrieve");
+  HIPDIE(hipGetLastError(), "retrieve");
+  /* Ran past the bits there are (or stopped on an error within a word of their end, where what it read were pad bits)?
+     Then the block is not all here: decode.c's NEED(). */
+  size_t outb = 0;
+  for (u32 i = 0; i < nb; i++) {
+    wd_req *r = batch[i];
+    lbz_dblock &rec = hrec[i];
+    const uint64_t used = rec.bit_used - (u64)off[i] * 8u;
+    r->past = used > r->avail || (rec.err && rec.err != 11u && used + 64u > r->avail);
+    rec.bit_used = used;
+    if (r->past || (rec.err && rec.err != 11u)) { rec.err = rec.err ? rec.err : 99u; rec.out_len = 0; r->rec = rec; continue; }
+    rec.err = 0;                                                 /* (11: the stand-in CRC does not match, of course) */
+    rec.out_off = outb;
+    outb += rec.out_len;
+    r->rec = rec;
+  }
+  if (outb) {
+    wd_grow_dev(&c->d_out, &c->d_out_cap, outb);
+    wd_grow_host(&c->h_out, &c->h_out_cap, outb + 256u);
+    HIPDIE(hipMemcpyAsync(c->blocks, hrec, recs, hipMemcpyHostToDevice, q), "retrieve");
+    hipLaunchKernelGGL(k_demit, dim3(nb * 8u), dim3(256), 0, q, (const lbz_dblock *)c->blocks, nb, (const u8 *)c->W, (const u32 *)c->pinfo, c->d_out, (u64)c->d_out_cap, c->cap);
+    HIPDIE(hipMemcpyAsync(c->h_out, c->d_out, outb, hipMemcpyDeviceToHost, q), "retrieve");
+    HIPDIE(hipStreamSynchronize(q), "retrieve");
+    HIPDIE(hipGetLastError(), "retrieve");
+    for (u32 i = 0; i < nb; i++) {
+      wd_req *r = batch[i];
+      if (r->rec.err == 0u && !r->past) r->st->out.assign(c->h_out + r->rec.out_off, c->h_out + r->rec.out_off + r->rec.out_len);
+    }
+  }
+}
+void wd_submit(wd_req *r)
+{
+  std::unique_lock<std::mutex> lk(g_wd.mu);
+  g_wd.queue.push_back(r);
+  for (;;) {
+    if (r->done) return;
+    if (!g_wd.leader) {
+      /* no round under way: this thread runs one over everything posted (its own block among it, as a rule), then lets
+         whoever is still waiting lead the next */
+      g_wd.leader = true;
+      const size_t take = std::min<size_t>(g_wd.queue.size(), WD_BATCH);
+      std::vector<wd_req *> batch(g_wd.queue.begin(), g_wd.queue.begin() + take);
+      g_wd.queue.erase(g_wd.queue.begin(), g_wd.queue.begin() + take);
+      lk.unlock();
+      wd_round(batch);
+      lk.lock();
+      for (wd_req *b : batch) b->done = true;
+      g_wd.leader = false;
+      g_wd.cv.notify_all();
+      continue;
+    }
+    g_wd.cv.wait(lk);
+  }
+}
 }  // namespace
 
 extern "C" void lbzamd_decoder_init(struct decoder_state *ds)
 {
   wd_state *st = new wd_state;
-  {
-    std::lock_guard<std::mutex> lk(g_wd_mu);
-    if (!g_wd_free.empty()) { st->c = g_wd_free.back(); g_wd_free.pop_back(); }
-  }
-  if (!st->c && lbzamd_dcreate(&st->c, -1, 1u)) die("decoder_init");
   st->bits.assign(4u, 0u);
   memset(ds, 0, sizeof *ds);
   ds->internal_state = reinterpret_cast<struct retriever_internal_state *>(st);
@@ -1559,8 +1679,6 @@ extern "C" void lbzamd_decoder_init(struct decoder_state *ds)
 extern "C" void lbzamd_decoder_free(struct decoder_state *ds)
 {
   wd_state *st = reinterpret_cast<wd_state *>(ds->internal_state);
-  if (!st) return;
-  if (st->c) { std::lock_guard<std::mutex> lk(g_wd_mu); g_wd_free.push_back(st->c); }
   delete st;
   ds->internal_state = nullptr;
 }
@@ -1569,8 +1687,6 @@ extern "C" int lbzamd_retrieve(struct decoder_state *ds, struct bitstream *bs)
 {
   wd_state *st = reinterpret_cast<wd_state *>(ds->internal_state);
   if (!st || !bs) { g_err = "retrieve(): bad decoder state"; die("retrieve"); }
-  lbzamd_dctx *c = st->c;
-  HIPDIE(hipSetDevice(c->device), "retrieve");
   /* everything the caller has: the bits left in its buffer word, then whole words (big-endian in memory: decode.c:404) */
   const unsigned live0 = bs->live;
   const uint64_t buff0 = bs->buff;
@@ -1579,29 +1695,15 @@ extern "C" int lbzamd_retrieve(struct decoder_state *ds, struct bitstream *bs)
   if (live0 > 32u) { wd_put(st, buff0 >> 32, 32u); wd_put(st, (buff0 << 32) >> (64u - (live0 - 32u)), live0 - 32u); }
   else if (live0) wd_put(st, buff0 >> (64u - live0), live0);
   for (const uint32_t *p = data0; p != bs->limit; p++) wd_put(st, ntohl(*p), 32u);
-  /* decode what there is */
-  std::vector<uint8_t> in(st->bits);
-  if (st->nacc) in.push_back((uint8_t)(st->acc << (8u - st->nacc)));
-  const uint64_t avail = 32u + st->nbits;
-  in.resize(in.size() + 16u, 0u);
-  if (in.size() + 16u > c->d_in_cap) {
-    (void)hipFree(c->d_in); c->d_in = nullptr; c->d_in_cap = 0;
-    HIPDIE(hipMalloc((void **)&c->d_in, in.size() * 2u + 4096u), "retrieve");
-    c->d_in_cap = in.size() * 2u + 4096u - 16u;
-  }
-  lbz_dblock rec{};
-  rec.bit_start = 0;
-  rec.max_block = LBZ_MAX_BLOCK;
-  HIPDIE(hipMemcpyAsync(c->d_in, in.data(), in.size(), hipMemcpyHostToDevice, c->q), "retrieve");
-  HIPDIE(hipMemcpyAsync(c->blocks, &rec, sizeof rec, hipMemcpyHostToDevice, c->q), "retrieve");
-  hipLaunchKernelGGL(k_dblock_w, dim3(1), dim3(1024), 0, c->q, (const u8 *)c->d_in, (u64)in.size() - 16u, c->blocks, 1u, c->tt8, c->tt, c->W, c->pinfo, c->X, c->cap);
-  HIPDIE(hipMemcpyAsync(&rec, c->blocks, sizeof rec, hipMemcpyDeviceToHost, c->q), "retrieve");
-  HIPDIE(hipStreamSynchronize(c->q), "retrieve");
-  HIPDIE(hipGetLastError(), "retrieve");
-  /* Ran past the bits there are (or stopped on an error within a word of their end, where what it read were pad bits)?
-     Then the block is not all here: decode.c's NEED() -- everything is taken, MORE, or ERR_EOF at the end of the input. */
-  const bool past = rec.bit_used > avail || (rec.err && rec.err != 11u && rec.bit_used + 64u > avail);
-  if (past) {
+  /* decode what there is (with whatever the other worker threads have posted) */
+  wd_req r{};
+  r.st = st;
+  r.nbytes = st->bits.size() + (st->nacc ? 1u : 0u);
+  r.tail = st->nacc ? (uint8_t)(st->acc << (8u - st->nacc)) : 0u;
+  r.avail = 32u + st->nbits;
+  wd_submit(&r);
+  const lbz_dblock &rec = r.rec;
+  if (r.past) {                                                /* everything is taken: MORE, or ERR_EOF at the end of the input */
     bs->live = 0; bs->buff = 0; bs->data = bs->limit;
     return bs->eof ? WD_ERR_EOF : WD_MORE;
   }
@@ -1618,27 +1720,10 @@ extern "C" int lbzamd_retrieve(struct decoder_state *ds, struct bitstream *bs)
       bs->data = p;
     }
   }
-  if (rec.err && rec.err != 11u) return wd_error(rec.err, rec.nblock);
+  if (rec.err) return wd_error(rec.err, rec.nblock);
   ds->rand = rec.randomised != 0u;
   ds->bwt_idx = rec.orig_ptr;
   ds->block_size = rec.nblock;
-  /* the bytes: k_demit into the context's output buffer, then to the host */
-  const size_t n = rec.out_len;
-  if (n > c->d_out_cap) {
-    (void)hipFree(c->d_out); c->d_out = nullptr; c->d_out_cap = 0;
-    HIPDIE(hipMalloc((void **)&c->d_out, n + n / 2u + 4096u), "retrieve");
-    c->d_out_cap = n + n / 2u + 3840u;
-  }
-  rec.err = 0;                                                 /* (11: the stand-in CRC does not match, of course) */
-  rec.out_off = 0;
-  st->out.resize(n);
-  if (n) {
-    HIPDIE(hipMemcpyAsync(c->blocks, &rec, sizeof rec, hipMemcpyHostToDevice, c->q), "retrieve");
-    hipLaunchKernelGGL(k_demit, dim3(8u), dim3(256), 0, c->q, (const lbz_dblock *)c->blocks, 1u, (const u8 *)c->W, (const u32 *)c->pinfo, c->d_out, (u64)c->d_out_cap, c->cap);
-    HIPDIE(hipMemcpyAsync(st->out.data(), c->d_out, n, hipMemcpyDeviceToHost, c->q), "retrieve");
-    HIPDIE(hipStreamSynchronize(c->q), "retrieve");
-    HIPDIE(hipGetLastError(), "retrieve");
-  }
   st->crc = rec.computed_crc;
   st->pos = 0;
   std::vector<uint8_t>().swap(st->bits);
@@ -1653,7 +1738,7 @@ extern "C" int lbzamd_emit(struct decoder_state *ds, void *buf, size_t *buf_sz)
   if (!st || !buf || !buf_sz) { g_err = "emit(): bad decoder state"; die("emit"); }
   const size_t left = st->out.size() - st->pos;
   const size_t n = left < *buf_sz ? left : *buf_sz;
-  memcpy(buf, st->out.data() + st->pos, n);
+  if (n) memcpy(buf, st->out.data() + st->pos, n);
   st->pos += n;
   *buf_sz -= n;
   if (st->pos < st->out.size()) return WD_MORE;
