@@ -436,7 +436,8 @@ __device__ __forceinline__ void radix_tile_scatter(u32 (*wcnt)[256], u32 *dbase,
 
 /* The same step for an HBM destination: ranks as above, then the tile is regrouped by digit
  * in LDS and written out by consecutive threads, so that each wave store covers a few runs of
- * consecutive addresses instead of 64 scattered rows.                                      */
+ * consecutive addresses instead of 64 scattered rows.  NEXT is a template argument on purpose: as a run-time test inside
+ * the write-out loop it cost the array passes 35 % (3.4 ms against 2.45 per pass of 371 blocks, r04 traces).      */
 template <bool NEXT>
 __device__ __forceinline__ void radix_tile_scatter_hbm(sort_lds *X, const u64 (&key)[SORT_IPT],
                                                        const u32 (&val)[SORT_IPT], u32 okmask, u32 shift,
@@ -498,9 +499,9 @@ __device__ __forceinline__ void radix_tile_scatter_hbm(sort_lds *X, const u64 (&
     if (i < rows) {
       const u64 kk = X->stage_k[i];
       const u32 dst = X->gdelta[(u32)(kk >> shift) & 255u] + i;
-      kout[dst] = kk;
-      vout[dst] = X->stage_v[i];
-      if (NEXT) atomicAdd(&nh[dst >> nshift][(u32)(kk >> (shift + 8u)) & 255u], 1u);    /* the NEXT pass's digit, by the range of its input the row lands in */
+      stg_u64(kout + dst, kk);
+      stg_u32(vout + dst, X->stage_v[i]);
+      if (NEXT) atomicAdd(&nh[dst >> nshift][(u32)(kk >> (shift + 8u)) & 255u], 1u);      /* the NEXT pass's digit, by the range of its input the row lands in */
     }
   }
   wg_lds_barrier();
@@ -514,28 +515,37 @@ __device__ __forceinline__ void radix_tile_scatter_hbm(sort_lds *X, const u64 (&
  *                  the way if `count_above` (hist[j]: the digit at bit 32 + 8 j).  Values carry the CODE of the
  *                  preceding byte; the emitters map it back.                                 */
 template <bool SCATTER, bool NEXT = false>
-__device__ void msd_text_pass(const u8 *T, u32 n, keycfg c, u64 *kout, u32 *vout, bwt_lds *S, u32 shift, u32 r0, u32 r1,
+__device__ __forceinline__ void msd_text_pass(const u8 *T, u32 n, keycfg c, u64 *kout, u32 *vout, bwt_lds *S, u32 shift, u32 r0, u32 r1,
                               u32 (*nh)[256] = nullptr, u32 nshift = 0u)      /* rotations [r0, r1), r0 a multiple of the tile */
 {
   sort_lds *P = &S->u.X;
   const u32 tid = threadIdx.x;
   u32 *tile32 = P->tile;        /* code of position t0 + j at byte 4 + j */
   const u64 keep = (c.b * c.sy >= 64u) ? ~0ull : ((1ull << (c.b * c.sy)) - 1ull);
+  /* a tile's text: four bytes per thread, the halo behind the tile (a few threads) and the byte before it (one thread),
+     requested one tile ahead and left in flight across the ranking of the tile before */
+  u32 raw = 0, halo = 0, before = 0;
+  auto fetch = [&](u32 t0) {
+    const u32 q0 = t0 + 4u * tid;
+    if (q0 + 4u <= n) raw = ldg_u32(reinterpret_cast<const u32 *>(T + q0));
+    else raw = ldg_u8(T + q0 % n) | (ldg_u8(T + (q0 + 1u) % n) << 8) | (ldg_u8(T + (q0 + 2u) % n) << 16) | (ldg_u8(T + (q0 + 3u) % n) << 24);
+    if (tid < PART_HALO / 4u) {
+      const u32 h0 = t0 + SORT_TILE + 4u * tid;
+      if (h0 + 4u <= n) halo = ldg_u32(reinterpret_cast<const u32 *>(T + h0));
+      else halo = ldg_u8(T + h0 % n) | (ldg_u8(T + (h0 + 1u) % n) << 8) | (ldg_u8(T + (h0 + 2u) % n) << 16) | (ldg_u8(T + (h0 + 3u) % n) << 24);
+    }
+    if (tid == PART_HALO / 4u) before = ldg_u8(T + (t0 + n - 1u) % n);
+  };
+  auto codes = [&](u32 x) {
+    return (u32)S->cmap[x & 255u] | ((u32)S->cmap[(x >> 8) & 255u] << 8) | ((u32)S->cmap[(x >> 16) & 255u] << 16) | ((u32)S->cmap[x >> 24] << 24);
+  };
+  if (r0 < r1) fetch(r0);
   for (u32 t0 = r0; t0 < r1; t0 += SORT_TILE) {
     const u32 q0 = t0 + 4u * tid;
-    {
-      u32 raw;
-      if (q0 + 4u <= n) raw = *reinterpret_cast<const u32 *>(T + q0);
-      else raw = (u32)T[q0 % n] | ((u32)T[(q0 + 1u) % n] << 8) | ((u32)T[(q0 + 2u) % n] << 16) | ((u32)T[(q0 + 3u) % n] << 24);
-      tile32[1u + tid] = (u32)S->cmap[raw & 255u] | ((u32)S->cmap[(raw >> 8) & 255u] << 8)
-                       | ((u32)S->cmap[(raw >> 16) & 255u] << 16) | ((u32)S->cmap[raw >> 24] << 24);
-      if (tid < PART_HALO / 4u) {
-        const u32 h0 = t0 + SORT_TILE + 4u * tid;
-        tile32[1u + LBZ_WG + tid] = (u32)S->cmap[T[h0 % n]] | ((u32)S->cmap[T[(h0 + 1u) % n]] << 8)
-                                  | ((u32)S->cmap[T[(h0 + 2u) % n]] << 16) | ((u32)S->cmap[T[(h0 + 3u) % n]] << 24);
-      }
-      if (tid == PART_HALO / 4u) tile32[0] = (u32)S->cmap[T[(t0 + n - 1u) % n]] << 24;
-    }
+    tile32[1u + tid] = codes(raw);
+    if (tid < PART_HALO / 4u) tile32[1u + LBZ_WG + tid] = codes(halo);
+    if (tid == PART_HALO / 4u) tile32[0] = (u32)S->cmap[before] << 24;
+    fetch(t0 + SORT_TILE);
     __syncthreads();
     u64 key[SORT_IPT];
     u32 val[SORT_IPT], okmask = 0;
@@ -585,21 +595,25 @@ __device__ void msd_text_pass(const u8 *T, u32 n, keycfg c, u64 *kout, u32 *vout
   }
 }
 
-/* A partition pass from (kin,vin) to (kout,vout) on the digit at `shift`; the next tile's rows
- * are requested before the current tile is ranked.                                        */
+/* A partition pass from (kin,vin) to (kout,vout) on the digit at `shift`.  The next tile's rows are requested before the
+ * current tile is ranked, and stay in flight across the ranking: the loads are unconditional (rows past the end read the last
+ * row again; okmask drops them) and say "global" (lbz_asm.h), so no wait for an LDS read waits for them.  The compiler's own
+ * form of this loop -- a guarded flat load per row, each followed by its wait -- ran a pass of 371 blocks in 3.3 ms. */
 template <bool NEXT>
-__device__ void msd_array_pass(const u64 *kin, const u32 *vin, u32 shift, u64 *kout, u32 *vout, bwt_lds *S, u32 r0, u32 r1,
-                               u32 (*nh)[256], u32 nshift)                     /* rows [r0, r1) */
+__device__ __forceinline__ void msd_array_pass(const u64 *kin, const u32 *vin, u32 shift, u64 *kout, u32 *vout, bwt_lds *S, u32 r0, u32 r1,
+                                               u32 (*nh)[256], u32 nshift)      /* rows [r0, r1) */
 {
+  if (r0 >= r1) return;                                      /* (workgroup-uniform) */
   sort_lds *P = &S->u.X;
   const u32 lane = lane_id(), w = wave_id();
+  const u32 last = r1 - 1u;
   u64 nkey[SORT_IPT];
   u32 nval[SORT_IPT];
 #pragma unroll
   for (u32 k = 0; k < SORT_IPT; k++) {
-    const u32 i = r0 + w * 64u * SORT_IPT + k * 64u + lane;
-    nkey[k] = i < r1 ? kin[i] : 0ull;
-    nval[k] = i < r1 ? vin[i] : 0u;
+    const u32 i0 = r0 + w * 64u * SORT_IPT + k * 64u + lane, i = i0 < last ? i0 : last;
+    nkey[k] = ldg_u64(kin + i);
+    nval[k] = ldg_u32(vin + i);
   }
   for (u32 t0 = r0; t0 < r1; t0 += SORT_TILE) {
     u64 key[SORT_IPT];
@@ -610,9 +624,12 @@ __device__ void msd_array_pass(const u64 *kin, const u32 *vin, u32 shift, u64 *k
       key[k] = nkey[k];
       val[k] = nval[k];
       if (wbase + k * 64u + lane < r1) okmask |= 1u << k;
-      const u32 i = wbase + SORT_TILE + k * 64u + lane;
-      nkey[k] = i < r1 ? kin[i] : 0ull;
-      nval[k] = i < r1 ? vin[i] : 0u;
+    }
+#pragma unroll
+    for (u32 k = 0; k < SORT_IPT; k++) {
+      const u32 i0 = wbase + SORT_TILE + k * 64u + lane, i = i0 < last ? i0 : last;
+      nkey[k] = ldg_u64(kin + i);
+      nval[k] = ldg_u32(vin + i);
     }
     radix_tile_scatter_hbm<NEXT>(P, key, val, okmask, shift, kout, vout, nh, nshift);
   }
@@ -1572,25 +1589,19 @@ k_bwt_part(const u8 *Tbase, lbz_block_meta *meta, lbz_layout L, u32 first, u32 c
   u64 *kb[2] = { s.k0, s.k1 };
   u32 *vb[2] = { s.v0, s.v1 };
   load_digit_offsets(passes == 4u ? P->hist[0] : P->hist[2], P->dbase, &S);
-  for (u32 pass = 0; pass < passes; pass++) {
-    const u32 dst = (passes - 1u - pass) & 1u;               /* the last pass lands in (k0,v0) */
-    const u32 shift = 32u + 8u * (4u - passes + pass);
-    const bool next = pass + 1u < passes && !bytes;
-    if (next) {
-      for (u32 i = tid; i < 256u; i += LBZ_WG) S_.nh[0][i] = 0;
-      __syncthreads();
-    }
-    if (pass == 0u) {
-      if (next) msd_text_pass<true, true>(T, n, c, kb[dst], vb[dst], &S, shift, 0u, n, S_.nh, 31u);
-      else msd_text_pass<true, false>(T, n, c, kb[dst], vb[dst], &S, shift, 0u, n);
-    } else {
-      if (next) msd_array_pass<true>(kb[dst ^ 1u], vb[dst ^ 1u], shift, kb[dst], vb[dst], &S, 0u, n, S_.nh, 31u);
-      else msd_array_pass<false>(kb[dst ^ 1u], vb[dst ^ 1u], shift, kb[dst], vb[dst], &S, 0u, n, nullptr, 0u);
-    }
-    if (pass + 1u < passes) {
-      __syncthreads();
-      load_digit_offsets(bytes ? P->hist[0] : S_.nh[0], P->dbase, &S);
-    }
+  u32 cur = (passes - 1u) & 1u;                                /* buffers alternate so that the last pass lands in (k0,v0) */
+  u32 (*nh)[256] = bytes ? nullptr : S_.nh;                   /* narrow symbols: a pass counts the next pass's digits */
+  if (nh) { for (u32 i = tid; i < 256u; i += LBZ_WG) S_.nh[0][i] = 0; __syncthreads(); }
+  if (nh && passes > 1u) msd_text_pass<true, true>(T, n, c, kb[cur], vb[cur], &S, 32u + 8u * (4u - passes), 0u, n, nh, 31u);
+  else msd_text_pass<true, false>(T, n, c, kb[cur], vb[cur], &S, 32u + 8u * (4u - passes), 0u, n);
+  for (u32 pass = 1; pass < passes; pass++) {
+    __syncthreads();
+    load_digit_offsets(bytes ? P->hist[0] : S_.nh[0], P->dbase, &S);
+    const bool next = pass + 1u < passes && nh;
+    if (next) { for (u32 i = tid; i < 256u; i += LBZ_WG) S_.nh[0][i] = 0; __syncthreads(); }
+    if (next) msd_array_pass<true>(kb[cur], vb[cur], 32u + 8u * (4u - passes + pass), kb[cur ^ 1u], vb[cur ^ 1u], &S, 0u, n, nh, 31u);
+    else msd_array_pass<false>(kb[cur], vb[cur], 32u + 8u * (4u - passes + pass), kb[cur ^ 1u], vb[cur ^ 1u], &S, 0u, n, nullptr, 0u);
+    cur ^= 1u;
   }
   /* the segments' bounds (k_bwt_segs) */
   __syncthreads();

@@ -275,17 +275,17 @@ static void launch_sort(lbzamd_ctx *c, hipStream_t q, u32 first, u32 count, u32 
   /* workgroups per block in the sorting kernels: more of them when the round has fewer blocks than the device has CUs -- the
      caller then waits for a block's chain of launches, and every launch is as long as its longest segment */
   const u32 segs = count <= c->ncus ? LBZ_BWT_MAXSEGS : LBZ_BWT_SEGS;
-  if (phase == 0 && (count > 2u * c->ncus || (overlapped && count > c->ncus)) && !getenv("LBZAMD_PARTS")) {
-    /* rounds that fill the device by their number of blocks, or big rounds side by side on several streams: one workgroup
-       per block, every pass in one launch (k_bwt.hip: 27.5 ms for 1112 blocks against 35 for the launch-per-pass form, which
-       pays its wider LDS footprint and a second read of the text; 371 blocks alone: 14.0 against 10.7) */
+  if (phase == 0 && overlapped && count > c->ncus && !getenv("LBZAMD_PARTS")) {
+    /* big rounds side by side on several streams: one workgroup per block, every pass in one launch.  Three rounds of 371
+       blocks overlapped: 8.1 GB/s against 7.8 with the launch-per-pass form, which alone on the device is the faster one
+       (371 blocks: 9.6 ms against 14; 1112 blocks: 28.0 against 29.9) */
     hipLaunchKernelGGL(k_bwt_part, dim3(nblk), dim3(LBZ_BWT_WG), 0, q, (const u8 *)c->T, c->meta, c->L,
                        first, count, ws, (u64)c->slot_bytes, wsp, (u64)c->spill_bytes, lst, segs);
   } else if (phase == 0) {
-    /* the partition: more workgroups per block the fewer blocks the round has (a block's passes are what a small input
-       waits for; a full device needs only enough workgroups to fill it evenly) */
+    /* the partition, a launch per pass: more workgroups per block the fewer blocks the round has (a block's passes are what
+       a small input waits for; a full device needs only enough workgroups to fill it evenly) */
     static const int forced = getenv("LBZAMD_PARTS") ? atoi(getenv("LBZAMD_PARTS")) : 0;      /* (tuning) */
-    const u32 parts = forced > 0 && forced <= 16 ? (u32)forced : (count <= c->ncus / 2u ? 16u : (count <= 2u * c->ncus ? 8u : 4u));
+    const u32 parts = forced > 0 && forced <= 16 ? (u32)forced : (count <= c->ncus / 2u ? 16u : 8u);
     const dim3 g(lbz_seg_grid(nblk, parts));
     hipLaunchKernelGGL(k_bwt_hist, g, dim3(LBZ_BWT_WG), 0, q, (const u8 *)c->T, c->meta, c->L,
                        first, count, nblk, parts, ws, (u64)c->slot_bytes, wsp, (u64)c->spill_bytes, lst);
@@ -298,8 +298,9 @@ static void launch_sort(lbzamd_ctx *c, hipStream_t q, u32 first, u32 count, u32 
     hipLaunchKernelGGL(k_bwt_batch, dim3(lbz_seg_grid(nblk, segs)), dim3(LBZ_BWT_WG), 0, q, (const u8 *)c->T, c->B, c->meta, c->L,
                        first, count, nblk, segs, ws, (u64)c->slot_bytes, wsp, (u64)c->spill_bytes, lst);
   } else {
+    static const unsigned deep_pad = getenv("LBZAMD_DEEP_PAD") ? (unsigned)atoi(getenv("LBZAMD_DEEP_PAD")) : 0u;   /* (tuning) idle LDS: fewer workgroups per CU */
     for (u32 r = 0; r < LBZ_DEEP_ROUNDS; r++)
-      hipLaunchKernelGGL(k_bwt_deep, dim3(lbz_seg_grid(nblk, segs)), dim3(LBZ_BWT_WG), 0, q, (const u8 *)c->T, c->B, c->meta, c->L,
+      hipLaunchKernelGGL(k_bwt_deep, dim3(lbz_seg_grid(nblk, segs)), dim3(LBZ_BWT_WG), deep_pad, q, (const u8 *)c->T, c->B, c->meta, c->L,
                          first, count, nblk, segs, ws, (u64)c->slot_bytes, wsp, (u64)c->spill_bytes, lst, r);
     hipLaunchKernelGGL(k_bwt_fix0, dim3(lbz_seg_grid(nblk, segs)), dim3(LBZ_BWT_WG), 0, q, (const u8 *)c->T, c->B, c->meta, c->L,
                        first, count, nblk, segs, ws, (u64)c->slot_bytes, wsp, (u64)c->spill_bytes, lst);
@@ -772,6 +773,11 @@ extern "C" int lbzamd_block_info_get(lbzamd_ctx *c, uint32_t blk, lbzamd_block_i
   info->num_sel = m.num_sel; info->out_len = m.out_len; info->err = m.err; info->rounds = m.rounds;
   info->sort_elems = m.sort_elems; for (int i = 0; i < 8; i++) info->ticks[i] = m.ticks[i];
   for (int i = 0; i < 16; i++) info->fticks[i] = m.fticks[i];
+  if (getenv("LBZAMD_DIAG_DEEP")) {       /* (tuning) the text rounds' counts in place of the rank rounds' ticks: tests/tools/diag_rows.py */
+    for (unsigned i = 0; i <= LBZ_DEEP_ROUNDS && i < 9u; i++) info->fticks[i] = m.deep_tot[i];
+    info->fticks[9] = m.deep_h0; info->fticks[10] = m.deep_skip; info->fticks[11] = m.deep_long; info->fticks[12] = m.deep_rows;
+    info->fticks[13] = m.deep_hmin[1]; info->fticks[14] = m.deep_hmin[LBZ_DEEP_ROUNDS];
+  }
   memcpy(info->inuse, m.inuse, 256);
   return 0;
 }

@@ -217,4 +217,14 @@ __device__ __forceinline__ unsigned add_if_less2(unsigned acc, unsigned long lon
   return acc;
 }
 
+/* Loads and stores that say "HBM" (address space 1): a pointer that reaches a function through a select or a table of pointers
+ * is generic to the compiler, which then issues flat_load -- and a flat load in flight makes every wait for an LDS read a wait
+ * for the load as well (both count in lgkmcnt), which undoes any prefetch across LDS work. */
+#define LBZ_GLOBAL(T) __attribute__((address_space(1))) T
+__device__ __forceinline__ unsigned long long ldg_u64(const unsigned long long *p) { return *(const LBZ_GLOBAL(unsigned long long) *)p; }
+__device__ __forceinline__ unsigned ldg_u32(const unsigned *p) { return *(const LBZ_GLOBAL(unsigned) *)p; }
+__device__ __forceinline__ unsigned ldg_u8(const unsigned char *p) { return *(const LBZ_GLOBAL(unsigned char) *)p; }
+__device__ __forceinline__ void stg_u64(unsigned long long *p, unsigned long long v) { *(LBZ_GLOBAL(unsigned long long) *)p = v; }
+__device__ __forceinline__ void stg_u32(unsigned *p, unsigned v) { *(LBZ_GLOBAL(unsigned) *)p = v; }
+
 #endif
