@@ -45,6 +45,7 @@ struct enc_lds {
   u16 leaves_in[PM_LEVELS + 1][PM_ITEMS + 2];
   u32 nitems[PM_LEVELS + 2];
   u32 taken[PM_LEVELS + 2][PM_LEVELS + 2];
+  u16 upto[PM_LEVELS + 2][PM_LEVELS + 2];
   u8 hl[PM_LEVELS + 1][LBZ_MAX_ALPHA + 2];
   u32 hcost[PM_LEVELS + 2];
   u32 win[WIN_WORDS];
@@ -80,45 +81,110 @@ __device__ void seed_tables(enc_lds *S, u32 as, u32 nm, u32 nt)
   }
 }
 
-/* ---- M-step for one table on one lane: unrestricted Huffman lengths (encode.c:713-766) */
-__device__ void huffman_lengths_lane(enc_lds *S, u32 t, u32 as)
+/* ---- M-step for one table on one WAVE: unrestricted Huffman lengths (encode.c:713-766).
+ * The two-queue merge is a chain of as - 1 decisions and stays on lane 0, but the heads of both queues (two leaves, two
+ * internal nodes) live in registers: a step compares registers and then refills them, one LDS round trip where a loop that
+ * reads its operands as it needs them took five or six in a row (0.11 ms per table and EM round, 0.89 ms per block).
+ * What follows the merge is the wave's: node depths by relaxation from the root (a node's parent has a smaller index; the
+ * tree is ~20 deep), their histogram, the leaves' depths from the counts per level.                                   */
+__device__ void huffman_lengths_wave(enc_lds *S, u32 t, u32 as)
 {
+  const u32 lane = threadIdx.x & 63u;
   u64 *w = S->wsort[t];
   u32 *par = S->parent[t];
+  u32 *depth = S->lc[t];                                /* free until limited_code() writes the final codes */
   u32 *internal_at = S->dcnt[t][0], *leaves_at = S->dcnt[t][1];
-  u32 leaf = as, node = as;
-  for (u32 x = as - 1u; x > 0u; x--) {
-    const u32 n_int = node - 1u - x;
-    u64 a, b;
-    if (leaf == 0u || (n_int >= 2u && w[node - 2u] < w[leaf - 1u])) {
-      a = w[node - 1u]; b = w[node - 2u];
-      par[node - 1u] = x; par[node - 2u] = x; node -= 2u;
-    } else if (n_int == 0u || (leaf >= 2u && w[leaf - 2u] <= w[node - 1u])) {
-      a = w[leaf - 1u]; b = w[leaf - 2u]; leaf -= 2u;
-    } else {
-      a = w[node - 1u]; b = w[leaf - 1u];
-      par[node - 1u] = x; node -= 1u; leaf -= 1u;
+  constexpr u32 UNK = 0xFFFFFFFFu;
+  for (u32 i = lane; i < as; i += 64u) depth[i] = i == 1u ? 0u : UNK;
+  if (lane < 32u) internal_at[lane] = 0;
+  if (lane == 0u) {
+    /* No branch inside a step: on one lane every instruction is four cycles of an otherwise idle SIMD, and a divergent
+       branch costs a dozen of them in exec-mask bookkeeping.  Stores that a case does not make go to a dummy slot (index 0
+       of par[], never read), loads are made for every case and selected. */
+    u32 leaf = as, node = as;
+    u64 L1 = w[as - 1u], L2 = as >= 2u ? w[as - 2u] : 0ull, N1 = 0, N2 = 0;
+    u64 keep = w[as - 1u] & 0xFFFFull;                  /* slot x held a leaf that is merged by now: its symbol stays (read below) */
+    for (u32 x = as - 1u; x > 0u; x--) {
+      const u32 n_int = node - 1u - x;
+      const bool two_nodes = leaf == 0u || (n_int >= 2u && N2 < L1);
+      const bool two_leaves = !two_nodes && (n_int == 0u || (leaf >= 2u && L2 <= N1));
+      const bool mixed = !two_nodes && !two_leaves;
+      const u64 a = two_leaves ? L1 : N1;
+      const u64 b = two_nodes ? N2 : (two_leaves ? L2 : L1);
+      par[two_leaves ? 0u : node - 1u] = x;
+      par[two_nodes ? node - 2u : 0u] = x;
+      node -= two_nodes ? 2u : (mixed ? 1u : 0u);
+      leaf -= two_leaves ? 2u : (mixed ? 1u : 0u);
+      const u64 da = a & 0xFF000000ull, db = b & 0xFF000000ull;
+      const u64 nv = keep + ((a + b) & ~0xFF00FFFFull) + (da > db ? da : db) + 0x01000000ull;
+      w[x] = nv;
+      /* the queues' heads for the next step: internal nodes x .. node-1 (oldest = lightest at node-1), leaves below `leaf` */
+      const u64 wn1 = w[node - 1u], wn2 = w[node >= 2u ? node - 2u : 0u];
+      const u64 wl1 = w[leaf >= 1u ? leaf - 1u : 0u], wl2 = w[leaf >= 2u ? leaf - 2u : 0u];
+      keep = w[x - 1u] & 0xFFFFull;
+      const u32 q = node - x;
+      N1 = node - 1u == x ? nv : wn1;
+      N2 = q >= 2u ? (node - 2u == x ? nv : wn2) : 0ull;
+      L1 = leaf >= 1u ? wl1 : 0ull;
+      L2 = leaf >= 2u ? wl2 : 0ull;
     }
-    const u64 da = a & 0xFF000000ull, db = b & 0xFF000000ull;
-    w[x] = (w[x] & 0xFFFFull) + ((a + b) & ~0xFF00FFFFull) + (da > db ? da : db) + 0x01000000ull;
   }
-  for (u32 d = 0; d < 32u; d++) internal_at[d] = 0;
-  par[1] = 0; internal_at[0] = 1;                       /* par[] now holds depths */
-  for (u32 i = 2; i < as; i++) { const u32 d = par[par[i]] + 1u; par[i] = d; internal_at[d]++; }
-  leaves_at[0] = 0;
-  for (u32 d = 1; d <= 30u; d++) leaves_at[d] = 2u * internal_at[d - 1u] - internal_at[d];
-  u32 i = 0;
-  for (u32 d = 1; d <= 30u; d++)
-    for (u32 k = leaves_at[d]; k > 0u; k--, i++)
+  wave_sync();
+  /* depths of the internal nodes 2 .. as-1 (node 1 is the root) */
+  u32 pj[5];
+  u32 pend = 0;
+#pragma unroll
+  for (u32 j = 0; j < 5u; j++) {
+    const u32 i = lane + 64u * j;
+    pj[j] = 0;
+    if (i >= 2u && i < as) { pj[j] = par[i]; pend |= 1u << j; }
+  }
+  while (__ballot(pend != 0u)) {
+#pragma unroll
+    for (u32 j = 0; j < 5u; j++)
+      if (pend & (1u << j)) {
+        const u32 dp = depth[pj[j]];
+        if (dp != UNK) { depth[lane + 64u * j] = dp + 1u; pend &= ~(1u << j); }
+      }
+    wave_sync();
+  }
+#pragma unroll
+  for (u32 j = 0; j < 5u; j++) {
+    const u32 i = lane + 64u * j;
+    if (i >= 1u && i < as) atomicAdd(&internal_at[depth[i]], 1u);
+  }
+  wave_sync();
+  /* leaves per level, then their running total: leaf number i (heaviest first) sits on the first level whose total passes i */
+  u32 la = 0;
+  if (lane >= 1u && lane <= 30u) la = 2u * internal_at[lane - 1u] - internal_at[lane];
+  const u32 cum = wave_incl_add(la);
+  wave_sync();
+  if (lane < 32u) leaves_at[lane] = cum;
+  wave_sync();
+#pragma unroll
+  for (u32 j = 0; j < 5u; j++) {
+    const u32 i = lane + 64u * j;
+    if (i < as) {
+      u32 d = 1u;
+      while (d < 30u && leaves_at[d] <= i) d++;
       S->len[t][LBZ_MAX_ALPHA - (u32)(w[i] & 0xFFFFull)] = (u8)d;
+    }
+  }
 }
 
 /* ---- descending sort of as weights by counting, whole workgroup: dst[rank] = src weight */
 __device__ __forceinline__ u32 rank_desc(const u64 *w, u32 as, u32 i)
 {
   const u64 me = w[i];
-  u32 r = 0;
-  for (u32 j = 0; j < as; j++) r += w[j] > me;
+  u32 r = 0, j = 0;
+  for (; j + 8u <= as; j += 8u) {                       /* eight reads in flight: one by one the loop is a chain of LDS round trips */
+    u64 v[8];
+#pragma unroll
+    for (u32 k = 0; k < 8u; k++) v[k] = w[j + k];
+#pragma unroll
+    for (u32 k = 0; k < 8u; k++) r += v[k] > me;
+  }
+  for (; j < as; j++) r += w[j] > me;
   return r;
 }
 
@@ -172,7 +238,8 @@ __device__ u32 limited_code(enc_lds *S, u32 t, u32 as)
     __syncthreads();
   }
 
-  /* taken[h][d] = leaves used on level h-d under height limit h */
+  /* taken[h][d] = leaves used on level h-d under height limit h; upto[h][d] = symbols (heaviest first) that the reference's
+     loop over the levels has given a length <= d -- kept exactly as that loop counts, saturation at `as` included */
   if (tid >= 1u && tid <= PM_LEVELS) {
     const u32 h = tid;
     u32 k = want < S->nitems[h] ? want : S->nitems[h];
@@ -184,26 +251,35 @@ __device__ u32 limited_code(enc_lds *S, u32 t, u32 as)
       S->taken[h][d] = nl;
       k = 2u * (k - nl);
     }
+    u32 cum = 0;
+    S->upto[h][0] = 0;
+    for (u32 d = 1; d <= h; d++) {
+      const u64 c = (u64)cum + (u64)(u32)(S->taken[h][d - 1u] - S->taken[h][d]);
+      cum = c < (u64)as ? (u32)c : as;
+      S->upto[h][d] = (u16)cum;
+    }
+    S->hcost[h] = (h >= 2u && (1u << h) >= as) ? 5u + as : 0u;
   }
   __syncthreads();
 
-  /* cost of every height limit in parallel (encode.c:922-938) */
-  if (tid >= 2u && tid <= PM_LEVELS) {
-    const u32 h = tid;
-    u32 cost = 0, rank = 0;
-    if ((1u << h) >= as) {
-      for (u32 d = 1; d <= h; d++)
-        for (u32 k = S->taken[h][d - 1u] - S->taken[h][d]; k > 0u && rank < as; k--, rank++) {
-          S->hl[h][LBZ_MAX_ALPHA - (u32)(wq[rank] & 0xFFFFull)] = (u8)d;
-          cost += (u32)(wq[rank] >> 32) * d;
-        }
-      for (u32 v = 1; v < as; v++) {
-        const int dl = (int)S->hl[h][v] - (int)S->hl[h][v - 1u];
-        cost += 2u * (u32)(dl < 0 ? -dl : dl);
-      }
-      cost += 5u + as;
+  /* cost of every height limit (encode.c:922-938), a (limit, symbol) pair per thread */
+  for (u32 e = tid; e < (PM_LEVELS - 1u) * as; e += LBZ_WG) {
+    const u32 h = 2u + e / as, rank = e % as;
+    if ((1u << h) < as) continue;
+    u32 d = 1u;
+    while (d <= h && (u32)S->upto[h][d] <= rank) d++;
+    if (d <= h) {
+      const u64 wr = wq[rank];
+      S->hl[h][LBZ_MAX_ALPHA - (u32)(wr & 0xFFFFull)] = (u8)d;
+      atomicAdd(&S->hcost[h], (u32)(wr >> 32) * d);
     }
-    S->hcost[h] = cost;
+  }
+  __syncthreads();
+  for (u32 e = tid; e < (PM_LEVELS - 1u) * as; e += LBZ_WG) {
+    const u32 h = 2u + e / as, v = e % as;
+    if ((1u << h) < as || v == 0u) continue;
+    const int dl = (int)S->hl[h][v] - (int)S->hl[h][v - 1u];
+    if (dl) atomicAdd(&S->hcost[h], 2u * (u32)(dl < 0 ? -dl : dl));
   }
   __syncthreads();
   if (tid == 0) {                                        /* first strict minimum, encode.c:913-945 */
@@ -226,8 +302,15 @@ __device__ u32 limited_code(enc_lds *S, u32 t, u32 as)
   const u32 best_cost = S->bc[0], best_h = S->bc[1];
   if (tid < as) {
     const u32 l = S->hl[best_h][tid];
-    u32 same = 0;
-    for (u32 v = 0; v < tid; v++) same += S->hl[best_h][v] == l;
+    u32 same = 0, v = 0;
+    for (; v + 8u <= tid; v += 8u) {
+      u32 x[8];
+#pragma unroll
+      for (u32 k = 0; k < 8u; k++) x[k] = S->hl[best_h][v + k];
+#pragma unroll
+      for (u32 k = 0; k < 8u; k++) same += x[k] == l;
+    }
+    for (; v < tid; v++) same += S->hl[best_h][v] == l;
     S->len[t][tid] = (u8)l;
     S->lc[t][tid] = ((S->hcost[l] + same) << 5) | l;
   }
@@ -294,7 +377,7 @@ k_encode(const u16 *Vbase, const u32 *freq_in, u8 *Obase, lbz_block_meta *meta, 
 
 #ifdef ENC_TICKS
   const u64 tk0 = wall_clock64();
-  u64 tke = 0, tkm = 0;
+  u64 tke = 0, tkm = 0, tks = 0;
 #endif
   /* ---- EM (encode.c:1043-1084) ---- */
   for (u32 it = 0; it < LBZ_CLUSTER; it++) {
@@ -359,7 +442,10 @@ k_encode(const u16 *Vbase, const u32 *freq_in, u8 *Obase, lbz_block_meta *meta, 
       cntm++;
     }
     __syncthreads();
-    if ((tid & 63u) == 0u && (tid >> 6) < nt) huffman_lengths_lane(&S, tid >> 6, as);
+#ifdef ENC_TICKS
+    tks += wall_clock64() - tb;
+#endif
+    if ((tid >> 6) < nt) huffman_lengths_wave(&S, tid >> 6, as);
     __syncthreads();
 #ifdef ENC_TICKS
     tkm += wall_clock64() - tb;
@@ -615,7 +701,7 @@ k_encode(const u16 *Vbase, const u32 *freq_in, u8 *Obase, lbz_block_meta *meta, 
     if ((u32)(bitpos >> 3) != out_len || (bitpos & 7ull)) M->err = 3u;   /* cf. encode.c:1275-1277 */
 #ifdef ENC_TICKS
     M->ticks[1] = (u32)tke; M->ticks[2] = (u32)tkm; M->ticks[3] = (u32)(tk2 - tk1); M->ticks[4] = (u32)(tk3 - tk2);
-    M->ticks[5] = (u32)(wall_clock64() - tk3); M->ticks[6] = (u32)(tk0 & 0xffffffffu);
+    M->ticks[5] = (u32)(wall_clock64() - tk3); M->ticks[6] = (u32)(tk0 & 0xffffffffu); M->ticks[7] = (u32)tks;
 #endif
   }
 }
