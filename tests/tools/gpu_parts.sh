@@ -1,6 +1,6 @@
+# (tuning) A/B of the working tree's library against variants/h0.so (the last commit)
 cd /root/repo; export PYTHONPATH=/root/repo:/root/repo/tests
-for kind in wiki mixed; do
-  echo "== $kind one round of 1112"; LBZAMD_STREAMS=1 LBZ_SLOTS=1112 timeout 100 python tests/tools/quickperf.py 1112 $kind 2>&1 | grep "MB/s"
-done
-echo "== wiki 3 streams"; LBZAMD_STREAMS=3 LBZ_SLOTS=371 timeout 100 python tests/tools/quickperf.py 1112 wiki 2>&1 | grep "MB/s"
-timeout 200 python -m pytest tests/test_gpu_parity.py -x -q -m gpu -k "fuzz or parity or golden" 2>&1 | tail -3
+for kind in ${KINDS:-wiki mixed}; do for v in default h0; do
+  if [ "$v" != "default" ]; then export LBZ_LIB=/root/repo/lbzip2_amd/csrc/variants/$v.so; else unset LBZ_LIB; fi
+  echo "== $kind $v"; LBZAMD_STREAMS=1 LBZ_SLOTS=371 timeout 60 python tests/tools/quickperf.py 1112 $kind 2>&1 | grep "MB/s\|batch kernel"
+done; done
