@@ -562,7 +562,8 @@ def main():
         pipe_alg = st.n_in + 13.0 * st.n_rle + 20.0 * st.n_mtf + st.n_out  # SURVEY 8(d), per step
         ncus = torch.cuda.get_device_properties(local).multi_processor_count
         per_round = min(nslots, nslabs)
-        segs = 32 if per_round <= ncus else 16                          # lbz_api.hip: launch_sort
+        nstreams = int(os.environ.get("LBZAMD_STREAMS", "3"))
+        segs, parts = ctx.round_shape(per_round, nstreams > 1 and nslabs > per_round)     # lbz_api.hip: launch_sort's choice, asked of the library
         res = {
             "metric": "compress MB/s (whole node) + ratio, enwik9 -9, at 1/2/4/8 MI355X",
             "value": round((len(full) if strong else total_in) * args.steps / elapsed / 1e6, 1),
@@ -571,8 +572,10 @@ def main():
             "scaling": args.scaling, "vs_baseline": None, "dtype": "u8",
             "data": "synthetic" if "synthetic" in source else "enwik9",
             "config": {"workload": f"{source}, level -{args.level}, {nslabs} slabs of {M} B per GPU, "
-                                   f"{slabs} resident per chunk, rounds of <= {nslots} slabs on {os.environ.get('LBZAMD_STREAMS', '3')} streams; one workgroup per block "
-                                   f"(collect, partition, MTF, coding), {segs} segment workgroups per block in the sorting kernels"
+                                   f"{slabs} resident per chunk, rounds of <= {nslots} slabs on {nstreams} streams; one workgroup per block (collect, "
+                                   + ("partition, " if parts == 1 else "") + f"MTF, coding), "
+                                   + (f"{parts} per block in the partition's launch-per-pass kernels, " if parts != 1 else "")
+                                   + f"{segs} segment workgroups per block in the sorting kernels"
                                    + ("; ONE stream gathered on rank 0 (RCCL send/recv of block bytes + 12-byte CRC partials)" if strong else ""),
                        "bytes_per_gpu": n, "level": args.level,
                        "parallelism": f"{world} slab range(s) of one input -> one stream" if strong else f"{world} independent shard(s)"},

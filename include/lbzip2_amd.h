@@ -158,6 +158,10 @@ size_t lbzamd_bound(size_t len);
 int  lbzamd_get_stats(lbzamd_ctx *ctx, lbzamd_stats *st);
 /* Slabs per round (see lbzamd_create). */
 uint32_t lbzamd_slots(lbzamd_ctx *ctx);
+/* Launch geometry of a round of `blocks` blocks (diagnostic; bench.py names it in its workload string): workgroups per
+ * block in the sorting kernels (segments) and in the partition (1: k_bwt_part, one workgroup per block; else the
+ * launch-per-pass kernels).  overlapped: other rounds run beside it on their own streams.                          */
+void lbzamd_round_shape(lbzamd_ctx *ctx, uint32_t blocks, int overlapped, uint32_t *segments, uint32_t *partition_wgs);
 /* The HIP stream (hipStream_t) a caller orders against: every call starts and ends on it (rounds
  * fan out to internal side streams and are joined before the call's last kernels).          */
 void *lbzamd_stream(lbzamd_ctx *ctx);

@@ -19,7 +19,7 @@ EXPORTS = [
     "lbzamd_encoder_alloc_size", "lbzamd_encoder_init", "lbzamd_collect", "lbzamd_encode",
     "lbzamd_transmit", "lbzamd_encoder_abandon",
     "lbzamd_create", "lbzamd_destroy", "lbzamd_last_error", "lbzamd_compress_device",
-    "lbzamd_compress_host", "lbzamd_bound", "lbzamd_get_stats", "lbzamd_stream", "lbzamd_slots", "lbzamd_set_sequential",
+    "lbzamd_compress_host", "lbzamd_bound", "lbzamd_get_stats", "lbzamd_stream", "lbzamd_slots", "lbzamd_round_shape", "lbzamd_set_sequential",
     "lbzamd_block_slots", "lbzamd_block_info_get", "lbzamd_read_stage", "lbzamd_run_stages",
     "lbzamd_compress_device_body", "lbzamd_compress_host_body", "lbzamd_fold_parts",
     "lbzamd_pinned_alloc", "lbzamd_pinned_free", "lbzamd_device_count",
@@ -139,6 +139,8 @@ class Library:
         lib.lbzamd_set_sequential.restype = C.c_int
         lib.lbzamd_slots.argtypes = [vp]
         lib.lbzamd_slots.restype = C.c_uint32
+        lib.lbzamd_round_shape.argtypes = [vp, C.c_uint32, C.c_int, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
+        lib.lbzamd_round_shape.restype = None
         lib.lbzamd_block_slots.argtypes = [vp]
         lib.lbzamd_block_slots.restype = C.c_uint32
         lib.lbzamd_block_info_get.argtypes = [vp, C.c_uint32, C.POINTER(BlockInfo)]
@@ -297,6 +299,12 @@ class Context:
     @property
     def nslots(self):
         return self.L.lib.lbzamd_slots(self.h)
+
+    def round_shape(self, blocks, overlapped):
+        """(segment workgroups per block in the sorting kernels, workgroups per block in the partition) of such a round."""
+        a, b = C.c_uint32(0), C.c_uint32(0)
+        self.L.lib.lbzamd_round_shape(self.h, blocks, 1 if overlapped else 0, C.byref(a), C.byref(b))
+        return a.value, b.value
 
     @property
     def stream(self):

@@ -266,6 +266,23 @@ static int timed_end(lbzamd_ctx *c, size_t *nbev, hipStream_t s)
   return 0;
 }
 
+/* Workgroups per block of a round of `count` blocks: in the sorting kernels (segments), and in the partition (1 = k_bwt_part,
+ * every pass in one launch; else the launch-per-pass kernels with that many workgroups per block).  LBZAMD_PARTS: (tuning). */
+static u32 round_segs(const lbzamd_ctx *c, u32 count) { return count <= c->ncus ? LBZ_BWT_MAXSEGS : LBZ_BWT_SEGS; }
+static u32 round_parts(const lbzamd_ctx *c, u32 count, bool overlapped)
+{
+  static const int forced = getenv("LBZAMD_PARTS") ? atoi(getenv("LBZAMD_PARTS")) : 0;
+  if (forced > 0 && forced <= 16) return (u32)forced == 1u ? 1u : (u32)forced;
+  if (overlapped && count > c->ncus) return 1u;
+  return count <= c->ncus / 2u ? 16u : 8u;
+}
+
+extern "C" void lbzamd_round_shape(lbzamd_ctx *c, uint32_t blocks, int overlapped, uint32_t *segments, uint32_t *partition_wgs)
+{
+  if (segments) *segments = c ? round_segs(c, blocks) : 0u;
+  if (partition_wgs) *partition_wgs = c ? round_parts(c, blocks, overlapped != 0) : 0u;
+}
+
 /* The sorter's launches for the blocks of one round (nblk = 2 * count: primaries then spills; or count: the
  * listed primaries only): partition (one workgroup per block), then batches, tie lists, the deep-tie rounds --
  * one launch per doubling depth, every (block, segment) a workgroup (k_bwt.hip) -- and the origin pointers.     */
@@ -274,8 +291,8 @@ static void launch_sort(lbzamd_ctx *c, hipStream_t q, u32 first, u32 count, u32 
 {
   /* workgroups per block in the sorting kernels: more of them when the round has fewer blocks than the device has CUs -- the
      caller then waits for a block's chain of launches, and every launch is as long as its longest segment */
-  const u32 segs = count <= c->ncus ? LBZ_BWT_MAXSEGS : LBZ_BWT_SEGS;
-  if (phase == 0 && overlapped && count > c->ncus && !getenv("LBZAMD_PARTS")) {
+  const u32 segs = round_segs(c, count);
+  if (phase == 0 && round_parts(c, count, overlapped) == 1u) {
     /* big rounds side by side on several streams: one workgroup per block, every pass in one launch.  Three rounds of 371
        blocks overlapped: 8.1 GB/s against 7.8 with the launch-per-pass form, which alone on the device is the faster one
        (371 blocks: 9.6 ms against 14; 1112 blocks: 28.0 against 29.9) */
@@ -284,8 +301,7 @@ static void launch_sort(lbzamd_ctx *c, hipStream_t q, u32 first, u32 count, u32 
   } else if (phase == 0) {
     /* the partition, a launch per pass: more workgroups per block the fewer blocks the round has (a block's passes are what
        a small input waits for; a full device needs only enough workgroups to fill it evenly) */
-    static const int forced = getenv("LBZAMD_PARTS") ? atoi(getenv("LBZAMD_PARTS")) : 0;      /* (tuning) */
-    const u32 parts = forced > 0 && forced <= 16 ? (u32)forced : (count <= c->ncus / 2u ? 16u : 8u);
+    const u32 parts = round_parts(c, count, overlapped);
     const dim3 g(lbz_seg_grid(nblk, parts));
     hipLaunchKernelGGL(k_bwt_hist, g, dim3(LBZ_BWT_WG), 0, q, (const u8 *)c->T, c->meta, c->L,
                        first, count, nblk, parts, ws, (u64)c->slot_bytes, wsp, (u64)c->spill_bytes, lst);
