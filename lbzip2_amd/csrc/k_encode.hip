@@ -20,6 +20,11 @@
  *
  * Traffic: 9 passes over the MTF symbols (8 E-steps + packing) = 18 B per symbol + output.
  */
+#include "lbz_common.h"
+#undef LBZ_WG
+#define LBZ_WG LBZ_ENCODE_WG
+#undef LBZ_NW
+#define LBZ_NW (LBZ_WG / 64)
 #include "lbz_kernels.h"
 
 #define PK_IPT 4u
@@ -29,30 +34,43 @@
 #define PM_ITEMS (2u * LBZ_MAX_ALPHA)
 static_assert(LBZ_WG >= 320 && LBZ_WG % 64 == 0, "tables are filled one symbol per thread");
 
+/* Three stretches of a block's coding need three sets of tables, one after the other: the EM rounds (cost fields, sorted
+ * weights, the merge's tree), the length-limited codes (package-merge lists, one table at a time) and the packing (bit
+ * window, selector bytes).  They share their LDS; what lives through all of them stands in front.  74 KB.            */
 struct enc_lds {
   wg_scratch sc;
-  u64 pack[LBZ_MAX_ALPHA + 2];
   u32 mfreq[LBZ_MAX_ALPHA + 2];
   u32 freq[LBZ_MAX_TREES][LBZ_MAX_ALPHA + 2];
   u8 len[LBZ_MAX_TREES][LBZ_MAX_ALPHA + 2];
-  u32 lc[LBZ_MAX_TREES][LBZ_MAX_ALPHA + 2];      /* code << 5 | length */
+  u32 lc[LBZ_MAX_TREES][LBZ_MAX_ALPHA + 2];      /* code << 5 | length (during the EM rounds: node depths of the M-step) */
   u8 sel[LBZ_MAX_SEL + 6];
-  u64 wsort[LBZ_MAX_TREES][LBZ_MAX_ALPHA];
-  u32 parent[LBZ_MAX_TREES][LBZ_MAX_ALPHA];
-  u32 dcnt[LBZ_MAX_TREES][2][32];
-  u32 lfreq[LBZ_MAX_ALPHA];
-  u32 items[PM_LEVELS + 1][PM_ITEMS];            /* reused as selector-MTF bytes when packing */
-  u16 leaves_in[PM_LEVELS + 1][PM_ITEMS + 2];
-  u32 nitems[PM_LEVELS + 2];
-  u32 taken[PM_LEVELS + 2][PM_LEVELS + 2];
-  u16 upto[PM_LEVELS + 2][PM_LEVELS + 2];
-  u8 hl[PM_LEVELS + 1][LBZ_MAX_ALPHA + 2];
-  u32 hcost[PM_LEVELS + 2];
-  u32 win[WIN_WORDS];
   u32 firstpos[LBZ_MAX_TREES];
   u32 old2new[LBZ_MAX_TREES], new2old[LBZ_MAX_TREES];
   u8 inuse[256];
   u32 bc[8];
+  union {
+    struct {
+      u64 pack[LBZ_MAX_ALPHA + 2];
+      u64 wsort[LBZ_MAX_TREES][LBZ_MAX_ALPHA];
+      u32 parent[LBZ_MAX_TREES][LBZ_MAX_ALPHA];
+      u32 dcnt[LBZ_MAX_TREES][2][32];
+    } em;
+    struct {
+      u64 wq[LBZ_MAX_ALPHA], wtmp[LBZ_MAX_ALPHA];
+      u32 lfreq[LBZ_MAX_ALPHA];
+      u32 items[2][PM_ITEMS];                    /* a level is built from the one below it only: two buffers */
+      u16 leaves_in[PM_LEVELS + 1][PM_ITEMS + 2];
+      u32 nitems[PM_LEVELS + 2];
+      u32 taken[PM_LEVELS + 2][PM_LEVELS + 2];
+      u16 upto[PM_LEVELS + 2][PM_LEVELS + 2];
+      u8 hl[PM_LEVELS + 1][LBZ_MAX_ALPHA + 2];
+      u32 hcost[PM_LEVELS + 2];
+    } lim;
+    struct {
+      u32 win[WIN_WORDS];
+      u8 selmtf[LBZ_MAX_SEL + 8];
+    } pk;
+  } u;
 };
 
 __device__ __forceinline__ u64 leaf_weight(u32 f, u32 sym)
@@ -90,10 +108,10 @@ __device__ void seed_tables(enc_lds *S, u32 as, u32 nm, u32 nt)
 __device__ void huffman_lengths_wave(enc_lds *S, u32 t, u32 as)
 {
   const u32 lane = threadIdx.x & 63u;
-  u64 *w = S->wsort[t];
-  u32 *par = S->parent[t];
+  u64 *w = S->u.em.wsort[t];
+  u32 *par = S->u.em.parent[t];
   u32 *depth = S->lc[t];                                /* free until limited_code() writes the final codes */
-  u32 *internal_at = S->dcnt[t][0], *leaves_at = S->dcnt[t][1];
+  u32 *internal_at = S->u.em.dcnt[t][0], *leaves_at = S->u.em.dcnt[t][1];
   constexpr u32 UNK = 0xFFFFFFFFu;
   for (u32 i = lane; i < as; i += 64u) depth[i] = i == 1u ? 0u : UNK;
   if (lane < 32u) internal_at[lane] = 0;
@@ -193,8 +211,8 @@ __device__ __forceinline__ u32 rank_desc(const u64 *w, u32 as, u32 i)
 __device__ u32 limited_code(enc_lds *S, u32 t, u32 as)
 {
   const u32 tid = threadIdx.x;
-  u64 *wq = S->wsort[0];                 /* M-step scratch is free now */
-  u64 *wtmp = S->wsort[1];
+  u64 *wq = S->u.lim.wq;
+  u64 *wtmp = S->u.lim.wtmp;
   const u32 want = 2u * as - 2u;
 
   if (tid < as) wtmp[tid] = leaf_weight(S->freq[t][tid], tid);
@@ -203,11 +221,11 @@ __device__ u32 limited_code(enc_lds *S, u32 t, u32 as)
   __syncthreads();
   if (tid < as) {
     const u32 f = (u32)(wq[as - 1u - tid] >> 32);       /* ascending */
-    S->lfreq[tid] = f;
-    S->items[1][tid] = f;
-    S->leaves_in[1][tid + 1u] = (u16)(tid + 1u);
+    S->u.lim.lfreq[tid] = f;
+    S->u.lim.items[1][tid] = f;
+    S->u.lim.leaves_in[1][tid + 1u] = (u16)(tid + 1u);
   }
-  if (tid == 0) { S->nitems[1] = as; S->leaves_in[1][0] = 0; }
+  if (tid == 0) { S->u.lim.nitems[1] = as; S->u.lim.leaves_in[1][0] = 0; }
   __syncthreads();
 
   /* one barrier per level: the item counts follow from as alone (every thread keeps them), a package's weight is the
@@ -215,26 +233,26 @@ __device__ u32 limited_code(enc_lds *S, u32 t, u32 as)
   u32 nprev = as;
   for (u32 lv = 2; lv <= PM_LEVELS; lv++) {
     const u32 npk = nprev / 2u;
-    const u32 *below = S->items[lv - 1u];
+    const u32 *below = S->u.lim.items[(lv - 1u) & 1u];
     for (u32 e = tid; e < as + npk; e += LBZ_WG) {
       if (e < as) {                                     /* leaf: packages strictly lighter go first */
-        const u32 f = S->lfreq[e];
+        const u32 f = S->u.lim.lfreq[e];
         u32 lo = 0, hi = npk;
         while (lo < hi) { const u32 mid = (lo + hi) >> 1; if (below[2u * mid] + below[2u * mid + 1u] < f) lo = mid + 1u; else hi = mid; }
         const u32 pos = e + lo;
-        if (pos < want) { S->items[lv][pos] = f; S->leaves_in[lv][pos + 1u] = (u16)(e + 1u); }
+        if (pos < want) { S->u.lim.items[lv & 1u][pos] = f; S->u.lim.leaves_in[lv][pos + 1u] = (u16)(e + 1u); }
       } else {                                          /* package: leaves of equal weight go first */
         const u32 k = e - as;
         const u32 f = below[2u * k] + below[2u * k + 1u];
         u32 lo = 0, hi = as;
-        while (lo < hi) { const u32 mid = (lo + hi) >> 1; if (S->lfreq[mid] <= f) lo = mid + 1u; else hi = mid; }
+        while (lo < hi) { const u32 mid = (lo + hi) >> 1; if (S->u.lim.lfreq[mid] <= f) lo = mid + 1u; else hi = mid; }
         const u32 pos = k + lo;
-        if (pos < want) { S->items[lv][pos] = f; S->leaves_in[lv][pos + 1u] = (u16)lo; }
+        if (pos < want) { S->u.lim.items[lv & 1u][pos] = f; S->u.lim.leaves_in[lv][pos + 1u] = (u16)lo; }
       }
     }
     const u32 tot = as + npk;
     nprev = tot < want ? tot : want;
-    if (tid == 0) { S->nitems[lv] = nprev; S->leaves_in[lv][0] = 0; }
+    if (tid == 0) { S->u.lim.nitems[lv] = nprev; S->u.lim.leaves_in[lv][0] = 0; }
     __syncthreads();
   }
 
@@ -242,23 +260,23 @@ __device__ u32 limited_code(enc_lds *S, u32 t, u32 as)
      loop over the levels has given a length <= d -- kept exactly as that loop counts, saturation at `as` included */
   if (tid >= 1u && tid <= PM_LEVELS) {
     const u32 h = tid;
-    u32 k = want < S->nitems[h] ? want : S->nitems[h];
-    for (u32 d = 0; d <= PM_LEVELS; d++) S->taken[h][d] = 0;
+    u32 k = want < S->u.lim.nitems[h] ? want : S->u.lim.nitems[h];
+    for (u32 d = 0; d <= PM_LEVELS; d++) S->u.lim.taken[h][d] = 0;
     for (u32 d = 0; d < h; d++) {
       const u32 lv = h - d;
-      if (k > S->nitems[lv]) k = S->nitems[lv];
-      const u32 nl = S->leaves_in[lv][k];
-      S->taken[h][d] = nl;
+      if (k > S->u.lim.nitems[lv]) k = S->u.lim.nitems[lv];
+      const u32 nl = S->u.lim.leaves_in[lv][k];
+      S->u.lim.taken[h][d] = nl;
       k = 2u * (k - nl);
     }
     u32 cum = 0;
-    S->upto[h][0] = 0;
+    S->u.lim.upto[h][0] = 0;
     for (u32 d = 1; d <= h; d++) {
-      const u64 c = (u64)cum + (u64)(u32)(S->taken[h][d - 1u] - S->taken[h][d]);
+      const u64 c = (u64)cum + (u64)(u32)(S->u.lim.taken[h][d - 1u] - S->u.lim.taken[h][d]);
       cum = c < (u64)as ? (u32)c : as;
-      S->upto[h][d] = (u16)cum;
+      S->u.lim.upto[h][d] = (u16)cum;
     }
-    S->hcost[h] = (h >= 2u && (1u << h) >= as) ? 5u + as : 0u;
+    S->u.lim.hcost[h] = (h >= 2u && (1u << h) >= as) ? 5u + as : 0u;
   }
   __syncthreads();
 
@@ -267,52 +285,52 @@ __device__ u32 limited_code(enc_lds *S, u32 t, u32 as)
     const u32 h = 2u + e / as, rank = e % as;
     if ((1u << h) < as) continue;
     u32 d = 1u;
-    while (d <= h && (u32)S->upto[h][d] <= rank) d++;
+    while (d <= h && (u32)S->u.lim.upto[h][d] <= rank) d++;
     if (d <= h) {
       const u64 wr = wq[rank];
-      S->hl[h][LBZ_MAX_ALPHA - (u32)(wr & 0xFFFFull)] = (u8)d;
-      atomicAdd(&S->hcost[h], (u32)(wr >> 32) * d);
+      S->u.lim.hl[h][LBZ_MAX_ALPHA - (u32)(wr & 0xFFFFull)] = (u8)d;
+      atomicAdd(&S->u.lim.hcost[h], (u32)(wr >> 32) * d);
     }
   }
   __syncthreads();
   for (u32 e = tid; e < (PM_LEVELS - 1u) * as; e += LBZ_WG) {
     const u32 h = 2u + e / as, v = e % as;
     if ((1u << h) < as || v == 0u) continue;
-    const int dl = (int)S->hl[h][v] - (int)S->hl[h][v - 1u];
-    if (dl) atomicAdd(&S->hcost[h], 2u * (u32)(dl < 0 ? -dl : dl));
+    const int dl = (int)S->u.lim.hl[h][v] - (int)S->u.lim.hl[h][v - 1u];
+    if (dl) atomicAdd(&S->u.lim.hcost[h], 2u * (u32)(dl < 0 ? -dl : dl));
   }
   __syncthreads();
   if (tid == 0) {                                        /* first strict minimum, encode.c:913-945 */
     u32 best_cost = 0xFFFFFFFFu, best_h = PM_LEVELS;
     for (u32 h = 2; h <= PM_LEVELS; h++) {
       if ((1u << h) < as) continue;
-      if (S->taken[h][h - 1u] == 0u) break;
-      if (S->hcost[h] < best_cost) { best_cost = S->hcost[h]; best_h = h; }
+      if (S->u.lim.taken[h][h - 1u] == 0u) break;
+      if (S->u.lim.hcost[h] < best_cost) { best_cost = S->u.lim.hcost[h]; best_h = h; }
     }
     S->bc[0] = best_cost;
     S->bc[1] = best_h;
     u32 next = 0;                                        /* canonical first codes per length */
     for (u32 d = 1; d <= best_h; d++) {
-      const u32 k = S->taken[best_h][d - 1u] - S->taken[best_h][d];
-      S->hcost[d] = next;
+      const u32 k = S->u.lim.taken[best_h][d - 1u] - S->u.lim.taken[best_h][d];
+      S->u.lim.hcost[d] = next;
       next = (next + k) << 1;
     }
   }
   __syncthreads();
   const u32 best_cost = S->bc[0], best_h = S->bc[1];
   if (tid < as) {
-    const u32 l = S->hl[best_h][tid];
+    const u32 l = S->u.lim.hl[best_h][tid];
     u32 same = 0, v = 0;
     for (; v + 8u <= tid; v += 8u) {
       u32 x[8];
 #pragma unroll
-      for (u32 k = 0; k < 8u; k++) x[k] = S->hl[best_h][v + k];
+      for (u32 k = 0; k < 8u; k++) x[k] = S->u.lim.hl[best_h][v + k];
 #pragma unroll
       for (u32 k = 0; k < 8u; k++) same += x[k] == l;
     }
-    for (; v < tid; v++) same += S->hl[best_h][v] == l;
+    for (; v < tid; v++) same += S->u.lim.hl[best_h][v] == l;
     S->len[t][tid] = (u8)l;
-    S->lc[t][tid] = ((S->hcost[l] + same) << 5) | l;
+    S->lc[t][tid] = ((S->u.lim.hcost[l] + same) << 5) | l;
   }
   if (tid == as) { S->len[t][as] = 0; S->lc[t][as] = 0; }
   __syncthreads();
@@ -350,7 +368,7 @@ __device__ u32 flush_window(u32 *win, u32 *out32, u32 wbase, u64 endbit)
   return wbase + complete;
 }
 
-__global__ void __launch_bounds__(LBZ_WG)
+__global__ void __launch_bounds__(LBZ_WG, 4)
 k_encode(const u16 *Vbase, const u32 *freq_in, u8 *Obase, lbz_block_meta *meta, lbz_layout L, u32 first, u32 count, const u32 *slabs)
 {
   __shared__ enc_lds S;
@@ -369,7 +387,6 @@ k_encode(const u16 *Vbase, const u32 *freq_in, u8 *Obase, lbz_block_meta *meta, 
 
   for (u32 i = tid; i < LBZ_MAX_ALPHA + 2u; i += LBZ_WG) S.mfreq[i] = i < as ? freq_in[(size_t)blk * 260u + i] : 0u;
   for (u32 i = tid; i < LBZ_MAX_TREES * (LBZ_MAX_ALPHA + 2u); i += LBZ_WG) (&S.len[0][0])[i] = 1;
-  for (u32 i = tid; i < WIN_WORDS; i += LBZ_WG) S.win[i] = 0;
   if (tid < 256u) S.inuse[tid] = M->inuse[tid];
   __syncthreads();
   if (tid == 0) seed_tables(&S, as, nm, nt);
@@ -388,7 +405,7 @@ k_encode(const u16 *Vbase, const u32 *freq_in, u8 *Obase, lbz_block_meta *meta, 
       u64 x = 0;
       if (tid < as)
         for (int t = (int)LBZ_MAX_TREES - 1; t >= 0; t--) x = (x << 10) + S.len[t][tid];
-      S.pack[tid] = x;
+      S.u.em.pack[tid] = x;
     }
     for (u32 i = tid; i < LBZ_MAX_TREES * (LBZ_MAX_ALPHA + 2u); i += LBZ_WG) (&S.freq[0][0])[i] = 0;
     __syncthreads();
@@ -399,7 +416,7 @@ k_encode(const u16 *Vbase, const u32 *freq_in, u8 *Obase, lbz_block_meta *meta, 
 #pragma unroll
       for (u32 i = 0; i < LBZ_GROUP / 2u; i++) {
         sy[i] = mtfv32[g * (LBZ_GROUP / 2u) + i];
-        sum += S.pack[sy[i] & 0xFFFFu] + S.pack[sy[i] >> 16];
+        sum += S.u.em.pack[sy[i] & 0xFFFFu] + S.u.em.pack[sy[i] >> 16];
       }
       u32 bt = 0, bcst = (u32)(sum & 0x3FFull);
       for (u32 t = 1; t < nt; t++) {
@@ -424,21 +441,22 @@ k_encode(const u16 *Vbase, const u32 *freq_in, u8 *Obase, lbz_block_meta *meta, 
     for (u32 e = tid; e < nt * as; e += LBZ_WG) {
       const u32 t = e / as, i = e - t * as;
       const u32 f = S.freq[t][i];
-      S.wsort[t][i] = leaf_weight(f ? f : 1u, i);
+      S.u.em.wsort[t][i] = leaf_weight(f ? f : 1u, i);
     }
     __syncthreads();
-    u64 mine[2]; u32 rk2[2]; u32 cntm = 0;
+    constexpr u32 MW = (LBZ_MAX_TREES * LBZ_MAX_ALPHA + LBZ_WG - 1u) / LBZ_WG;   /* weights per thread */
+    u64 mine[MW]; u32 rk2[MW]; u32 cntm = 0;
     for (u32 e = tid; e < nt * as; e += LBZ_WG) {
       const u32 t = e / as, i = e - t * as;
-      mine[cntm] = S.wsort[t][i];
-      rk2[cntm] = rank_desc(S.wsort[t], as, i);
+      mine[cntm] = S.u.em.wsort[t][i];
+      rk2[cntm] = rank_desc(S.u.em.wsort[t], as, i);
       cntm++;
     }
     __syncthreads();
     cntm = 0;
     for (u32 e = tid; e < nt * as; e += LBZ_WG) {
       const u32 t = e / as;
-      S.wsort[t][rk2[cntm]] = mine[cntm];
+      S.u.em.wsort[t][rk2[cntm]] = mine[cntm];
       cntm++;
     }
     __syncthreads();
@@ -491,12 +509,15 @@ k_encode(const u16 *Vbase, const u32 *freq_in, u8 *Obase, lbz_block_meta *meta, 
     used = 2u;
     __syncthreads();
   }
+  /* the packing's tables take the place of the code tables from here on (limited_code() ends on a barrier; the scans of the
+     selector stage come before the first bit is deposited) */
+  for (u32 i = tid; i < WIN_WORDS; i += LBZ_WG) S.u.pk.win[i] = 0;
 
 #ifdef ENC_TICKS
   const u64 tk2 = wall_clock64();
 #endif
   /* ---- selector MTF, exact size, padding (encode.c:473-545) ---- */
-  u8 *selmtf = reinterpret_cast<u8 *>(&S.items[0][0]);
+  u8 *selmtf = S.u.pk.selmtf;
   /* Selector MTF (encode.c:473-492).  As in k_mtf: the rank of a group's table is the number of
      tables used more recently, so all that is serial is "where was table t last used before
      group g" -- one exclusive max-scan per table.  Positions are kept as g + 7; a table not used
@@ -579,25 +600,25 @@ k_encode(const u16 *Vbase, const u32 *freq_in, u8 *Obase, lbz_block_meta *meta, 
   u64 bitpos = 0;
   if (tid == 0) {
     u64 bp = 0;
-    put_bits(S.win, 0, bp, 24, 0x314159u); bp += 24;
-    put_bits(S.win, 0, bp, 24, 0x265359u); bp += 24;
-    put_bits(S.win, 0, bp, 32, ~M->crc); bp += 32;
+    put_bits(S.u.pk.win, 0, bp, 24, 0x314159u); bp += 24;
+    put_bits(S.u.pk.win, 0, bp, 24, 0x265359u); bp += 24;
+    put_bits(S.u.pk.win, 0, bp, 32, ~M->crc); bp += 32;
     bp += 1;                                              /* not randomised */
-    put_bits(S.win, 0, bp, 24, M->bwt_idx); bp += 24;
-    put_bits(S.win, 0, bp, 16, big); bp += 16;
+    put_bits(S.u.pk.win, 0, bp, 24, M->bwt_idx); bp += 24;
+    put_bits(S.u.pk.win, 0, bp, 16, big); bp += 16;
     for (u32 i = 0; i < 16u; i++)
       if (big & (0x8000u >> i)) {
         u32 pk = 0;
         for (u32 j = 0; j < 16u; j++) pk = (pk << 1) | (S.inuse[16u * i + j] ? 1u : 0u);
-        put_bits(S.win, 0, bp, 16, pk); bp += 16;
+        put_bits(S.u.pk.win, 0, bp, 16, pk); bp += 16;
       }
-    put_bits(S.win, 0, bp, 3, used); bp += 3;
-    put_bits(S.win, 0, bp, 15, nstx); bp += 15;
+    put_bits(S.u.pk.win, 0, bp, 3, used); bp += 3;
+    put_bits(S.u.pk.win, 0, bp, 15, nstx); bp += 15;
     S.bc[5] = (u32)bp;
   }
   __syncthreads();
   bitpos = S.bc[5];
-  wbase = flush_window(S.win, out32, wbase, bitpos);
+  wbase = flush_window(S.u.pk.win, out32, wbase, bitpos);
 
   /* selectors: value j as j ones and a zero */
   for (u32 t0 = 0; t0 < nstx; t0 += PK_TILE) {
@@ -611,11 +632,11 @@ k_encode(const u16 *Vbase, const u32 *freq_in, u8 *Obase, lbz_block_meta *meta, 
     for (u32 k = 0; k < PK_IPT; k++)
       if (i0 + k < nstx) {
         const u32 v = selmtf[i0 + k] + 1u;
-        put_bits(S.win, wbase, bp, v, (1u << v) - 2u);
+        put_bits(S.u.pk.win, wbase, bp, v, (1u << v) - 2u);
         bp += v;
       }
     bitpos += tot;
-    wbase = flush_window(S.win, out32, wbase, bitpos);
+    wbase = flush_window(S.u.pk.win, out32, wbase, bitpos);
   }
 
   /* code-length tables: 5-bit start, then +/-1 steps "10"/"11" and a "0" per symbol */
@@ -642,13 +663,13 @@ k_encode(const u16 *Vbase, const u32 *freq_in, u8 *Obase, lbz_block_meta *meta, 
       u32 tot;
       u64 bp = bitpos + wg_excl_add(nb, &tot, &S.sc);
       if (e < nitem) {
-        if (is_first) put_bits(S.win, wbase, bp, 5, first5);
+        if (is_first) put_bits(S.u.pk.win, wbase, bp, 5, first5);
         else {
           u32 left = steps;
           while (left) {                                 /* <=16 steps (32 bits) per deposit */
             const u32 c = left < 16u ? left : 16u;
             const u32 pat = up ? 0xAAAAAAAAu : 0xFFFFFFFFu;
-            put_bits(S.win, wbase, bp, 2u * c, pat >> (32u - 2u * c));
+            put_bits(S.u.pk.win, wbase, bp, 2u * c, pat >> (32u - 2u * c));
             bp += 2u * c;
             left -= c;
           }
@@ -656,7 +677,7 @@ k_encode(const u16 *Vbase, const u32 *freq_in, u8 *Obase, lbz_block_meta *meta, 
         }
       }
       bitpos += tot;
-      wbase = flush_window(S.win, out32, wbase, bitpos);
+      wbase = flush_window(S.u.pk.win, out32, wbase, bitpos);
     }
   }
 
@@ -686,15 +707,15 @@ k_encode(const u16 *Vbase, const u32 *freq_in, u8 *Obase, lbz_block_meta *meta, 
 #pragma unroll
       for (u32 k = 0; k < PK_IPT; k++) {
         const u32 l = lcv[k] & 31u;
-        put_bits(S.win, wbase, bp, l, lcv[k] >> 5);
+        put_bits(S.u.pk.win, wbase, bp, l, lcv[k] >> 5);
         bp += l;
       }
       bitpos += tot;
-      wbase = flush_window(S.win, out32, wbase, bitpos);
+      wbase = flush_window(S.u.pk.win, out32, wbase, bitpos);
     }
   }
   if (tid == 0) {
-    if (bitpos & 31ull) out32[wbase] = bswap32(S.win[0]);
+    if (bitpos & 31ull) out32[wbase] = bswap32(S.u.pk.win[0]);
     M->out_len = out_len;
     M->num_trees = used;
     M->num_sel = nstx;

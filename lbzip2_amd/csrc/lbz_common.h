@@ -31,6 +31,11 @@
 #ifndef LBZ_COLLECT_WG
 #define LBZ_COLLECT_WG 512  /* k_collect's own geometry: scans and barriers, two workgroups per CU wait less on each other (-13 %) */
 #endif
+#ifndef LBZ_ENCODE_WG
+#define LBZ_ENCODE_WG 512   /* k_encode's own geometry: 74 KB of LDS and eight waves, so that two workgroups share a CU -- one's serial stretches
+                               (a Huffman merge is one lane for 80 us) run beside the other's parallel ones -- and a workgroup finds room
+                               beside the sorters' (one 141 KB, sixteen-wave workgroup needed a CU to itself) */
+#endif
 #define LBZ_HEAD_SLABS 96u  /* host-buffer calls: slabs of the short first round (the device starts after 1.5 ms of PCIe traffic) */
 #define LBZ_FINISH_WG 256   /* k_offsets / k_gather: small workgroups -- a sixteen-wave workgroup that needs a whole CU's wave slots
                                at once waits tens of milliseconds behind the sorters' small workgroups (profiles/r03_h_host_timeline.txt) */
