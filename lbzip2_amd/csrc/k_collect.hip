@@ -65,7 +65,7 @@ __device__ __forceinline__ u32 crc_xpow(u32 nbits)     /* x^nbits mod P */
 }
 
 /* CRC (init 0xFFFFFFFF, no final inversion) of x[a..b).  All threads must call. */
-__device__ u32 wg_crc32(const u8 *x, u32 a, u32 b, u32 xlen, collect_lds *S)
+__device__ __forceinline__ u32 wg_crc32(const u8 *x, u32 a, u32 b, u32 xlen, collect_lds *S)
 {
   const u32 tid = threadIdx.x;
   const u32 len = b - a;
@@ -140,7 +140,7 @@ __device__ __forceinline__ u32 run_count(const u8 *x, u32 q, u32 end, u8 byte, b
  * [1] = first unconsumed position (== end if everything fitted).  EMIT = false: the same decisions without
  * the output (count bytes, staging, stores, used-byte map) -- where the block ends, nothing else.          */
 template <bool EMIT = true>
-__device__ void collect_pass(const u8 *x, u32 base, u32 end, u32 cap, u8 *out, collect_lds *S,
+__device__ __forceinline__ void collect_pass(const u8 *x, u32 base, u32 end, u32 cap, u8 *out, collect_lds *S,
                              u32 t_resume = 0xFFFFFFFFu, u32 o_resume = 0, u32 rs_resume = 0)
 {
   const u32 tid = threadIdx.x;
@@ -386,7 +386,7 @@ __device__ __forceinline__ u32 skip_count(const skip_regs &r, u64 act, u64 heads
   return nout;
 }
 
-__device__ void seq_skip(const u8 *x, u32 base, u32 end, u32 cap, collect_lds *S, u32 *t_out, u32 *o_out, u32 *rs_out)
+__device__ __forceinline__ void seq_skip(const u8 *x, u32 base, u32 end, u32 cap, collect_lds *S, u32 *t_out, u32 *o_out, u32 *rs_out)
 {
   const u32 tid = threadIdx.x;
   const bool vec_ok = ((uintptr_t)x & 15u) == 0u;
