@@ -15,8 +15,9 @@
  * atomics), every sort (rank by counting), the package-merge lists (each level is one
  * parallel merge of leaves and packages by binary search), the per-height cost evaluation,
  * and the bit packer (code lengths -> workgroup add-scan -> each lane ORs its codes into an
- * LDS window that is flushed as big-endian words).  What stays serial on one lane: the
- * 257-step Huffman merge per table and the 6-entry selector MTF.
+ * LDS window that is flushed as big-endian words), the selector MTF (a max-scan per table).  What stays serial
+ * on one lane: the 257-step Huffman merge per table (a wave per table; the rest of the M-step is the wave's).
+ * 512 threads and 73 KB of LDS: two blocks share a CU (enc_lds below).
  *
  * Traffic: 9 passes over the MTF symbols (8 E-steps + packing) = 18 B per symbol + output.
  */
