@@ -20,6 +20,11 @@
  *
  * Traffic: reads N_rle bytes twice (+1 B/pos of rank scratch), writes 2 B per MTF symbol.
  */
+#include "lbz_common.h"
+#undef LBZ_WG
+#define LBZ_WG LBZ_MTF_WG
+#undef LBZ_NW
+#define LBZ_NW (LBZ_WG / 64)
 #include "lbz_kernels.h"
 
 #define MTF_IPT 16u

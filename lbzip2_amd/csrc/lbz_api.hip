@@ -447,7 +447,7 @@ static int run_chunk(lbzamd_ctx *c, const u8 *d_in, size_t len, uint32_t nsl, in
       if (timed_end(c, &nbev, q)) return -1;
       if (upto >= 2) {
         if (timed_begin(c, &nbev, 3, q)) return -1;
-        hipLaunchKernelGGL(k_mtf, dim3(grid), dim3(LBZ_WG), 0, q, (const u8 *)c->B, c->R, c->V, c->freq, c->meta, c->L, first, count, nullptr);
+        hipLaunchKernelGGL(k_mtf, dim3(grid), dim3(LBZ_MTF_WG), 0, q, (const u8 *)c->B, c->R, c->V, c->freq, c->meta, c->L, first, count, nullptr);
         if (timed_end(c, &nbev, q)) return -1;
       }
       if (upto >= 3) {
@@ -1331,7 +1331,7 @@ static void pool_round(wu_pool *p, int stage, const std::vector<wu_req *> &batch
       const u32 count = cnt - o < c->nslots ? cnt - o : c->nslots;
       const u32 *lst = ln.d_list + o;
       for (int ph = 0; ph < 3; ph++) launch_sort(c, ln.q, 0u, count, count, ws, wsp, lst, ph);
-      hipLaunchKernelGGL(k_mtf, dim3(count), dim3(LBZ_WG), 0, ln.q, (const u8 *)c->B, c->R, c->V, c->freq, c->meta, c->L, 0u, count, lst);
+      hipLaunchKernelGGL(k_mtf, dim3(count), dim3(LBZ_MTF_WG), 0, ln.q, (const u8 *)c->B, c->R, c->V, c->freq, c->meta, c->L, 0u, count, lst);
       hipLaunchKernelGGL(k_encode, dim3(count), dim3(LBZ_ENCODE_WG), 0, ln.q, (const u16 *)c->V, (const u32 *)c->freq, c->O, c->meta, c->L, 0u, count, lst);
     }
   }

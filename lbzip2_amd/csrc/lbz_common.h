@@ -31,6 +31,9 @@
 #ifndef LBZ_COLLECT_WG
 #define LBZ_COLLECT_WG 512  /* k_collect's own geometry: scans and barriers, two workgroups per CU wait less on each other (-13 %) */
 #endif
+#ifndef LBZ_MTF_WG
+#define LBZ_MTF_WG 1024     /* k_mtf: a wave per slice, sixteen slices per block (512: 7.5 -> 8.0 ms alone, -0.5 % on three streams; 256: -1 %) */
+#endif
 #ifndef LBZ_ENCODE_WG
 #define LBZ_ENCODE_WG 512   /* k_encode's own geometry: 74 KB of LDS and eight waves, so that two workgroups share a CU -- one's serial stretches
                                (a Huffman merge is one lane for 80 us) run beside the other's parallel ones -- and a workgroup finds room
