@@ -54,7 +54,9 @@
 #define LBZ_BWT_SEGS 32u    /* segments of a block's sorted rows = workgroups per block in k_bwt_batch / k_bwt_deep / k_bwt_fix*: fewer blocks at a time
                                per XCD, so more of their text in its L2 for the text rounds (16: wiki -3 %, Python sources -8 %) */
 #endif
+#ifndef LBZ_DEEP_ROUNDS
 #define LBZ_DEEP_ROUNDS 8u  /* launches of k_bwt_deep (the text rounds) per round of blocks */
+#endif
 #define LBZ_BWT_MAXSEGS 32u /* ... and in rounds of fewer blocks than CUs, where a block's chain of launches is what the caller waits for */
 
 /* Per-block record in HBM.  Blocks are numbered 2*slab (primary) and 2*slab+1 (spill). */
