@@ -13,9 +13,12 @@
  *                workgroups (ranges of the pass's input; a pass counts the next pass's digits per range while it
  *                scatters).  Keys are built on the fly from the block text streamed through an LDS tile (the first pass
  *                never reads a key array); per-wave digit counters in LDS, ranks inside a wave from 8 ballots per row, a
- *                tile regrouped by digit in LDS so that every write is a run of equal-digit rows.  k_bwt_segs fixes the
- *                SEGMENTS: 16 or 32 cuts of the sorted rows at group boundaries -- from here on every (block, segment)
+ *                tile regrouped by digit in LDS so that every write is a run of equal-digit rows; the next tile's rows are
+ *                in flight while a tile is ranked (unconditional global loads: lbz_asm.h, ldg_*).  k_bwt_segs fixes the
+ *                SEGMENTS: 32 cuts of the sorted rows at group boundaries -- from here on every (block, segment)
  *                is a workgroup.
+ *   k_bwt_part   the same partition as one workgroup per block, every pass in one launch: what launch_sort picks when big
+ *                rounds run side by side on several streams.
  *   k_bwt_batch  consecutive whole groups of <= 1024 rows are pulled into LDS.  Waves claim chunks of groups (longest
  *                first); rows of a short group are placed by counting smaller keys, long groups are radix-sorted by their
  *                wave.  A finished batch writes 1 B (BWT byte) + 4 B (suffix-array entry) per rotation; rows whose 64-bit
