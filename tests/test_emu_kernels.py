@@ -58,15 +58,17 @@ def test_streams_multi_slab_spill_chunked(emu):
 
 
 def test_rounds_of_many_and_of_few_blocks(emu):
-    """Rounds with more blocks than the (emulated, 8-CU) device has CUs take 16 segment workgroups per block, smaller
-    rounds 32; the partition runs a launch per pass with 4-16 workgroups per block (k_bwt_hist / k_bwt_scat / k_bwt_segs),
-    or -- rounds of more blocks than CUs side by side on several streams -- as one workgroup per block (k_bwt_part)
-    (lbz_api.hip: launch_sort).  Same stream."""
+    """The partition runs a launch per pass with 8-16 workgroups per block (k_bwt_hist / k_bwt_scat / k_bwt_segs), or --
+    rounds of more blocks than the (emulated, 8-CU) device has CUs side by side on several streams -- as one workgroup per
+    block (k_bwt_part) (lbz_api.hip: launch_sort; lbzamd_round_shape says which).  Same stream."""
     data = bytes(gen("wiki", 1_130_000, 6) + gen("text", 520_000, 8) + gen("rand", 400_000, 9))       # 21 slabs at -1
     want = L.orc_compress(data, 1)
     for max_slabs, nslots in ((21, 21), (21, 4), (21, 10)):
         with emu.context(1, max_slabs, nslots) as ctx:
             assert ctx.compress(data) == want, (max_slabs, nslots)
+            segs, parts = ctx.round_shape(nslots, True)
+            assert segs == 32 and parts == (1 if nslots > 8 else 16 if nslots <= 4 else 8), (nslots, segs, parts)
+            assert ctx.round_shape(nslots, False)[1] in (8, 16)
 
 
 def test_round_schedule(emu, monkeypatch):
