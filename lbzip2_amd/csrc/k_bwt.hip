@@ -1914,6 +1914,8 @@ __device__ void deep_big_run(deep_wave *W, u32 lane, u32 p, u32 g, deep_lists Ls
   const u32 rank0 = Ls.gin[p];
   const u32 d0 = Ls.din[p];
   if (lane == 0u) { W->st_off[0] = 0u; W->st_len[0] = g; W->st_dep[0] = d0; W->st_buf[0] = 0u; W->sp = 1u; }
+  if (R.live)                                                     /* as for the strips: rank and depth at the start of the launch */
+    for (u32 k = lane; k < g; k += 64u) R.isa[SA_IDX(ping[p + k])] = ISA_ENTRY_D(rank0, rank0, 0u, d0);
   wave_sync();
   for (;;) {
     const u32 sp = W->sp;
@@ -2171,6 +2173,12 @@ k_bwt_deep(const u8 *Tbase, u8 *Bbase, lbz_block_meta *meta, lbz_layout L, u32 f
         continue;
       }
       const bool in = lane < cut;
+      /* What the list knows about a row -- its run's rank and the symbols the run shares, both as they stood when this launch
+         began -- goes into the row's rank entry before the strip starts: an entry is otherwise only written when a rank
+         CHANGES, so the depth of a long repeat stayed what it was at its last split, and the runs that look it up stepped
+         through the repeat fifty symbols at a time (thousands of round trips in the last launches; Python sources: 5.7 ms in
+         one launch for two thousand rows a block).  Tag 0 = "not of this launch": a reader takes rank and depth as they are. */
+      if (in && R.live) R.isa[SA_IDX(val)] = ISA_ENTRY_D(g, g, 0u, d);
       const u32 row = g + (lane - hl);                  /* places are fixed: the run's rows are consecutive from its rank on */
       if (!in) hl = lane;
       bool tied = in, longmode = false;
