@@ -189,6 +189,15 @@ def test_c_side_multi_device(emu, tmp_path):
     assert r.returncode == 0 and r.stdout == want, r.stderr[-400:]
 
 
+def test_long_repeats_step_by_ranks(emu):
+    """Passages of thousands of symbols that occur two and three times (a source tree's licence headers, copied files): the
+    rows they tie outlast the first text launches, get rank entries and step through the repeat by ranks -- with the depth
+    a run had when the launch began written into its rows' entries first (k_bwt_deep).  All stages against the oracle."""
+    a, b, c = gen("wiki", 9000, 21), gen("text", 6000, 22), gen("wiki", 2500, 23)
+    data = gen("wiki", 8000, 24) + a + gen("text", 3000, 25) + b + a[:7000] + gen("rand", 500, 26) + b + c + a + c[:2000] + b[1000:]
+    _stages(emu, bytes(data), 1)
+
+
 def test_oversized_runs_at_segment_bounds(emu):
     """Case 10 of the decoder fuzz (seed 41: tests/test_decode.py::test_fuzz_on_the_gpu): three byte values, nearly
     periodic, so that groups of more than a batch of EQUAL keys lie on both sides of a segment bound.  Such a group trades
