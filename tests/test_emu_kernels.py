@@ -190,9 +190,14 @@ def test_c_side_multi_device(emu, tmp_path):
 
 
 def test_long_repeats_step_by_ranks(emu):
-    """Passages of thousands of symbols that occur two and three times (a source tree's licence headers, copied files): the
-    rows they tie outlast the first text launches, get rank entries and step through the repeat by ranks -- with the depth
-    a run had when the launch began written into its rows' entries first (k_bwt_deep).  All stages against the oracle."""
+    """Passages of thousands of symbols that occur two and three times (a source tree's licence headers, copied files).
+    First input: a third of the rows are tied after the first text launch, so the block stays with the text rounds; the rows
+    of the repeats outlast them launch after launch (tied rows per launch 27059, 15803, 12828, 12204, 7112, 338, 28; least
+    depth 9, 10, 36, 116, 810, 836, 1285: a -DDEEP_DEBUG build prints them), get rank entries and step through the repeats by
+    ranks -- with the depth a run had when the launch began written into its rows' entries first (k_bwt_deep).  Second
+    input: four fifths tied after the first launch: handed to the rank rounds.  All stages against the oracle."""
+    P, Q, base = gen("wiki", 4000, 32), gen("text", 2500, 33), gen("wiki", 40000, 34)
+    _stages(emu, bytes(base[:15000] + P + base[15000:30000] + P + base[30000:] + Q + Q), 1)
     a, b, c = gen("wiki", 9000, 21), gen("text", 6000, 22), gen("wiki", 2500, 23)
     data = gen("wiki", 8000, 24) + a + gen("text", 3000, 25) + b + a[:7000] + gen("rand", 500, 26) + b + c + a + c[:2000] + b[1000:]
     _stages(emu, bytes(data), 1)
