@@ -184,6 +184,49 @@ def real_leg(lib, torch, name, target, level, local, roots=REAL_ROOTS, suffixes=
     if made is None:
         return {"config": name, "skipped": "the file set is not on this box"}
     data, count, md5 = made
+    what = f"tar of {count} real files of this image ({', '.join(roots)}; sorted, no repeats), {len(data)} B, md5 {md5}, -{level}"
+    return data_leg(lib, torch, name, what, data, level, local, steps)
+
+
+# the real corpora BASELINE.json names, where a box holds them: environment variable -> (config, levels)
+CORPORA = [("LBZ_ENWIK8", "C1 enwik8 (real file)", (9,)), ("LBZ_SILESIA", "C3 Silesia corpus, concatenated (real file)", (1, 9)),
+           ("LBZ_LINUX_TAR", "C5 Linux kernel tarball (real file)", (9,))]
+
+
+def corpus_legs(lib, torch, local):
+    """$LBZ_ENWIK8 / $LBZ_SILESIA / $LBZ_LINUX_TAR (and $LBZ_ENWIK9 through --kind wiki): the real corpora of BASELINE.json
+    where a box has them.  No fixture can exist for a file this repository has never seen, so the stream is checked on the
+    box against the compiled reference (oracle/_ref), as the real-file legs are."""
+    out = []
+    for var, name, levels in CORPORA:
+        path = os.environ.get(var)
+        if not path or not os.path.isfile(path):
+            continue
+        data = bytearray(open(path, "rb").read())
+        for level in levels:
+            what = f"{path}, {len(data)} B, md5 {hashlib.md5(data).hexdigest()}, -{level}"
+            out.append(data_leg(lib, torch, name, what, data, level, local))
+    return out
+
+
+def check_against_reference(z, data, level):
+    """Untimed checker: the stream against the compiled reference's for the same bytes (oracle/_ref; origin pointers of
+    exactly periodic blocks canonical), or, where that library is missing, through Python's bz2 and back."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_lib as L   # test infrastructure: the checker, after the timed region
+    try:
+        if L.have_ref():
+            aff, _ = usable_cpus()
+            want = L.ref_compress_mt(data, level, max(1, aff), canon=True)[0]
+            return z == want, "byte-identical to the compiled reference's stream (oracle/_ref, origin pointers of periodic blocks canonical)"
+    except Exception:                                   # noqa: BLE001 -- fall through to the independent decoder
+        pass
+    import bz2
+    return bz2.decompress(z) == bytes(data), "round trip through Python's bz2"
+
+
+def data_leg(lib, torch, name, what, data, level, local, steps=3):
+    """One device-resident leg over bytes that have no fixture: timed like the others, checked by check_against_reference."""
     n = len(data)
     M = level * 100000
     nslabs = (n + M - 1) // M
@@ -203,20 +246,8 @@ def real_leg(lib, torch, name, target, level, local, roots=REAL_ROOTS, suffixes=
     z = dst[:m].cpu().numpy().tobytes()
     del src, dst
     torch.cuda.empty_cache()
-    sys.path.insert(0, os.path.join(ROOT, "tests"))
-    import oracle_lib as L   # test infrastructure: the checker of this leg, after the timed region
-    ok, how = None, None
-    try:
-        if L.have_ref():
-            aff, _ = usable_cpus()
-            want = L.ref_compress_mt(data, level, max(1, aff), canon=True)[0]
-            ok, how = z == want, "byte-identical to the compiled reference's stream (oracle/_ref, origin pointers of periodic blocks canonical)"
-    except Exception:                                   # noqa: BLE001 -- fall through to the independent decoder
-        ok = None
-    if ok is None:
-        import bz2
-        ok, how = bz2.decompress(z) == bytes(data), "round trip through Python's bz2"
-    return {"config": name, "workload": f"tar of {count} real files of this image ({', '.join(roots)}; sorted, no repeats), {n} B, md5 {md5}, -{level}",
+    ok, how = check_against_reference(z, data, level)
+    return {"config": name, "workload": what,
             "value": round(n / dt / 1e6, 1), "unit": "MB/s", "ms_per_step": round(dt * 1e3, 2), "steps": steps, "blocks": st.nblocks,
             "ratio": round(n / max(1, m), 4), "verified": bool(ok), "verified_against": how,
             "kernel_ms_sum_over_streams": {k: round(v, 2) for k, v in kms.items()}}
@@ -400,6 +431,8 @@ def main():
             ok = len(stream) == fixture["out_len"] and hashlib.md5(stream).hexdigest() == fixture["canon_md5"]
             verified_against = (f"tests/golden/bench_fixtures.json {args.kind}({args.bytes}, seed {seed}) -{args.level}: "
                                 f"reference stream md5 {fixture['canon_md5']}, {fixture['out_len']} B")
+        elif source == "enwik9 file":
+            ok, verified_against = check_against_reference(stream, full, args.level)
         elif len(full) <= 300_000_000:
             import bz2
             ok = bz2.decompress(stream) == bytes(full)
@@ -506,6 +539,7 @@ def main():
             legs.append(real_leg(lib, torch, "C5 real files: tar of headers and sources", 1_000_000_000, args.level, local))
             legs.append(real_leg(lib, torch, "real files: Python sources only", 300_000_000, args.level, local,
                                  ["/usr/lib/python3", "/usr/lib/python3.10", "/usr/local/lib/python3.10/dist-packages"], (".py",)))
+        legs += corpus_legs(lib, torch, local)
 
     if rank == 0:
         nchunks = (nslabs + slabs - 1) // slabs
@@ -541,7 +575,7 @@ def main():
             pt = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
             if pt.get("workload") == f"{args.kind} -{args.level}":
                 tk = pt["kernels"]
-                cand = {"k_bwt_part": ["k_bwt_part2", "k_bwt_part"], "k_bwt_batch": ["k_bwt_batch", "k_bwt_fix", "k_bwt_fix0", "k_bwt_fixr", "k_bwt_fixend"]}.get(dom, [dom])
+                cand = {"k_bwt_part": ["k_bwt_part2", "k_bwt_part"], "k_bwt_batch": ["k_bwt_batch", "k_bwt_deep", "k_bwt_fix", "k_bwt_fix0", "k_bwt_fixr", "k_bwt_fixend"]}.get(dom, [dom])
                 kb = sum(2.0 * tk[c]["fetch_kb_per_slab"] + tk[c]["write_kb_per_slab"] for c in cand if c in tk)
                 if kb > 0:
                     traffic = round(kb * 1024.0 * nslabs * args.steps / launches)
@@ -589,6 +623,7 @@ def main():
                          "measured": ("one single-stream pass (LBZAMD_STREAMS=1): HIP events around every launch, nothing overlaps"
                                       if iso_tab else "live sums over the overlapping streams"),
                          "alg_bytes_per_launch": round(alg[dom] / max(1, dom_launches)), "launches_per_step": dom_launches,
+                         "traffic_over_alg": (round(traffic / max(1.0, alg[dom] / max(1, dom_launches)), 2) if traffic else None),
                          "avg_launch_ms": round(dom_ms / max(1, dom_launches), 3),
                          "overlapped": {"note": "HIP-event sums of the timed region's %s streams: a launch's time includes what it shares "
                                                 "with the other streams' kernels, so a kernel's sum can exceed ms_per_step"

@@ -192,6 +192,10 @@ int  lbzamd_decompress_alloc(lbzamd_dctx *ctx, const uint8_t *in, size_t len, ui
 void lbzamd_free(void *p);
 int  lbzamd_decompress_host(lbzamd_dctx *ctx, const uint8_t *in, size_t len, uint8_t *out, size_t out_cap, size_t *out_len);
 int  lbzamd_dget_stats(lbzamd_dctx *ctx, lbzamd_dstats *st);
+/* After a -3: WHY the stream was refused, as the reference's enum error (src/common.h:54-76: 3 ERR_MAGIC bad stream header
+ * ... 15 ERR_BLKCRC, 16 ERR_STRMCRC ... 19 ERR_EOF), so that a host program can word it as lbzip2 does
+ * (src/expand.c:69-94 err2str; lbzip2_amd/host/lbzamd.c).  0 after anything else.                                    */
+int  lbzamd_last_error_code(void);
 
 /* ------------------------------------------------------------------ (D) the inverse path's work-unit interface
  * reference src/decode.h:38-81, verbatim in its types and prototypes: one compressed block of one worker thread --

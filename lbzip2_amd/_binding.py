@@ -24,7 +24,7 @@ EXPORTS = [
     "lbzamd_compress_device_body", "lbzamd_compress_host_body", "lbzamd_fold_parts",
     "lbzamd_pinned_alloc", "lbzamd_pinned_free", "lbzamd_device_count",
     "lbzamd_dcreate", "lbzamd_ddestroy", "lbzamd_decompress_device", "lbzamd_decompress_host", "lbzamd_dget_stats",
-    "lbzamd_decompress_alloc", "lbzamd_free",
+    "lbzamd_decompress_alloc", "lbzamd_free", "lbzamd_last_error_code",
 ]
 
 

@@ -34,6 +34,11 @@ static int fail_msg(const char *what, hipError_t e)
 #define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) return fail_msg(#x, e_); } while (0)
 
 extern "C" const char *lbzamd_last_error(void) { return g_err.c_str(); }
+/* the reference's enum error (src/common.h:54-76) for a stream the decoder refused (return value -3), 0 otherwise */
+static thread_local int g_err_code;
+extern "C" int lbzamd_last_error_code(void) { return g_err_code; }
+enum { RE_MAGIC = 3, RE_HEADER = 4, RE_BLKCRC = 15, RE_STRMCRC = 16, RE_EOF = 19 };
+static int dec_error(int code, uint32_t nblock);
 
 static inline uint32_t round_up(uint32_t v, uint32_t a) { return (v + a - 1u) / a * a; }
 
@@ -904,7 +909,17 @@ extern "C" int lbzamd_decompress_device(lbzamd_dctx *c, const void *d_in_v, size
   hipStream_t q = c->q;
   c->stats = lbzamd_dstats{};
   c->stats.n_in = len;
-  if (len < 14) { g_err = "lbzamd_decompress: not a bzip2 stream (too short)"; return -3; }
+  g_err_code = 0;
+  if (len < 14) {
+    /* no room for a header and a trailer.  As the reference tells the two apart (process.c:664-681, expand.c:435): without
+       "BZh1".."BZh9" in front it is not a bzip2 file, with it the file ends too early */
+    uint8_t h4[4] = { 0, 0, 0, 0 };
+    if (len >= 4) HIPCHK(hipMemcpy(h4, d_in, 4, hipMemcpyDeviceToHost));
+    const bool hdr = len >= 4 && h4[0] == 'B' && h4[1] == 'Z' && h4[2] == 'h' && h4[3] >= '1' && h4[3] <= '9';
+    g_err = "lbzamd_decompress: not a bzip2 stream (too short)";
+    g_err_code = hdr ? RE_EOF : RE_MAGIC;
+    return -3;
+  }
   /* 1. magics */
   HIPCHK(hipEventRecord(c->ev[0], q));
   HIPCHK(hipMemsetAsync(c->nmarks, 0, sizeof(u32), q));
@@ -945,7 +960,7 @@ extern "C" int lbzamd_decompress_device(lbzamd_dctx *c, const void *d_in_v, size
   {
     const int h = header_at(0, &level0);
     if (h < 0) return fail_msg("hipMemcpy", hipGetLastError());
-    if (h == 0) { g_err = "lbzamd_decompress: not a bzip2 stream (bad header)"; return -3; }
+    if (h == 0) { g_err = "lbzamd_decompress: not a bzip2 stream (bad header)"; g_err_code = RE_MAGIC; return -3; }
     unsigned lvl = level0;
     for (size_t i = 0; i < marks.size(); i++) {
       const uint64_t bit = marks[i] >> 1;
@@ -1026,6 +1041,7 @@ extern "C" int lbzamd_decompress_device(lbzamd_dctx *c, const void *d_in_v, size
       if (bit > expect) {
         g_err = stream_blocks ? "lbzamd_decompress: no block or end-of-stream magic where the previous block ends (damaged or overrun block)"
                               : "lbzamd_decompress: no block magic behind the stream header";
+        g_err_code = RE_HEADER;
         return -3;
       }
       if (is_end) {
@@ -1045,6 +1061,7 @@ extern "C" int lbzamd_decompress_device(lbzamd_dctx *c, const void *d_in_v, size
         char buf[128];
         snprintf(buf, sizeof buf, "lbzamd_decompress: block %u: %s (code %u)", nblocks, b.err == 11 ? "CRC mismatch" : "malformed block", b.err);
         g_err = buf;
+        g_err_code = dec_error((int)b.err, b.nblock);
         return -3;
       }
       b.out_off = total;
@@ -1053,7 +1070,7 @@ extern "C" int lbzamd_decompress_device(lbzamd_dctx *c, const void *d_in_v, size
       expect = b.bit_used;
       nblocks++; stream_blocks++;
     }
-    if (last_batch && in_stream) { g_err = "lbzamd_decompress: stream without end-of-stream marker (truncated?)"; return -3; }
+    if (last_batch && in_stream) { g_err = "lbzamd_decompress: stream without end-of-stream marker (truncated?)"; g_err_code = RE_EOF; return -3; }
     if (c->grow_out && nb && total > out_cap) {
       /* the size is known only now (the blocks of this pass are decoded, their bytes not yet in place): a larger buffer,
          sized for the passes still to come as the blocks so far suggest, keeps what the earlier passes have written */
@@ -1092,7 +1109,7 @@ extern "C" int lbzamd_decompress_device(lbzamd_dctx *c, const void *d_in_v, size
       HIPCHK(hipMemcpy(tail.data(), d_in + by, nbytes, hipMemcpyDeviceToHost));
       std::vector<uint8_t> h(tail.begin(), tail.begin() + nbytes);
       const uint32_t want = rd_be32_bits(h, (tr.bit + 48) & 7u);
-      if (want != tr.cc) { g_err = "lbzamd_decompress: stream CRC mismatch"; return -3; }
+      if (want != tr.cc) { g_err = "lbzamd_decompress: stream CRC mismatch"; g_err_code = RE_STRMCRC; return -3; }
     }
   }
   c->stats.n_out = total;
@@ -1569,6 +1586,26 @@ void wd_put(wd_state *st, uint64_t v, unsigned n)       /* n <= 32 bits, right-a
   st->nbits += n;
   while (st->nacc >= 8u) { st->bits.push_back((uint8_t)(st->acc >> (st->nacc - 8u))); st->nacc -= 8u; }
 }
+/* whole words of the caller's buffer (big-endian in memory, decode.c:404) behind the st->nacc pending bits: four bytes a word */
+void wd_put_words(wd_state *st, const uint32_t *p, const uint32_t *limit)
+{
+  const size_t nw = (size_t)(limit - p);
+  if (!nw) return;
+  const size_t o = st->bits.size();
+  st->bits.resize(o + nw * 4u);
+  uint8_t *d = st->bits.data() + o;
+  const unsigned k = st->nacc;                            /* < 8 */
+  const uint64_t keep = (1ull << k) - 1ull;
+  uint64_t acc = st->acc & keep;
+  for (; p != limit; p++, d += 4) {
+    acc = (acc << 32) | (uint64_t)ntohl(*p);
+    const uint32_t w = (uint32_t)(acc >> k);
+    d[0] = (uint8_t)(w >> 24); d[1] = (uint8_t)(w >> 16); d[2] = (uint8_t)(w >> 8); d[3] = (uint8_t)w;
+    acc &= keep;
+  }
+  st->acc = acc;
+  st->nbits += 32u * (uint64_t)nw;
+}
 int wd_error(uint32_t code, uint32_t nblock)
 {
   switch (code) {
@@ -1583,6 +1620,9 @@ int wd_error(uint32_t code, uint32_t nblock)
     default: return WD_ERR_PREFIX;
   }
 }
+}  // namespace
+static int dec_error(int code, uint32_t nblock) { return code == 11 ? RE_BLKCRC : wd_error((uint32_t)code, nblock); }
+namespace {
 void wd_grow_host(u8 **p, size_t *cap, size_t want)
 {
   if (want <= *cap) return;
@@ -1716,7 +1756,7 @@ extern "C" int lbzamd_retrieve(struct decoder_state *ds, struct bitstream *bs)
   const uint64_t before = st->nbits;
   if (live0 > 32u) { wd_put(st, buff0 >> 32, 32u); wd_put(st, (buff0 << 32) >> (64u - (live0 - 32u)), live0 - 32u); }
   else if (live0) wd_put(st, buff0 >> (64u - live0), live0);
-  for (const uint32_t *p = data0; p != bs->limit; p++) wd_put(st, ntohl(*p), 32u);
+  wd_put_words(st, data0, bs->limit);
   /* decode what there is (with whatever the other worker threads have posted) */
   wd_req r{};
   r.st = st;
@@ -1727,7 +1767,17 @@ extern "C" int lbzamd_retrieve(struct decoder_state *ds, struct bitstream *bs)
   const lbz_dblock &rec = r.rec;
   if (r.past) {                                                /* everything is taken: MORE, or ERR_EOF at the end of the input */
     bs->live = 0; bs->buff = 0; bs->data = bs->limit;
-    return bs->eof ? WD_ERR_EOF : WD_MORE;
+    if (!bs->eof) return WD_MORE;
+    /* no more bits will come: an error the decoder flagged inside the last word is that error, as the reference reports
+       it (ERR_PREFIX, ERR_DELTA ...: common.h:54-76), not "unexpected end of file" (99 = it simply ran out of bits) */
+    return rec.err && rec.err != 99u ? wd_error(rec.err, rec.nblock) : WD_ERR_EOF;
+  }
+  /* A malformed block: the error, and the caller's stream taken as consumed -- where it stands means nothing then, and an
+     error position in front of THIS call's bits (it lay in the pad bits of the call before and came back as MORE) must
+     not be turned into a pointer. */
+  if (rec.err || rec.bit_used < 32u + before) {
+    bs->live = 0; bs->buff = 0; bs->data = bs->limit;
+    return wd_error(rec.err, rec.nblock);
   }
   /* the caller's stream stands behind the block's last code */
   {
@@ -1742,7 +1792,6 @@ extern "C" int lbzamd_retrieve(struct decoder_state *ds, struct bitstream *bs)
       bs->data = p;
     }
   }
-  if (rec.err) return wd_error(rec.err, rec.nblock);
   ds->rand = rec.randomised != 0u;
   ds->bwt_idx = rec.orig_ptr;
   ds->block_size = rec.nblock;

@@ -25,6 +25,15 @@ void lbzgen_rand(uint8_t *out, size_t n, uint32_t seed)
   for (size_t i = 0; i < n; i++) out[i] = (uint8_t)(xs32(&x) >> 24);
 }
 
+/* The same sequence in pieces: *state is the generator's state (the seed before the first piece) and is left
+   where the next piece goes on -- 10^10 bytes (C4 as BASELINE.json words it) need not be held at once. */
+void lbzgen_rand_from(uint8_t *out, size_t n, uint32_t *state)
+{
+  uint32_t x = *state;
+  for (size_t i = 0; i < n; i++) out[i] = (uint8_t)(xs32(&x) >> 24);
+  *state = x;
+}
+
 void lbzgen_text(uint8_t *out, size_t n, uint32_t seed)
 {
   static __thread char words[4096][10];

@@ -56,6 +56,49 @@ def record(kind, n, seed, level, config):
     return rec
 
 
+def record_c4_full(n=10_000_000_000, seed=4, level=9, piece_slabs=1000):
+    """C4 as BASELINE.json words it: 10 GB of random bytes at -9.  Neither the input nor the reference's stream is held at once:
+    slab-aligned pieces of the generator's sequence (lbzgen_rand_from) go through the compiled reference one by one; their
+    block bytes are the stream's body in order (every block is byte aligned) and the block CRCs fold into the trailer."""
+    import ctypes as C
+    g = C.CDLL(os.path.join(os.path.dirname(os.path.dirname(HERE)), "lbzip2_amd", "host", "libgen_inputs.so"))
+    g.lbzgen_rand_from.argtypes = [C.c_void_p, C.c_size_t, C.POINTER(C.c_uint32)]
+    g.lbzgen_rand_from.restype = None
+    M = level * 100000
+    state = C.c_uint32(seed)
+    hin, hout = hashlib.md5(), hashlib.md5()
+    hout.update(b"BZh" + bytes([48 + level]))
+    out_len, nblocks, cc, pieces, sec, done = 4, 0, 0, [], 0.0, 0
+    nt = os.cpu_count() or 1
+    while done < n:
+        ln = min(n - done, piece_slabs * M)
+        buf = bytearray(ln)
+        cb = (C.c_uint8 * ln).from_buffer(buf)
+        g.lbzgen_rand_from(cb, ln, C.byref(state))
+        del cb
+        hin.update(buf)
+        ref, blocks, s = L.ref_compress_mt(buf, level, nt)
+        body = ref[4:len(ref) - 10]
+        assert sum(b[0] for b in blocks) == len(body) and all(b[3] <= 1 for b in blocks)
+        hout.update(body)
+        pieces.append(md5(body))
+        for b in blocks:
+            cc = (((cc << 1) | (cc >> 31)) ^ b[1] ^ 0xFFFFFFFF) & 0xFFFFFFFF
+        out_len += len(body)
+        nblocks += len(blocks)
+        sec += s
+        done += ln
+        print("  C4 full:", done, "of", n, "bytes,", nblocks, "blocks", flush=True)
+    trailer = bytes.fromhex("177245385090") + cc.to_bytes(4, "big")
+    hout.update(trailer)
+    out_len += 10
+    m = hout.hexdigest()
+    return {"config": "C4 random, 10 GB as specified (streamed: rand continues over the pieces)", "kind": "rand", "n": n, "seed": seed,
+            "level": level, "in_md5": hin.hexdigest(), "out_len": out_len, "ref_md5": m, "canon_md5": m, "blocks": nblocks,
+            "periodic_blocks": 0, "combined_crc": cc, "piece_slabs": piece_slabs, "piece_md5": pieces,
+            "ref_MBps_all_cores_build_container": round(n / sec / 1e6, 1)}
+
+
 def periodic_corpus_blocks():
     out = []
     for name, raw in sorted(suite_inputs().items()):
@@ -73,6 +116,13 @@ def periodic_corpus_blocks():
 def main():
     assert L.have_ref(), "build oracle/_ref first (make -C oracle ref)"
     quick = len(sys.argv) > 1 and sys.argv[1] == "quick"
+    path = os.path.join(HERE, "bench_fixtures.json")
+    if len(sys.argv) > 1 and sys.argv[1] == "c4full":        # only (re)make the 10 GB record: ~3 minutes of the reference on 8 cores
+        rec = record_c4_full()
+        recs = [r for r in json.load(open(path)) if not (r["kind"] == "rand" and r["n"] == rec["n"])] + [rec]
+        json.dump(recs, open(path, "w"), indent=1)
+        print("C4 full:", rec["out_len"], rec["ref_md5"], rec["blocks"], "blocks")
+        return
     G = 1_000_000_000
     work = []
     # C2 (headline): enwik9-sized, level -9; one seed per rank of the weak-scaling bench (2 + rank)
@@ -99,7 +149,8 @@ def main():
     if quick:
         work = [w for w in work if w[1] <= 3_000_000]
     recs = [record(*w) for w in work]
-    path = os.path.join(HERE, "bench_fixtures.json")
+    if not quick:
+        recs.append(record_c4_full())
     if quick and os.path.exists(path):
         old = [r for r in json.load(open(path)) if r["n"] > 3_000_000]
         recs = old + recs

@@ -291,3 +291,81 @@ def test_foreign_streams_on_the_gpu():
     bad = bytearray(z); bad[len(bad) // 3] ^= 4
     with pytest.raises(lbzip2_amd.LbzError):
         lib.decompress(bytes(bad))
+
+
+def test_retrieve_error_just_in_front_of_a_chunk_boundary():
+    """decode.h's retrieve() (lbz_api.hip section D) fed in two pieces, with a malformed field (7 coding tables: ERR_TREES,
+    decode.c) a few bits in front of the first piece's end.  The first call cannot tell the error from running out of bits
+    (what it read there may have been pad bits) and asks for MORE; the second sees the same error at a bit position that
+    now lies in front of its own input -- it must come back as the reference's error code with the caller's bitstream left
+    consumed, not as a position computed from a negative offset (round-4 review: wild pointer)."""
+    import ctypes as C
+    import struct
+    import subprocess
+    emu_dir = os.path.join(os.path.dirname(os.path.abspath(__file__)), "emu")
+    subprocess.check_call(["make", "-s", "-C", emu_dir, "WG=1024"])
+    lib = C.CDLL(os.path.join(emu_dir, "_build", "liblbzamd_emu_1024.so"))
+
+    class BitStream(C.Structure):           # decode.h:38-45
+        _fields_ = [("live", C.c_uint), ("buff", C.c_uint64), ("block", C.c_void_p), ("data", C.POINTER(C.c_uint32)),
+                    ("limit", C.POINTER(C.c_uint32)), ("eof", C.c_bool)]
+
+    class DecoderState(C.Structure):        # decode.h:48-66
+        _fields_ = [("internal_state", C.c_void_p), ("rand", C.c_bool), ("bwt_idx", C.c_uint), ("block_size", C.c_uint),
+                    ("crc", C.c_uint32), ("ftab", C.c_uint32 * 256), ("tt", C.c_void_p), ("rle_state", C.c_int),
+                    ("rle_crc", C.c_uint32), ("rle_index", C.c_uint32), ("rle_avail", C.c_uint32), ("rle_char", C.c_uint8),
+                    ("rle_prev", C.c_uint8)]
+
+    lib.lbzamd_retrieve.argtypes = [C.POINTER(DecoderState), C.POINTER(BitStream)]
+    lib.lbzamd_decoder_init.argtypes = [C.POINTER(DecoderState)]
+    lib.lbzamd_decoder_free.argtypes = [C.POINTER(DecoderState)]
+    ERR_TREES, MORE, OK = 6, 1, 0           # common.h:54-76
+    data = bytes(gen("text", 20000, 3))
+    z = L.orc_compress(data, 1)
+    body = bytearray(z[14:]) + bytes(16)    # behind "BZh1", the block magic and the stored CRC: what retrieve() reads
+    # randomised (1) + origin pointer (24) + 16-bit map of ranges + 16 bits per used range, then the 3-bit table count
+    nranges = bin(int.from_bytes(body[3:6], "big") >> 7 & 0xFFFF).count("1")
+    pos = 1 + 24 + 16 + 16 * nranges
+    def words(b):
+        b = bytes(b) + bytes(-len(b) % 4)
+        return (C.c_uint32 * (len(b) // 4)).from_buffer_copy(b)     # big-endian words as they lie in the file (decode.c:404)
+
+    def call(ds, w, lo, hi, eof):
+        bs = BitStream()
+        bs.live, bs.buff, bs.eof = 0, 0, eof
+        base = C.cast(w, C.POINTER(C.c_uint32))
+        bs.data = C.cast(C.addressof(w) + 4 * lo, C.POINTER(C.c_uint32))
+        bs.limit = C.cast(C.addressof(w) + 4 * hi, C.POINTER(C.c_uint32))
+        rc = lib.lbzamd_retrieve(C.byref(ds), C.byref(bs))
+        return rc, (C.addressof(bs.data.contents) - C.addressof(w)) // 4, bs.live
+
+    # the intact block first, in two pieces: MORE, then OK with the stream left behind the block's last code
+    ds = DecoderState()
+    lib.lbzamd_decoder_init(C.byref(ds))
+    w = words(body)
+    cut = (pos + 3 + 31) // 32 + 1
+    rc, at, live = call(ds, w, 0, cut, False)
+    assert rc == MORE and at == cut
+    rc, at, live = call(ds, w, cut, len(w), True)
+    assert rc == OK and ds.block_size > 0 and cut <= at <= len(w)
+    lib.lbzamd_decoder_free(C.byref(ds))
+    # now 7 tables, and a first piece that ends less than a word behind the field
+    bad = bytearray(body)
+    for k in range(3):
+        bad[(pos + k) // 8] |= 0x80 >> ((pos + k) % 8)
+    w = words(bad)
+    ds = DecoderState()
+    lib.lbzamd_decoder_init(C.byref(ds))
+    cut = (pos + 3 + 31) // 32
+    rc, at, live = call(ds, w, 0, cut, False)
+    assert rc == MORE and at == cut and live == 0
+    rc, at, live = call(ds, w, cut, len(w), False)
+    assert rc == ERR_TREES, rc
+    assert at == len(w) and live == 0
+    lib.lbzamd_decoder_free(C.byref(ds))
+    # the same damage with nothing behind it and end of file: the error itself, not "unexpected end of file"
+    ds = DecoderState()
+    lib.lbzamd_decoder_init(C.byref(ds))
+    rc, at, live = call(ds, w, 0, cut, True)
+    assert rc == ERR_TREES, rc
+    lib.lbzamd_decoder_free(C.byref(ds))

@@ -58,7 +58,8 @@ def _fixture_id(r):
     return f"{r['kind']}-{r['n']}-s{r['seed']}-L{r['level']}"
 
 
-@pytest.mark.parametrize("rec", [r for r in bench_fixtures() if r["seed"] <= 5 and not (r["kind"] == "wiki" and r["seed"] not in (1, 2))],
+@pytest.mark.parametrize("rec", [r for r in bench_fixtures(max_n=2_000_000_000)
+                                 if r["seed"] <= 5 and not (r["kind"] == "wiki" and r["seed"] not in (1, 2))],
                          ids=_fixture_id)
 def test_baseline_configs_vs_reference(lib, rec):
     """Every BASELINE.json configuration that fits one GPU, at full size, against the stream of the
@@ -88,6 +89,54 @@ def test_baseline_configs_vs_reference(lib, rec):
         assert rec["canon_md5"] == rec["ref_md5"]
     if n <= 200_000_000:
         assert bz2.decompress(out) == bytes(data)
+
+
+def test_c4_ten_gigabytes_as_specified(lib):
+    """BASELINE.json configs[3] at the size it names: 10^10 random bytes at -9 -- `rand(10^10, seed 4)` -- through ONE context
+    in ONE call.  The context holds 1112 slabs, so the 11 112 slabs stream through it in ten chunks (stream position and CRC
+    fold carried from chunk to chunk in lbz_stream_state); input and stream are resident in HBM (20 GB of the 288), the host
+    only ever holds a piece: the input is generated piece by piece (lbzgen_rand_from continues the sequence) and the stream is
+    hashed piece by piece.  Fixture: the compiled reference on the same pieces (make_bench_fixtures.py c4full)."""
+    import ctypes as C
+    import hashlib
+    import torch
+    rec = [r for r in bench_fixtures(min_n=10_000_000_000) if r["kind"] == "rand"]
+    assert rec, "tests/golden/bench_fixtures.json has no 10^10-byte record (make_bench_fixtures.py c4full)"
+    rec = rec[0]
+    n, lvl = rec["n"], rec["level"]
+    g = C.CDLL(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "lbzip2_amd", "host", "libgen_inputs.so"))
+    g.lbzgen_rand_from.argtypes = [C.c_void_p, C.c_size_t, C.POINTER(C.c_uint32)]
+    g.lbzgen_rand_from.restype = None
+    src = torch.empty(n, dtype=torch.uint8, device="cuda")
+    dst = torch.empty(lib.bound(n), dtype=torch.uint8, device="cuda")
+    piece = 500_000_000
+    bufs = [torch.empty(piece, dtype=torch.uint8).pin_memory() for _ in range(2)]
+    state = C.c_uint32(rec["seed"])
+    hin = hashlib.md5()
+    with ThreadPoolExecutor(1) as ex:
+        pending = None
+        for i, off in enumerate(range(0, n, piece)):
+            ln = min(piece, n - off)
+            b = bufs[i & 1]
+            g.lbzgen_rand_from(b.data_ptr(), ln, C.byref(state))          # (the hash of the piece before runs beside it)
+            if pending is not None:
+                pending.result()
+            src[off:off + ln].copy_(b[:ln], non_blocking=False)
+            pending = ex.submit(hin.update, memoryview(b.numpy())[:ln])
+        pending.result()
+    assert hin.hexdigest() == rec["in_md5"]
+    with lib.context(lvl, 1112) as ctx:
+        m = ctx.compress_device(src.data_ptr(), n, dst.data_ptr(), dst.numel())
+        st = ctx.stats()
+    assert m == rec["out_len"] and st.nblocks == rec["blocks"] and st.nperiodic == 0
+    hout = hashlib.md5()
+    for off in range(0, m, piece):
+        ln = min(piece, m - off)
+        bufs[0][:ln].copy_(dst[off:off + ln])
+        hout.update(memoryview(bufs[0].numpy())[:ln])
+    tail = dst[m - 4:m].cpu().numpy().tobytes()
+    assert int.from_bytes(tail, "big") == rec["combined_crc"]
+    assert hout.hexdigest() == rec["ref_md5"]
 
 
 @pytest.mark.parametrize("rec", load("stages.json"),
