@@ -993,6 +993,8 @@ extern "C" int lbzamd_decompress_device(lbzamd_dctx *c, const void *d_in_v, size
   unsigned level = level0;
   bool in_stream = true, finished = false;      /* finished: the last stream is closed and what follows is not a header */
   uint32_t cc = 0, nblocks = 0, stream_blocks = 0;
+  int pend_code = 0;                            /* the first block-level error met on the chain (see the walk) */
+  std::string pend_msg;
   for (size_t b0 = 0; b0 < hb.size() || b0 == 0; b0 += c->max_blocks) {
     const u32 nb = (u32)std::min<size_t>(c->max_blocks, hb.size() - b0);
     if (nb) {
@@ -1056,13 +1058,26 @@ extern "C" int lbzamd_decompress_device(lbzamd_dctx *c, const void *d_in_v, size
         continue;
       }
       lbz_dblock &b = hb[ci];
-      if (!b.err && b.nblock > level * 100000u) b.err = 8;     /* more bytes than the stream's block size allows (decode.c: the same check) */
+      const bool kernel_ok = !b.err || b.err == 11u;            /* decoded to its last code (11: only the CRC differs) */
+      bool behind_the_block = b.err == 11u || b.err == 9u;     /* errors found with the block's bits all taken: the chain itself goes on */
+      if (!b.err && b.nblock > level * 100000u) { b.err = 8; behind_the_block = true; }   /* more bytes than the stream's block size allows (expand.c:726) */
       if (b.err) {
         char buf[128];
         snprintf(buf, sizeof buf, "lbzamd_decompress: block %u: %s (code %u)", nblocks, b.err == 11 ? "CRC mismatch" : "malformed block", b.err);
-        g_err = buf;
-        g_err_code = dec_error((int)b.err, b.nblock);
-        return -3;
+        /* What the reference's PROGRAM says (lbzamd_last_error_code).  Its parser walks the chain ahead of everything else and
+           fails at once on what IT finds (expand.c:395-491: a missing magic, a stream CRC that is not the fold of the stored
+           block CRCs, the end of the file), while a block's own status is reported only when the muxer reaches the block
+           (:726-735).  So (a) a block that breaks off inside its tables or codes leaves the parser at the bit where
+           retrieve() stopped, and what it finds there is not a block magic: ERR_HEADER; (b) an error noticed behind the
+           block's last code (CRC, size against the stream's level) is remembered, the walk goes on, and it is reported only
+           if the parser finds nothing of its own further down (the reference's decompressor suite: crc2). */
+        if (behind_the_block && kernel_ok) {
+          if (!pend_code) { pend_code = dec_error((int)b.err, b.nblock); pend_msg = buf; }
+        } else {
+          g_err = buf;
+          g_err_code = behind_the_block ? dec_error((int)b.err, b.nblock) : RE_HEADER;
+          return -3;
+        }
       }
       b.out_off = total;
       total += b.out_len;
@@ -1071,7 +1086,7 @@ extern "C" int lbzamd_decompress_device(lbzamd_dctx *c, const void *d_in_v, size
       nblocks++; stream_blocks++;
     }
     if (last_batch && in_stream) { g_err = "lbzamd_decompress: stream without end-of-stream marker (truncated?)"; g_err_code = RE_EOF; return -3; }
-    if (c->grow_out && nb && total > out_cap) {
+    if (c->grow_out && nb && total > out_cap && !pend_code) {
       /* the size is known only now (the blocks of this pass are decoded, their bytes not yet in place): a larger buffer,
          sized for the passes still to come as the blocks so far suggest, keeps what the earlier passes have written */
       const uint64_t prev = before;                           /* (not hb[b0].out_off: the batch's first candidate may be off the chain -- a
@@ -1086,7 +1101,7 @@ extern "C" int lbzamd_decompress_device(lbzamd_dctx *c, const void *d_in_v, size
       c->d_out = bigger; c->d_out_cap = want;
       d_out = bigger; out_cap = want;
     }
-    if (nb && total <= out_cap && d_out) {
+    if (nb && total <= out_cap && d_out && !pend_code) {
       HIPCHK(hipMemcpyAsync(c->blocks, hb.data() + b0, nb * sizeof(lbz_dblock), hipMemcpyHostToDevice, q));
       HIPCHK(hipEventRecord(c->ev[5], q));
       hipLaunchKernelGGL(k_demit, dim3(nb * 8u), dim3(256), 0, q, (const lbz_dblock *)c->blocks, nb, (const u8 *)c->W, (const u32 *)c->pinfo, d_out, (u64)out_cap, c->cap);
@@ -1112,6 +1127,7 @@ extern "C" int lbzamd_decompress_device(lbzamd_dctx *c, const void *d_in_v, size
       if (want != tr.cc) { g_err = "lbzamd_decompress: stream CRC mismatch"; g_err_code = RE_STRMCRC; return -3; }
     }
   }
+  if (pend_code) { g_err = pend_msg; g_err_code = pend_code; return -3; }
   c->stats.n_out = total;
   c->stats.ms_scan = ms[0]; c->stats.ms_huff = ms[1]; c->stats.ms_sort = ms[2]; c->stats.ms_walk = ms[3]; c->stats.ms_emit = ms[4];
   c->stats.ms_blocks = ms[5];

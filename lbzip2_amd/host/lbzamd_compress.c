@@ -12,24 +12,24 @@
  *             outside the scheduler lock, concurrently).
  *
  *   -f IN -o OUT   file splitter / muxer at line rate (process.c:260-307 source thread,
- *             :351-417 sink thread, compress.c:238-250 reorder): a reader thread fills a ring of
- *             page-locked chunk buffers (-c slabs per chunk), -p pipeline threads -- each with its own
- *             device context, so the H2D, kernels and D2H of consecutive chunks overlap -- compress
- *             chunks as body-only slab ranges (lbzamd_compress_host_body), and a writer thread drains
- *             them in order: header, bodies, trailer with the CRC folded from the 12-byte partials
- *             (lbzamd_fold_parts).  The file is never resident as a whole; the stream is the same
- *             single stream the batch call and reference lbzip2 produce.
+ *             :351-417 sink thread, compress.c:238-250 reorder) -- lbzamd_io.c: -R reader threads fill a ring of
+ *             page-locked chunk buffers (-c slabs per chunk; pread at chunk offsets on a regular file), -p pipeline
+ *             threads -- each with its own device context, so the H2D, kernels and D2H of consecutive chunks
+ *             overlap -- compress chunks as body-only slab ranges (lbzamd_compress_host_body), and -W writer threads
+ *             put every finished chunk whose offset is known in place (pwrite; a pipe: one writer, in order): header,
+ *             bodies, trailer with the CRC folded from the 12-byte partials (lbzamd_fold_parts).  The file is never
+ *             resident as a whole; the stream is the same single stream the batch call and reference lbzip2 produce.
  *
  *   -g N      (with -f/-o) the pipelines' contexts live on N devices, pipeline i on device i mod N (0 = every
- *             device; -p then counts pipelines PER device): the reader and the writer stay single threads, the
- *             chunks go to the GPUs by direct H2D from the pinned ring -- the C-side form of the reference's N
- *             workers behind one splitter/muxer (process.c:515-548, compress.c:73-118, :238-250).
+ *             device; -p then counts pipelines PER device): the chunks go to the GPUs by direct H2D from the pinned
+ *             ring -- the C-side form of the reference's N workers behind one splitter/muxer (process.c:515-548,
+ *             compress.c:73-118, :238-250).
  *
  *   lbzamd_compress [-1..-9] [-w N] < input > output.bz2
  *   lbzamd_compress [-1..-9] -f input -o output.bz2 [-c slabs] [-p pipelines] [-g devices] [-t]
  *
- * Not a CLI clone of lbzip2; it exists so the drop-in boundary is exercised
- * from C the way the reference would.
+ * A test driver, not the command: lbzip2's option surface is lbzamd.c.  This one exists so that the
+ * drop-in boundary is exercised from C the way the reference would.
  */
 #include <fcntl.h>
 #include <pthread.h>
@@ -40,6 +40,7 @@
 #include <time.h>
 
 #include "../../include/lbzip2_amd.h"
+#include "lbzamd_io.h"
 
 static double now_s(void)
 {
@@ -101,173 +102,29 @@ static void *worker(void *arg)
   }
 }
 
-/* ------------------------------------------------------------------ -f/-o: streaming splitter + muxer */
-enum { SL_FREE = 0, SL_FULL = 1, SL_BUSY = 2, SL_DONE = 3 };
-struct slot { unsigned char *in, *out; size_t len, out_len; lbzamd_part part; int state; size_t seq; };
-struct pipe {
-  int fd_in, fd_out;
-  unsigned level, nslots, ndev, next_pipe;
-  size_t chunk_bytes, out_cap;
-  struct slot *slots;
-  size_t next_read, next_compute, next_write;     /* chunk sequence numbers */
-  int eof;                                        /* reader saw the end: total chunks = next_read */
-  int failed;
-  pthread_mutex_t mu;
-  pthread_cond_t cv;
-  size_t total_in, total_out;
-};
-
-static void *reader_thread(void *arg)
-{
-  struct pipe *p = arg;
-  for (;;) {
-    pthread_mutex_lock(&p->mu);
-    struct slot *s = &p->slots[p->next_read % p->nslots];
-    while (s->state != SL_FREE && !p->failed) pthread_cond_wait(&p->cv, &p->mu);
-    pthread_mutex_unlock(&p->mu);
-    if (p->failed) return NULL;
-    size_t n = 0;
-    while (n < p->chunk_bytes) {                                   /* whole slabs per chunk: fill it completely */
-      ssize_t r = read(p->fd_in, s->in + n, p->chunk_bytes - n);
-      if (r < 0) { perror("read"); p->failed = 1; break; }
-      if (r == 0) break;
-      n += (size_t)r;
-    }
-    pthread_mutex_lock(&p->mu);
-    if (n == 0 || p->failed) { p->eof = 1; pthread_cond_broadcast(&p->cv); pthread_mutex_unlock(&p->mu); return NULL; }
-    s->len = n; s->seq = p->next_read; s->state = SL_FULL;
-    p->next_read++; p->total_in += n;
-    if (n < p->chunk_bytes) p->eof = 1;
-    pthread_cond_broadcast(&p->cv);
-    const int done = p->eof;
-    pthread_mutex_unlock(&p->mu);
-    if (done) return NULL;
-  }
-}
-
-static void *pipeline_thread(void *arg)
-{
-  struct pipe *p = arg;
-  lbzamd_ctx *ctx = NULL;
-  const size_t mbs = p->level * 100000ul;
-  pthread_mutex_lock(&p->mu);
-  const int device = p->ndev ? (int)(p->next_pipe++ % p->ndev) : -1;      /* -g: pipeline i on device i mod N */
-  pthread_mutex_unlock(&p->mu);
-  if (lbzamd_create(&ctx, device, p->level, (unsigned)(p->chunk_bytes / mbs), 0)) {
-    fprintf(stderr, "lbzamd: %s\n", lbzamd_last_error());
-    pthread_mutex_lock(&p->mu); p->failed = 1; pthread_cond_broadcast(&p->cv); pthread_mutex_unlock(&p->mu);
-    return NULL;
-  }
-  for (;;) {
-    pthread_mutex_lock(&p->mu);
-    struct slot *s = NULL;
-    for (;;) {
-      if (p->failed) break;
-      if (p->next_compute < p->next_read) { s = &p->slots[p->next_compute % p->nslots]; break; }   /* chunks are taken in order */
-      if (p->eof) break;
-      pthread_cond_wait(&p->cv, &p->mu);
-    }
-    if (!s) { pthread_mutex_unlock(&p->mu); break; }
-    p->next_compute++;
-    s->state = SL_BUSY;
-    pthread_mutex_unlock(&p->mu);
-    if (lbzamd_compress_host_body(ctx, s->in, s->len, s->out, p->out_cap, &s->out_len, &s->part)) {
-      fprintf(stderr, "lbzamd: %s\n", lbzamd_last_error());
-      pthread_mutex_lock(&p->mu); p->failed = 1; pthread_cond_broadcast(&p->cv); pthread_mutex_unlock(&p->mu);
-      break;
-    }
-    pthread_mutex_lock(&p->mu);
-    s->state = SL_DONE;
-    pthread_cond_broadcast(&p->cv);
-    pthread_mutex_unlock(&p->mu);
-  }
-  lbzamd_destroy(ctx);
-  return NULL;
-}
-
-static int write_all(int fd, const void *b, size_t n)
-{
-  const unsigned char *q = b;
-  while (n) { ssize_t w = write(fd, q, n); if (w < 0) { perror("write"); return -1; } q += w; n -= (size_t)w; }
-  return 0;
-}
-
-static void *writer_thread(void *arg)
-{
-  struct pipe *p = arg;
-  unsigned char hdr[HEADER_SIZE] = { 'B', 'Z', 'h', (unsigned char)('0' + p->level) };
-  uint32_t cc = 0;
-  if (write_all(p->fd_out, hdr, HEADER_SIZE)) p->failed = 1;
-  p->total_out = HEADER_SIZE;
-  for (;;) {
-    pthread_mutex_lock(&p->mu);
-    struct slot *s = &p->slots[p->next_write % p->nslots];
-    while (!p->failed && !(s->state == SL_DONE && s->seq == p->next_write) && !(p->eof && p->next_write >= p->next_read))
-      pthread_cond_wait(&p->cv, &p->mu);
-    const int fin = p->failed || !(s->state == SL_DONE && s->seq == p->next_write);
-    pthread_mutex_unlock(&p->mu);
-    if (fin) break;
-    if (write_all(p->fd_out, s->out, s->out_len)) { pthread_mutex_lock(&p->mu); p->failed = 1; pthread_cond_broadcast(&p->cv); pthread_mutex_unlock(&p->mu); break; }
-    cc = lbzamd_fold_parts(cc, &s->part, 1);                        /* compress.c:246-247, a whole range at a time */
-    p->total_out += s->out_len;
-    pthread_mutex_lock(&p->mu);
-    s->state = SL_FREE;
-    p->next_write++;
-    pthread_cond_broadcast(&p->cv);
-    pthread_mutex_unlock(&p->mu);
-  }
-  if (!p->failed) {
-    unsigned char tr[TRAILER_SIZE] = { 0x17, 0x72, 0x45, 0x38, 0x50, 0x90, (unsigned char)(cc >> 24), (unsigned char)(cc >> 16),
-                                       (unsigned char)(cc >> 8), (unsigned char)cc };
-    if (write_all(p->fd_out, tr, TRAILER_SIZE)) p->failed = 1;
-    p->total_out += TRAILER_SIZE;
-  }
-  return NULL;
-}
-
+/* ------------------------------------------------------------------ -f/-o: streaming splitter + muxer (lbzamd_io.c) */
 static int stream_files(const char *in_path, const char *out_path, unsigned level, unsigned chunk_slabs, unsigned npipes, int timing,
-                        unsigned ndev)
+                        unsigned ndev, unsigned readers, unsigned writers)
 {
-  struct pipe p;
-  memset(&p, 0, sizeof p);
-  p.level = level;
-  p.ndev = ndev;
-  if (ndev) npipes *= ndev;                       /* -p pipelines on each device */
-  p.fd_in = strcmp(in_path, "-") ? open(in_path, O_RDONLY) : 0;
-  p.fd_out = strcmp(out_path, "-") ? open(out_path, O_WRONLY | O_CREAT | O_TRUNC, 0644) : 1;
-  if (p.fd_in < 0 || p.fd_out < 0) { perror("open"); return 1; }
-  p.chunk_bytes = (size_t)chunk_slabs * level * 100000ul;
-  p.out_cap = lbzamd_bound(p.chunk_bytes);
-  p.nslots = 2u * npipes + 1u;                    /* one being read, one per pipeline in flight, one per pipeline waiting for the writer */
-  p.slots = calloc(p.nslots, sizeof *p.slots);
-  for (unsigned i = 0; i < p.nslots; i++) {
-    p.slots[i].in = lbzamd_pinned_alloc(p.chunk_bytes);
-    p.slots[i].out = lbzamd_pinned_alloc(p.out_cap);
-    if (!p.slots[i].in || !p.slots[i].out) { fprintf(stderr, "lbzamd: cannot allocate pinned chunk buffers\n"); return 1; }
-  }
-  pthread_mutex_init(&p.mu, NULL);
-  pthread_cond_init(&p.cv, NULL);
-  const double t0 = now_s();
-  pthread_t rd, wr, *pl = malloc(npipes * sizeof *pl);
-  pthread_create(&rd, NULL, reader_thread, &p);
-  pthread_create(&wr, NULL, writer_thread, &p);
-  for (unsigned i = 0; i < npipes; i++) pthread_create(&pl[i], NULL, pipeline_thread, &p);
-  pthread_join(rd, NULL);
-  for (unsigned i = 0; i < npipes; i++) pthread_join(pl[i], NULL);
-  pthread_join(wr, NULL);
-  const double t1 = now_s();
-  if (timing)
-    fprintf(stderr, "file splitter/muxer: %zu B -> %zu B in %.3f s = %.0f MB/s (%u pipelines on %u device(s), chunks of %u slabs, contexts included)\n",
-            p.total_in, p.total_out, t1 - t0, (double)p.total_in / (t1 - t0) / 1e6, npipes, ndev ? ndev : 1u, chunk_slabs);
-  for (unsigned i = 0; i < p.nslots; i++) { lbzamd_pinned_free(p.slots[i].in); lbzamd_pinned_free(p.slots[i].out); }
-  if (p.fd_in > 0) close(p.fd_in);
-  if (p.fd_out > 1) close(p.fd_out);
-  return p.failed ? 1 : 0;
+  const int fd_in = strcmp(in_path, "-") ? open(in_path, O_RDONLY) : 0;
+  const int fd_out = strcmp(out_path, "-") ? open(out_path, O_WRONLY | O_CREAT | O_TRUNC, 0644) : 1;
+  if (fd_in < 0 || fd_out < 0) { perror("open"); return 1; }
+  struct lbzamd_io_cfg cfg;
+  memset(&cfg, 0, sizeof cfg);
+  cfg.level = level; cfg.chunk_slabs = chunk_slabs; cfg.pipes = npipes; cfg.ndev = ndev; cfg.readers = readers; cfg.writers = writers;
+  cfg.report = timing;
+  int sys = 0;
+  char msg[256];
+  const int rc = lbzamd_io_compress(fd_in, fd_out, &cfg, NULL, &sys, msg, sizeof msg);
+  if (rc) fprintf(stderr, "lbzamd: %s%s%s\n", msg, sys ? ": " : "", sys ? strerror(sys) : "");
+  if (fd_in > 0) close(fd_in);
+  if (fd_out > 1 && close(fd_out)) { perror("close"); return 1; }
+  return rc ? 1 : 0;
 }
 
 int main(int argc, char **argv)
 {
-  unsigned level = 9, nworkers = 0, timing = 0, repeat = 1, chunk_slabs = 256, npipes = 2, decompress = 0, sequential = 0, ndev = 0;
+  unsigned level = 9, nworkers = 0, timing = 0, repeat = 1, chunk_slabs = 0, npipes = 2, decompress = 0, sequential = 0, ndev = 0, readers = 0, writers = 0;
   int want_dev = -1;
   const char *in_path = NULL, *out_path = NULL;
   for (int i = 1; i < argc; i++) {
@@ -276,6 +133,8 @@ int main(int argc, char **argv)
     if (!strcmp(argv[i], "-c") && i + 1 < argc) { chunk_slabs = (unsigned)atoi(argv[++i]); continue; }
     if (!strcmp(argv[i], "-p") && i + 1 < argc) { npipes = (unsigned)atoi(argv[++i]); continue; }
     if (!strcmp(argv[i], "-g") && i + 1 < argc) { want_dev = atoi(argv[++i]); continue; }
+    if (!strcmp(argv[i], "-R") && i + 1 < argc) { readers = (unsigned)atoi(argv[++i]); continue; }   /* reader / writer threads of -f/-o */
+    if (!strcmp(argv[i], "-W") && i + 1 < argc) { writers = (unsigned)atoi(argv[++i]); continue; }
     if (!strcmp(argv[i], "-t")) { timing = 1; continue; }            /* phase times on stderr */
     if (!strcmp(argv[i], "-d")) { decompress = 1; continue; }        /* the inverse path: .bz2 -> bytes */
     if (!strcmp(argv[i], "-u")) { sequential = 1; continue; }        /* the reference's -u: blocks cut where they are full (batch mode) */
@@ -313,14 +172,13 @@ int main(int argc, char **argv)
     return 0;
   }
   if (in_path || out_path) {
-    if (chunk_slabs < 1) chunk_slabs = 1;
     if (npipes < 1) npipes = 1;
     if (want_dev >= 0) {
       const int have = lbzamd_device_count();
       if (have < 1) { fprintf(stderr, "lbzamd: no HIP device\n"); return 1; }
       ndev = (unsigned)(want_dev == 0 || want_dev > have ? have : want_dev);
     }
-    return stream_files(in_path ? in_path : "-", out_path ? out_path : "-", level, chunk_slabs, npipes, (int)timing, ndev);
+    return stream_files(in_path ? in_path : "-", out_path ? out_path : "-", level, chunk_slabs, npipes, (int)timing, ndev, readers, writers);
   }
   size_t len;
   unsigned char *in = read_all(stdin, &len);
