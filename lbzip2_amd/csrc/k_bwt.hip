@@ -89,7 +89,7 @@
 #define BIG_ROUNDS 16u                  /* such refinements a chunk gets at most; what is still tied in long runs then is left to the rank rounds */
 #endif
 #define DEEP_ROUNDS LBZ_DEEP_ROUNDS      /* launches of k_bwt_deep (lbz_kernels.h); what they leave tied goes to the rank rounds (k_bwt_fix*) */
-#define DEEP_HANDOVER 1u                /* the launch of k_bwt_deep at which a block with too many rows still tied is handed to the rank rounds */
+#define DEEP_HANDOVER LBZ_DEEP_HANDOVER /* the launch of k_bwt_deep at which a block with too many rows still tied is handed to the rank rounds */
 #define DEEP_BUILD 1u                   /* the rows still tied at the end of this launch of k_bwt_deep get rank entries: later launches may step by ranks */
 #define DEEP_STACK 48u
 #define DEEP_LEVELS 4u                  /* symbols a long run is split on in one launch */
@@ -1761,7 +1761,7 @@ k_bwt_batch(const u8 *Tbase, u8 *Bbase, lbz_block_meta *meta, lbz_layout L, u32 
   }
   __syncthreads();
   if (tid == 0) {
-    if (S.bc[8]) { atomicMax(&M->periodic, 2u); atomicMin(&M->deep_h0, S.h0min); M->deep_skip = 1u; }  /* 2 = ties left for the rank rounds: long runs BIG_ROUNDS did not split */
+    if (S.bc[8]) { atomicMax(&M->periodic, LBZ_TIES_EARLY); atomicMin(&M->deep_h0, S.h0min); M->deep_skip = 1u; }  /* ties left for the rank rounds: long runs BIG_ROUNDS did not split */
     M->seg_m[seg] = S.listn;                   /* short runs: the text rounds' list */
     if (S.listn) { atomicAdd(&M->deep_tot[0], S.listn); atomicMin(&M->deep_hmin[0], S.lmin); }
     if (S.bc[9]) atomicAdd(&M->deep_long, S.bc[9]);
@@ -2057,7 +2057,7 @@ __device__ void deep_big_run(deep_wave *W, u32 lane, u32 p, u32 g, deep_lists Ls
 
 __global__ void __launch_bounds__(LBZ_WG, 4)
 k_bwt_deep(const u8 *Tbase, u8 *Bbase, lbz_block_meta *meta, lbz_layout L, u32 first, u32 count, u32 nblk, u32 segs,
-           u8 *ws, u64 slot_bytes, u8 *ws_spill, u64 spill_bytes, const u32 *slabs, u32 round)
+           u8 *ws, u64 slot_bytes, u8 *ws_spill, u64 spill_bytes, const u32 *slabs, u32 round, u32 handover)
 {
   __shared__ deep_lds S;
   u32 bi, seg;
@@ -2076,9 +2076,17 @@ k_bwt_deep(const u8 *Tbase, u8 *Bbase, lbz_block_meta *meta, lbz_layout L, u32 f
   /* ... and so does a block of which two fifths are still tied after the first launch (source trees, logs: repeats of
      hundreds of symbols under most rows).  Ranks double through those, but a run can only step by ranks if the rotations it
      looks up have entries, and giving every rotation one is what the rank rounds do.  Every segment decides the same.  */
-  if (M->deep_skip || (u64)M->deep_long * 2ull > n || (round == DEEP_HANDOVER && (u64)tot * 5ull > (u64)n * 2ull)) {
-    if (seg == 0u && threadIdx.x == 0u) {
-      atomicMax(&M->periodic, 2u); atomicMin(&M->deep_h0, M->deep_hmin[round]);
+  /* `handover`: the two thresholds in thousandths of the block's rows -- tied when the text rounds begin (low half; 0 = no
+     such rule: what k_bwt_batch leaves tied says how many rows repeat, the second launch sees how long the repeats are) and
+     tied after the first launch (high half: 400).  A block handed over here is flagged LBZ_TIES_EARLY: its rank rounds start
+     behind launch DEEP_HANDOVER, on a stream of their own, beside the later text launches of the round's other blocks
+     (lbz_api.hip: launch_sort).  Only launches up to DEEP_HANDOVER flag: a later one would set the flag again on a block
+     whose rank rounds may have finished by then. */
+  const u32 ho0 = handover & 0xFFFFu, ho1 = handover >> 16;
+  if (M->deep_skip || (u64)M->deep_long * 2ull > n || (ho0 && (u64)M->deep_tot[0] * 1000ull > (u64)n * ho0)
+      || (round == DEEP_HANDOVER && (u64)tot * 1000ull > (u64)n * ho1)) {
+    if (seg == 0u && threadIdx.x == 0u && round <= DEEP_HANDOVER) {
+      atomicMax(&M->periodic, LBZ_TIES_EARLY); atomicMin(&M->deep_h0, M->deep_hmin[round]);
     }
     return;
   }
@@ -2350,7 +2358,7 @@ k_bwt_deep(const u8 *Tbase, u8 *Bbase, lbz_block_meta *meta, lbz_layout L, u32 f
     M->seg_m[seg] = S.outn;
     if (S.bad) M->err = 7u;
     if (S.outn) { atomicAdd(&M->deep_tot[round + 1u], S.outn); atomicMin(&M->deep_hmin[round + 1u], S.h0min); }
-    if (round + 1u == DEEP_ROUNDS && S.outn) { atomicMax(&M->periodic, 2u); atomicMin(&M->deep_h0, S.h0min); }
+    if (round + 1u == DEEP_ROUNDS && S.outn) { atomicMax(&M->periodic, LBZ_TIES_LATE); atomicMin(&M->deep_h0, S.h0min); }
 #ifdef DEEP_DEBUG
     if (S.outn && round + 1u == DEEP_ROUNDS) printf("blk %u seg %u left %u hmin %u\n", blk, seg, S.outn, S.h0min);
 #endif
@@ -2372,11 +2380,16 @@ k_bwt_deep(const u8 *Tbase, u8 *Bbase, lbz_block_meta *meta, lbz_layout L, u32 f
  *              ever ordered by a mixture of ranks from before and after a split.  A launch whose segment has nothing tied
  *              (or whose h has passed n) exits at once; the host enqueues the log2(M / 8) launches a block can need
  *              without looking.
- * k_bwt_fixend origin pointer and "exactly periodic" flag, the bytes of rows that stay tied for good.                  */
+ * k_bwt_fixend origin pointer and "exactly periodic" flag, the bytes of rows that stay tied for good.
+ * `which` (round 5): the chain runs TWICE per round of blocks -- for the blocks flagged LBZ_TIES_EARLY (handed over by
+ *              k_bwt_batch or by the first two text launches: a third of the blocks of a source tree, 7-12 doublings each),
+ *              on a stream of its own beside the later text launches of the other blocks, and for the blocks flagged
+ *              LBZ_TIES_LATE (whatever the last text launch left tied) behind both.  A chain only touches blocks with its
+ *              flag, and k_bwt_fixend replaces the flag by the block's final 0 / 1.                                     */
 static_assert(sizeof(u64) == 8 && alignof(u64) == 8, "a rank entry is one aligned 64-bit word");
 __global__ void __launch_bounds__(LBZ_WG, 4)
 k_bwt_fix0(const u8 *Tbase, u8 *Bbase, lbz_block_meta *meta, lbz_layout L, u32 first, u32 count, u32 nblk, u32 segs,
-           u8 *ws, u64 slot_bytes, u8 *ws_spill, u64 spill_bytes, const u32 *slabs)
+           u8 *ws, u64 slot_bytes, u8 *ws_spill, u64 spill_bytes, const u32 *slabs, u32 which)
 {
   __shared__ bwt_lds S;
   u32 bi, seg;
@@ -2384,7 +2397,7 @@ k_bwt_fix0(const u8 *Tbase, u8 *Bbase, lbz_block_meta *meta, lbz_layout L, u32 f
   const u32 blk = lbz_round_block(first, count, bi, slabs);
   lbz_block_meta *M = &meta[blk];
   const u32 n = M->n;
-  if (n < 2u || M->periodic != 2u || seg >= M->nseg) return;
+  if (n < 2u || M->periodic != which || seg >= M->nseg) return;
   const u32 lo = M->seg_lo[seg], hi = M->seg_lo[seg + 1u];
   if (lo >= hi) return;
   const u64 tk0 = wall_clock64();
@@ -2401,7 +2414,7 @@ k_bwt_fix0(const u8 *Tbase, u8 *Bbase, lbz_block_meta *meta, lbz_layout L, u32 f
 
 __global__ void __launch_bounds__(LBZ_WG, 4)
 k_bwt_fixr(const u8 *Tbase, u8 *Bbase, lbz_block_meta *meta, lbz_layout L, u32 first, u32 count, u32 nblk, u32 segs,
-           u8 *ws, u64 slot_bytes, u8 *ws_spill, u64 spill_bytes, const u32 *slabs, u32 round)
+           u8 *ws, u64 slot_bytes, u8 *ws_spill, u64 spill_bytes, const u32 *slabs, u32 round, u32 which)
 {
   __shared__ bwt_lds S;
   u32 bi, seg;
@@ -2409,7 +2422,7 @@ k_bwt_fixr(const u8 *Tbase, u8 *Bbase, lbz_block_meta *meta, lbz_layout L, u32 f
   const u32 blk = lbz_round_block(first, count, bi, slabs);
   lbz_block_meta *M = &meta[blk];
   const u32 n = M->n;
-  if (n < 2u || M->periodic != 2u || seg >= M->nseg) return;
+  if (n < 2u || M->periodic != which || seg >= M->nseg) return;
   const u32 m = M->seg_m[seg];
   if (m == 0u) return;
   const u64 tk0 = wall_clock64();
@@ -2433,14 +2446,14 @@ k_bwt_fixr(const u8 *Tbase, u8 *Bbase, lbz_block_meta *meta, lbz_layout L, u32 f
 /* one workgroup per block of the round */
 __global__ void __launch_bounds__(LBZ_WG, 4)
 k_bwt_fixend(u8 *Bbase, lbz_block_meta *meta, lbz_layout L, u32 first, u32 count,
-             u8 *ws, u64 slot_bytes, u8 *ws_spill, u64 spill_bytes, const u32 *slabs)
+             u8 *ws, u64 slot_bytes, u8 *ws_spill, u64 spill_bytes, const u32 *slabs, u32 which)
 {
   __shared__ u8 inv[256];
   __shared__ wg_scratch sc;
   const u32 tid = threadIdx.x;
   const u32 blk = lbz_round_block(first, count, blockIdx.x, slabs);
   lbz_block_meta *M = &meta[blk];
-  if (M->n < 2u || M->periodic != 2u) return;
+  if (M->n < 2u || M->periodic != which) return;
   const bwt_slot s = round_slot(ws, slot_bytes, ws_spill, spill_bytes, count, L, blockIdx.x);
   u8 *bwt = Bbase + lbz_elem_off(L, blk);
   {

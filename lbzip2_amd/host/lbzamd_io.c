@@ -27,7 +27,7 @@ static double now_s(void)
   return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
 }
 
-enum { S_FREE = 0, S_READING, S_FULL, S_BUSY, S_DONE, S_WRITING };
+enum { S_FREE = 0, S_READING, S_FULL, S_BUSY, S_DONE, S_WRITING, S_UNBORN };
 
 struct slot {                       /* one position of the ring: a chunk's input and its compressed bytes, both page-locked */
   uint8_t *in, *out;
@@ -59,7 +59,7 @@ struct engine {
   size_t note_cap;
   int failed, sys_errno;
   char msg[256];
-  double t0, t_setup, busy_r, busy_w, busy_p;
+  double t0, t_setup, t_ring, busy_r, busy_w, busy_p;
   uint64_t in_bytes;
 };
 
@@ -353,23 +353,35 @@ int lbzamd_io_compress(int fd_in, int fd_out, const struct lbzamd_io_cfg *cfg, s
   pthread_t *th = calloc(e.nreaders + e.npipes + e.nwriters, sizeof *th);
   unsigned nth = 0;
   if (!e.slots || !th) { rc = LBZAMD_IO_MEMORY; *sys_errno = ENOMEM; snprintf(msg, msg_cap, "chunk ring"); goto out; }
-  for (unsigned i = 0; i < e.nslots; i++) {
-    e.slots[i].in = lbzamd_pinned_alloc(e.chunk_bytes);
-    e.slots[i].out = lbzamd_pinned_alloc(e.out_cap);
-    if (!e.slots[i].in || !e.slots[i].out) {
-      rc = lbzamd_device_count() < 1 ? LBZAMD_IO_DEVICE : LBZAMD_IO_MEMORY;
-      *sys_errno = ENOMEM;
-      snprintf(msg, msg_cap, "%s", rc == LBZAMD_IO_DEVICE ? "no HIP device (this program has no CPU path)" : "page-locked chunk buffers");
-      goto out;
-    }
-  }
   {
     const uint8_t hdr[HEADER_SIZE] = { 'B', 'Z', 'h', (uint8_t)('0' + cfg->level) };      /* compress.c:291-302 */
     if (write_fully(fd_out, hdr, HEADER_SIZE, e.out_seek, e.out_base)) { rc = LBZAMD_IO_WRITE; *sys_errno = errno; snprintf(msg, msg_cap, "write()"); goto out; }
   }
-  for (unsigned i = 0; i < e.npipes; i++) pthread_create(&th[nth++], NULL, pipeline_main, &e);     /* contexts first: they take the longest */
+  /* The contexts take the longest (gigabytes of device memory each): their threads start first and create them side by side,
+     while this thread page-locks the ring, position by position -- a position is S_UNBORN until its buffers exist, and the
+     readers, which take chunks in order, begin as soon as the first ones do. */
+  for (unsigned i = 0; i < e.nslots; i++) e.slots[i].state = S_UNBORN;
+  for (unsigned i = 0; i < e.npipes; i++) pthread_create(&th[nth++], NULL, pipeline_main, &e);
   for (unsigned i = 0; i < e.nreaders; i++) pthread_create(&th[nth++], NULL, reader_main, &e);
   for (unsigned i = 0; i < e.nwriters; i++) pthread_create(&th[nth++], NULL, writer_main, &e);
+  for (unsigned i = 0; i < e.nslots; i++) {
+    uint8_t *in = lbzamd_pinned_alloc(e.chunk_bytes), *outb = lbzamd_pinned_alloc(e.out_cap);
+    pthread_mutex_lock(&e.mu);
+    e.slots[i].in = in;
+    e.slots[i].out = outb;
+    if (!in || !outb) {
+      const int no_dev = lbzamd_device_count() < 1;
+      fail_locked(&e, no_dev ? LBZAMD_IO_DEVICE : LBZAMD_IO_MEMORY, ENOMEM, no_dev ? "no HIP device (this program has no CPU path)" : "page-locked chunk buffers");
+      pthread_mutex_unlock(&e.mu);
+      break;
+    }
+    e.slots[i].state = S_FREE;
+    pthread_cond_broadcast(&e.cv);
+    const int stop = e.failed;
+    pthread_mutex_unlock(&e.mu);
+    if (stop) break;
+  }
+  e.t_ring = now_s();
   for (unsigned i = 0; i < nth; i++) pthread_join(th[i], NULL);
   if (e.failed) { rc = e.failed; *sys_errno = e.sys_errno; snprintf(msg, msg_cap, "%s", e.msg); goto out; }
   {
@@ -394,10 +406,11 @@ out:;
   }
   if (cfg->report && !rc) {
     const double w = t1 - e.t0;
-    fprintf(stderr, "file splitter/muxer: %llu B -> %llu B in %.3f s = %.0f MB/s (contexts included: first one ready after %.3f s); "
+    fprintf(stderr, "file splitter/muxer: %llu B -> %llu B in %.3f s = %.0f MB/s (contexts included: first one ready after %.3f s, ring page-locked after %.3f s; %.0f MB/s behind the first context); "
                     "%u pipeline(s) on %u device(s), chunks of %u slabs; %u reader(s) busy %.0f%% each, %u writer(s) busy %.0f%% each, pipelines busy %.0f%%\n",
             (unsigned long long)e.in_bytes, (unsigned long long)(e.next_off + TRAILER_SIZE), w, (double)e.in_bytes / w / 1e6,
-            e.t_setup > 0.0 ? e.t_setup - e.t0 : 0.0, e.npipes, cfg->ndev ? cfg->ndev : 1u, chunk_slabs,
+            e.t_setup > 0.0 ? e.t_setup - e.t0 : 0.0, e.t_ring - e.t0, (double)e.in_bytes / (w - (e.t_setup > 0.0 ? e.t_setup - e.t0 : 0.0)) / 1e6,
+            e.npipes, cfg->ndev ? cfg->ndev : 1u, chunk_slabs,
             e.nreaders, 100.0 * e.busy_r / (w * e.nreaders), e.nwriters, 100.0 * e.busy_w / (w * e.nwriters), 100.0 * e.busy_p / (w * e.npipes));
   }
   if (e.slots) for (unsigned i = 0; i < e.nslots; i++) { if (e.slots[i].in) lbzamd_pinned_free(e.slots[i].in); if (e.slots[i].out) lbzamd_pinned_free(e.slots[i].out); }

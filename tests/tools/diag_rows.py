@@ -8,16 +8,9 @@ lib = lbzip2_amd.library()
 from bench import gen_input
 slabs = int(sys.argv[1]); kind = sys.argv[2]
 n = slabs * 900000
-def pysrc(n):
-    import glob
-    out = bytearray()
-    for f in sorted(glob.glob("/usr/lib/python3*/**/*.py", recursive=True)) + sorted(glob.glob("/usr/local/lib/python3*/dist-packages/**/*.py", recursive=True)):
-        try: out += open(f, "rb").read()
-        except Exception: pass
-        if len(out) >= n: break
-    while len(out) < n: out += out[:n - len(out)]
-    return out[:n]
-data = pysrc(n) if kind == "pysrc" else gen_input(kind, n, 2)
+sys.path.insert(0, "/root/repo/tests/tools")
+import inputs
+data = inputs.get(kind, n, 2)
 src = torch.frombuffer(data, dtype=torch.uint8).cuda()
 dst = torch.empty(lib.bound(n), dtype=torch.uint8, device="cuda")
 ctx = lib.context(9, slabs, slabs)

@@ -37,6 +37,15 @@ for k, c in sorted(K.items(), key=lambda kv: -kv[1].get("total_ms", 0)):
               "SQ_LDS_BANK_CONFLICT", "SQ_LDS_IDX_ACTIVE", "SQ_INSTS_LDS_ATOMIC", "SQ_INSTS_BRANCH"):
         if n in c:
             e[n + "_per_row"] = round(c[n] / rows, 4)
+    if c.get("TCC_HIT_sum") is not None and c.get("TCC_MISS_sum") is not None and c["TCC_HIT_sum"] + c["TCC_MISS_sum"] > 0:
+        e["l2_hit_rate"] = round(c["TCC_HIT_sum"] / (c["TCC_HIT_sum"] + c["TCC_MISS_sum"]), 4)
+        e["l2_requests_per_row"] = round((c["TCC_HIT_sum"] + c["TCC_MISS_sum"]) / rows, 3)
+    if c.get("TCC_EA0_RDREQ_sum"):
+        e["fabric_rdreq_per_row"] = round(c["TCC_EA0_RDREQ_sum"] / rows, 3)
+        e["fabric_rdreq_32B_share"] = round(c.get("TCC_EA0_RDREQ_32B_sum", 0.0) / c["TCC_EA0_RDREQ_sum"], 3)
+    if c.get("TCC_EA0_WRREQ_sum"):
+        e["fabric_wrreq_per_row"] = round(c["TCC_EA0_WRREQ_sum"] / rows, 3)
+        e["fabric_wrreq_64B_share"] = round(c.get("TCC_EA0_WRREQ_64B_sum", 0.0) / c["TCC_EA0_WRREQ_sum"], 3)
     if "FETCH_SIZE" in c:
         e["fetch_kb_per_slab_raw"] = round(c["FETCH_SIZE"] / (slabs * iters), 1)
     if "WRITE_SIZE" in c:
@@ -47,4 +56,4 @@ for k, c in sorted(K.items(), key=lambda kv: -kv[1].get("total_ms", 0)):
 json.dump({"slabs": slabs, "iterations": iters, "note": "wave-instruction counts per block row (900000 rows per slab); SQ cycle counters in quad-cycles",
            "kernels": res}, open(out + "_pmc_summary.json", "w"), indent=1)
 for k, e in res.items():
-    print(k, {kk: e[kk] for kk in e if kk.startswith("frac") or kk.endswith("per_row") or kk in ("ms_per_iter", "fetch_kb_per_slab_raw", "write_kb_per_slab_raw")})
+    print(k, {kk: e[kk] for kk in e if kk.startswith("frac") or kk.endswith("per_row") or kk.endswith("share") or kk in ("ms_per_iter", "fetch_kb_per_slab_raw", "write_kb_per_slab_raw", "l2_hit_rate")})

@@ -7,21 +7,9 @@ import os
 if os.environ.get('LBZ_LIB'): lbzip2_amd.LIB_PATH = os.environ['LBZ_LIB']
 lib = lbzip2_amd.library()
 g = C.CDLL("/root/repo/lbzip2_amd/host/libgen_inputs.so")
-def pysrc(n):
-    import glob
-    out = bytearray()
-    for f in sorted(glob.glob("/usr/lib/python3*/**/*.py", recursive=True)) + sorted(glob.glob("/usr/local/lib/python3*/dist-packages/**/*.py", recursive=True)):
-        try: out += open(f, "rb").read()
-        except Exception: pass
-        if len(out) >= n: break
-    while len(out) < n: out += out[:n - len(out)]
-    return out[:n]
-def gen(kind, n, seed):
-    if kind == "pysrc": return pysrc(n)
-    buf = bytearray(n); cb = (C.c_uint8 * n).from_buffer(buf)
-    f = getattr(g, "lbzgen_" + kind)
-    f.argtypes = [C.c_void_p, C.c_size_t, C.c_uint32]; f(cb, n, seed); del cb
-    return buf
+sys.path.insert(0, "/root/repo/tests/tools")
+import inputs
+def gen(kind, n, seed): return inputs.get(kind, n, seed)
 slabs = int(sys.argv[1]) if len(sys.argv) > 1 else 512
 LEVEL = int(os.environ.get("LBZ_LEVEL", "9"))
 for kind in (sys.argv[2].split(",") if len(sys.argv) > 2 else ("text", "rand")):

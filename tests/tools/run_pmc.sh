@@ -18,4 +18,7 @@ run_pass sqB SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_
 run_pass sqC SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_VMEM SQ_INSTS_SMEM SQ_LDS_ADDR_CONFLICT SQ_LDS_UNALIGNED_STALL SQ_INSTS_LDS_ATOMIC SQ_INSTS_BRANCH SQ_ACTIVE_INST_MISC
 run_pass fetch FETCH_SIZE
 run_pass write WRITE_SIZE
+# the XCD's L2: hit rate of the sorting kernels' gathers (TCC has four slots a pass) and the fabric requests behind the misses
+run_pass tccA TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCC_READ_sum
+run_pass tccB TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum
 python $REPO/tests/tools/pmc_summary.py $OUT/prof_$TAG $OUT/${TAG} $SLABS 2
