@@ -35,6 +35,7 @@ struct mtf_lds {
   wg_scratch sc;
   int last[LBZ_NW][256];       /* per-slice last occurrence, then slice start state */
   u32 hist[LBZ_MAX_ALPHA + 2];
+  int front[256];              /* last occurrence of every code in front of the workgroup's range (k_mtf_ranks; -1: none) */
   u8 cmap[256];
   u8 slot_of[256];
   u32 bc[4];
@@ -172,24 +173,16 @@ __device__ __forceinline__ void mtf_ranks(const u8 *bwt, u8 *rk_out, u32 lo, u32
   }
 }
 
-/* two workgroups per CU: the SGPR file admits 8 waves per SIMD only at <= 80 SGPRs per wave */
-__global__ void __launch_bounds__(LBZ_WG) __attribute__((amdgpu_num_sgpr(80)))
-k_mtf(const u8 *Bbase, u8 *Rbase, u16 *Vbase, u32 *freq_out, lbz_block_meta *meta, lbz_layout L, u32 first, u32 count, const u32 *slabs)
+/* Stage 1 of a block: dense codes, the slices' start states, the ranks of the run heads -> rk[].  The block's positions are
+ * dealt over `parts` workgroups (1: the whole block, k_mtf; 2 or 4: k_mtf_ranks, rounds of fewer blocks than the device has
+ * CUs): workgroup `part` owns LBZ_NW consecutive slices, one per wave.  A slice starts from the last occurrences of every
+ * symbol in front of it: those inside the workgroup's own range are chained over its slices as before; those in front of the
+ * range come from one more scan of bwt[0, range start) by the whole workgroup -- the price of not talking to the other
+ * workgroups (a quarter of the prelude's time per part: the scan touches LDS only at the ends of runs).  Ranks do not depend
+ * on the slot numbering, so every workgroup numbers by its own head counts.  Returns the number of bytes in use. */
+__device__ __forceinline__ u32 mtf_rank_stage(const u8 *bwt, u8 *rk, const lbz_block_meta *M, u32 n, u32 part, u32 parts, mtf_lds &S)
 {
-  __shared__ mtf_lds S;
   const u32 tid = threadIdx.x, lane = lane_id(), w = wave_id();
-  const u32 blk = lbz_round_block(first, count, blockIdx.x, slabs);
-  lbz_block_meta *M = &meta[blk];
-  const u32 n = M->n;
-  if (n == 0u) return;
-  const size_t off = lbz_elem_off(L, blk);
-  const u8 *bwt = Bbase + off;
-  u8 *rk = Rbase + off;
-  u16 *mtfv = Vbase + off;               /* room for n + 1 + 50 symbols (cap >= M + 64) */
-
-#ifdef MTF_TICKS
-  const u64 tk0 = wall_clock64();
-#endif
   /* dense symbol numbering of the used bytes (encode.c:340-355) */
   u32 tot_inuse;
   {
@@ -197,16 +190,31 @@ k_mtf(const u8 *Bbase, u8 *Rbase, u16 *Vbase, u32 *freq_out, lbz_block_meta *met
     const u32 ex = wg_excl_add(f, &tot_inuse, &S.sc);
     if (tid < 256u) S.cmap[tid] = (u8)ex;
   }
-  const u32 eob = tot_inuse + 1u;
   for (u32 i = tid; i < LBZ_NW * 256u; i += LBZ_WG) (&S.last[0][0])[i] = -1;
   for (u32 i = tid; i < LBZ_MAX_ALPHA + 2u; i += LBZ_WG) S.hist[i] = 0;
+  if (tid < 256u) S.front[tid] = -1;
   __syncthreads();
 
   /* slices: one per wave, multiples of 64 positions */
-  const u32 cs = (((n + LBZ_NW - 1u) / LBZ_NW) + 63u) & ~63u;
-  const u32 lo = w * cs < n ? w * cs : n;
+  const u32 nsl = LBZ_NW * parts;
+  const u32 cs = (((n + nsl - 1u) / nsl) + 63u) & ~63u;
+  const u32 sl = part * LBZ_NW + w;
+  const u32 lo = (u64)sl * cs < n ? sl * cs : n;
   const u32 hi = lo + cs < n ? lo + cs : n;
+  const u32 wg_lo = (u64)part * LBZ_NW * cs < n ? part * LBZ_NW * cs : n;
 
+  /* last occurrences in front of the workgroup's range (parts > 1): every thread four positions a trip, run ends only */
+  for (u32 b0 = 256u * (tid >> 6); b0 < wg_lo; b0 += 256u * LBZ_NW) {
+    u32 by[4];
+#pragma unroll
+    for (u32 k = 0; k < 4u; k++) { const u32 p = b0 + 64u * k + lane; by[k] = p < wg_lo ? bwt[p] : 0u; }
+#pragma unroll
+    for (u32 k = 0; k < 4u; k++) {
+      const u32 p = b0 + 64u * k + lane;
+      const u32 after = lane_from_above(by[k]);
+      if (p < wg_lo && (lane == 63u || p + 1u == wg_lo || after != by[k])) atomicMax(&S.front[S.cmap[by[k]]], (int)p);
+    }
+  }
   for (u32 b0 = lo; b0 < hi; b0 += 256u) {
     u32 by[4];
 #pragma unroll
@@ -237,7 +245,7 @@ k_mtf(const u8 *Bbase, u8 *Rbase, u16 *Vbase, u32 *freq_out, lbz_block_meta *met
       for (u32 j = 0; j < tot_inuse; j++) { const u32 o = S.hist[j]; r += (o > mine || (o == mine && j < tid)) ? 1u : 0u; }
       slot = r;
     }
-    int run = -1 - (int)tid;
+    int run = S.front[tid] >= 0 ? S.front[tid] : -1 - (int)tid;
 #pragma unroll
     for (u32 w2 = 0; w2 < LBZ_NW; w2++) {
       const int t = S.last[w2][tid];
@@ -251,24 +259,23 @@ k_mtf(const u8 *Bbase, u8 *Rbase, u16 *Vbase, u32 *freq_out, lbz_block_meta *met
     for (u32 w2 = 0; w2 < LBZ_NW; w2++) S.last[w2][slot] = st[w2];
     S.slot_of[tid] = (u8)slot;
   }
-  for (u32 i = tid; i < LBZ_MAX_ALPHA + 2u; i += LBZ_WG) S.hist[i] = 0;
   __syncthreads();
   if (tid < 256u) S.cmap[tid] = S.slot_of[S.cmap[tid]];       /* byte -> slot */
   __syncthreads();
 
-#ifdef MTF_TICKS
-  const u64 tk1 = wall_clock64();
-#endif
-  /* ranks at run heads, wave-serial over heads; NQ = registers needed for the alphabet */
+  /* ranks at run heads; NQ = 64-symbol words the alphabet needs */
   if (tot_inuse <= 64u) mtf_ranks<1>(bwt, rk, lo, hi, &S);
   else if (tot_inuse <= 128u) mtf_ranks<2>(bwt, rk, lo, hi, &S);
   else mtf_ranks<4>(bwt, rk, lo, hi, &S);
-  __syncthreads();
+  return tot_inuse;
+}
 
-#ifdef MTF_TICKS
-  const u64 tk2 = wall_clock64();
-#endif
-  /* zero-run coding + histogram */
+/* Stage 2 of a block: zero-run coding of the ranks (encode.c:381-386), the symbol histogram, the end-of-block symbol and
+ * the padding of the last group.  One workgroup per block: output offsets are a scan over the whole block. */
+__device__ __forceinline__ void mtf_zrle_stage(const u8 *rk, u16 *mtfv, u32 *freq_out, u32 blk, lbz_block_meta *M, u32 n, u32 tot_inuse, mtf_lds &S)
+{
+  const u32 tid = threadIdx.x, lane = lane_id();
+  const u32 eob = tot_inuse + 1u;
   u32 hot0 = 0, hot1 = 0, hot2 = 0;   /* RUNA, RUNB and rank 1 are counted in registers: half of all symbols */
   u32 carry_nz = 0;        /* (position of the last non-zero rank) + 1 */
   u32 o_base = 0;
@@ -343,7 +350,69 @@ k_mtf(const u8 *Bbase, u8 *Rbase, u16 *Vbase, u32 *freq_out, lbz_block_meta *met
   }
   __syncthreads();
   for (u32 i = tid; i < LBZ_MAX_ALPHA + 2u; i += LBZ_WG) freq_out[(size_t)blk * 260u + i] = S.hist[i];
+}
+
+/* two workgroups per CU: the SGPR file admits 8 waves per SIMD only at <= 80 SGPRs per wave */
+__global__ void __launch_bounds__(LBZ_WG) __attribute__((amdgpu_num_sgpr(80)))
+k_mtf(const u8 *Bbase, u8 *Rbase, u16 *Vbase, u32 *freq_out, lbz_block_meta *meta, lbz_layout L, u32 first, u32 count, const u32 *slabs)
+{
+  __shared__ mtf_lds S;
+  const u32 blk = lbz_round_block(first, count, blockIdx.x, slabs);
+  lbz_block_meta *M = &meta[blk];
+  const u32 n = M->n;
+  if (n == 0u) return;
+  const size_t off = lbz_elem_off(L, blk);
+  const u8 *bwt = Bbase + off;
+  u8 *rk = Rbase + off;
+  u16 *mtfv = Vbase + off;               /* room for n + 1 + 50 symbols (cap >= M + 64) */
 #ifdef MTF_TICKS
-  if (tid == 0) { M->ticks[3] = (u32)(tk1 - tk0); M->ticks[4] = (u32)(tk2 - tk1); M->ticks[5] = (u32)(wall_clock64() - tk2); }
+  const u64 tk0 = wall_clock64();
 #endif
+  const u32 tot_inuse = mtf_rank_stage(bwt, rk, M, n, 0u, 1u, S);
+  __syncthreads();
+#ifdef MTF_TICKS
+  const u64 tk2 = wall_clock64();
+#endif
+  for (u32 i = threadIdx.x; i < LBZ_MAX_ALPHA + 2u; i += LBZ_WG) S.hist[i] = 0;
+  __syncthreads();
+  mtf_zrle_stage(rk, mtfv, freq_out, blk, M, n, tot_inuse, S);
+#ifdef MTF_TICKS
+  if (threadIdx.x == 0) { M->ticks[3] = 0; M->ticks[4] = (u32)(tk2 - tk0); M->ticks[5] = (u32)(wall_clock64() - tk2); }
+#endif
+}
+
+/* The same in two launches, for rounds of fewer blocks than the device has CUs (round 5): the ranks with `parts` workgroups
+ * per block (blockIdx = block * parts + part), then the zero-run coding with one.  A round of 112 blocks left half of the
+ * CUs idle for the 2.3 ms a block's ranks take; as four workgroups they take a quarter of that (+ the scan of the text in
+ * front of a part) and the second launch 0.5 ms. */
+__global__ void __launch_bounds__(LBZ_WG) __attribute__((amdgpu_num_sgpr(80)))
+k_mtf_ranks(const u8 *Bbase, u8 *Rbase, lbz_block_meta *meta, lbz_layout L, u32 first, u32 count, const u32 *slabs, u32 parts)
+{
+  __shared__ mtf_lds S;
+  const u32 blk = lbz_round_block(first, count, blockIdx.x / parts, slabs);
+  const lbz_block_meta *M = &meta[blk];
+  const u32 n = M->n;
+  if (n == 0u) return;
+  const size_t off = lbz_elem_off(L, blk);
+  (void)mtf_rank_stage(Bbase + off, Rbase + off, M, n, blockIdx.x % parts, parts, S);
+}
+
+__global__ void __launch_bounds__(LBZ_WG) __attribute__((amdgpu_num_sgpr(80)))
+k_mtf_zrle(const u8 *Rbase, u16 *Vbase, u32 *freq_out, lbz_block_meta *meta, lbz_layout L, u32 first, u32 count, const u32 *slabs)
+{
+  __shared__ mtf_lds S;
+  const u32 tid = threadIdx.x;
+  const u32 blk = lbz_round_block(first, count, blockIdx.x, slabs);
+  lbz_block_meta *M = &meta[blk];
+  const u32 n = M->n;
+  if (n == 0u) return;
+  const size_t off = lbz_elem_off(L, blk);
+  u32 tot_inuse;
+  {
+    const u32 f = (tid < 256u && M->inuse[tid]) ? 1u : 0u;
+    (void)wg_excl_add(f, &tot_inuse, &S.sc);
+  }
+  for (u32 i = tid; i < LBZ_MAX_ALPHA + 2u; i += LBZ_WG) S.hist[i] = 0;
+  __syncthreads();
+  mtf_zrle_stage(Rbase + off, Vbase + off, freq_out, blk, M, n, tot_inuse, S);
 }

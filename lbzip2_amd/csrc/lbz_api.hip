@@ -295,6 +295,23 @@ extern "C" void lbzamd_round_shape(lbzamd_ctx *c, uint32_t blocks, int overlappe
 /* The sorter's launches for the blocks of one round (nblk = 2 * count: primaries then spills; or count: the
  * listed primaries only): partition (one workgroup per block), then batches, tie lists, the deep-tie rounds --
  * one launch per doubling depth, every (block, segment) a workgroup (k_bwt.hip) -- and the origin pointers.     */
+/* Move-to-front ranks, zero runs and the histogram of a round's blocks: one workgroup per block in one launch when the round
+ * fills the device by itself; for rounds of fewer blocks than CUs the ranks -- nine tenths of the kernel -- are dealt over 2 or
+ * 4 workgroups per block (k_mtf_ranks) and the zero-run coding follows in a launch of its own (k_mtf_zrle).  `real`: blocks
+ * that hold bytes, about (the spill blocks of a round are mostly empty).  LBZAMD_MTF_PARTS: (tuning) 1, 2 or 4. */
+static void launch_mtf(lbzamd_ctx *c, hipStream_t q, u32 first, u32 count, u32 nblk, u32 real, const u32 *lst)
+{
+  const char *e = getenv("LBZAMD_MTF_PARTS");
+  u32 parts = e ? (u32)atoi(e) : (real <= c->ncus / 2u ? 4u : (real <= c->ncus ? 2u : 1u));
+  if (parts != 2u && parts != 4u) parts = 1u;
+  if (parts == 1u) {
+    hipLaunchKernelGGL(k_mtf, dim3(nblk), dim3(LBZ_MTF_WG), 0, q, (const u8 *)c->B, c->R, c->V, c->freq, c->meta, c->L, first, count, lst);
+    return;
+  }
+  hipLaunchKernelGGL(k_mtf_ranks, dim3(nblk * parts), dim3(LBZ_MTF_WG), 0, q, (const u8 *)c->B, c->R, c->meta, c->L, first, count, lst, parts);
+  hipLaunchKernelGGL(k_mtf_zrle, dim3(nblk), dim3(LBZ_MTF_WG), 0, q, (const u8 *)c->R, c->V, c->freq, c->meta, c->L, first, count, lst);
+}
+
 static void launch_sort(lbzamd_ctx *c, hipStream_t q, u32 first, u32 count, u32 nblk, u8 *ws, u8 *wsp, const u32 *lst,
                         int phase /* 0 = partition, 1 = batches, 2 = deep ties */, bool overlapped = false /* other rounds run beside this one */)
 {
@@ -503,7 +520,7 @@ static int run_chunk(lbzamd_ctx *c, const u8 *d_in, size_t len, uint32_t nsl, in
       if (timed_end(c, &nbev, q)) return -1;
       if (upto >= 2) {
         if (timed_begin(c, &nbev, 3, q)) return -1;
-        hipLaunchKernelGGL(k_mtf, dim3(grid), dim3(LBZ_MTF_WG), 0, q, (const u8 *)c->B, c->R, c->V, c->freq, c->meta, c->L, first, count, nullptr);
+        launch_mtf(c, q, first, count, grid, count, nullptr);
         if (timed_end(c, &nbev, q)) return -1;
       }
       if (upto >= 3) {
@@ -1415,7 +1432,7 @@ static void pool_round(wu_pool *p, int stage, const std::vector<wu_req *> &batch
       const u32 count = cnt - o < c->nslots ? cnt - o : c->nslots;
       const u32 *lst = ln.d_list + o;
       for (int ph = 0; ph < 3; ph++) launch_sort(c, ln.q, 0u, count, count, ws, wsp, lst, ph);
-      hipLaunchKernelGGL(k_mtf, dim3(count), dim3(LBZ_MTF_WG), 0, ln.q, (const u8 *)c->B, c->R, c->V, c->freq, c->meta, c->L, 0u, count, lst);
+      launch_mtf(c, ln.q, 0u, count, count, count, lst);
       hipLaunchKernelGGL(k_encode, dim3(count), dim3(LBZ_ENCODE_WG), 0, ln.q, (const u16 *)c->V, (const u32 *)c->freq, c->O, c->meta, c->L, 0u, count, lst);
     }
   }

@@ -95,6 +95,9 @@ static inline u32 lbz_seg_grid(u32 nblk, u32 segs) { return (nblk + 7u) / 8u * 8
 /* deep-tie rounds a block of up to M rows can need: depths 8 << r < M (keys hold at least 8 symbols) */
 static inline u32 lbz_fix_rounds(u32 M) { u32 r = 0; while ((8ull << r) < M) r++; return r; }
 __global__ void k_mtf(const u8 *Bbase, u8 *Rbase, u16 *Vbase, u32 *freq_out, lbz_block_meta *meta, lbz_layout L, u32 first, u32 count, const u32 *slabs);
+/* ... in two launches for rounds of few blocks: the ranks with `parts` workgroups per block, then zero runs + histogram */
+__global__ void k_mtf_ranks(const u8 *Bbase, u8 *Rbase, lbz_block_meta *meta, lbz_layout L, u32 first, u32 count, const u32 *slabs, u32 parts);
+__global__ void k_mtf_zrle(const u8 *Rbase, u16 *Vbase, u32 *freq_out, lbz_block_meta *meta, lbz_layout L, u32 first, u32 count, const u32 *slabs);
 __global__ void k_encode(const u16 *Vbase, const u32 *freq_in, u8 *Obase, lbz_block_meta *meta, lbz_layout L, u32 first, u32 count, const u32 *slabs);
 __global__ void k_offsets(const lbz_block_meta *meta, u32 nblk, u32 bs100k, u32 first, u32 last, u32 body,
                           u64 *offs, lbz_stream_state *st, u8 *out, u64 out_cap);
