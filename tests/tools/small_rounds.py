@@ -1,19 +1,26 @@
-"""Ad-hoc: device-resident rate of small inputs (rounds of few blocks): 16, 64 and 112 slabs of the enwik-like text."""
-import sys, time, hashlib
-sys.path.insert(0, "/root/repo")
-import torch, lbzip2_amd, os
-import bench
-lib = lbzip2_amd.Library(os.environ["LBZ_LIB"]) if os.environ.get("LBZ_LIB") else lbzip2_amd.library()
-for n in [int(a) for a in sys.argv[1:]] or (14_400_000, 57_600_000, 100_000_000):
-    data = bench.gen_input("wiki", n, 1)
-    src = torch.frombuffer(data, dtype=torch.uint8).cuda()
+"""Ad-hoc: device-resident time of inputs of a few slabs (one round each): wiki of 16 / 64 / 112 / 139 / 200 slabs, with the
+library's tuning knobs from the environment.  usage: small_rounds.py "K=V,K=V;..." [kind]"""
+import os, sys, time
+sys.path.insert(0, "/root/repo"); sys.path.insert(0, "/root/repo/tests"); sys.path.insert(0, "/root/repo/tests/tools")
+import torch, lbzip2_amd, inputs
+lib = lbzip2_amd.library()
+settings = sys.argv[1].split(";") if len(sys.argv) > 1 else [""]
+kind = sys.argv[2] if len(sys.argv) > 2 else "wiki"
+big = inputs.get(kind, 200 * 900000, 1)
+for slabs in (16, 64, 112, 139, 200):
+    n = slabs * 900000 if slabs != 112 else 100_000_000
+    src = torch.frombuffer(big[:n], dtype=torch.uint8).cuda()
     dst = torch.empty(lib.bound(n), dtype=torch.uint8, device="cuda")
-    with lib.context(9, (n + 899999) // 900000) as ctx:
-        best = None
-        for it in range(6):
-            torch.cuda.synchronize(); t = time.time()
-            m = ctx.compress_device(src.data_ptr(), n, dst.data_ptr(), dst.numel())
-            torch.cuda.synchronize(); dt = time.time() - t
-            best = dt if best is None or dt < best else best
-        st = ctx.stats()
-    print("%d B (%d slabs): %.2f ms = %.0f MB/s  md5 %s  part %.2f batch %.2f fix %.2f" % (n, (n + 899999) // 900000, best * 1e3, n / best / 1e6, hashlib.md5(dst[:m].cpu().numpy().tobytes()).hexdigest()[:8], st.ms_bwt_part, st.ms_bwt_batch, st.ms_bwt_fix), flush=True)
+    for st in settings:
+        env = dict(kv.split("=") for kv in st.split(",") if kv)
+        for k, v in env.items(): os.environ[k] = v
+        with lib.context(9, (n + 899999) // 900000, 0) as ctx:
+            best = None
+            for it in range(6):
+                torch.cuda.synchronize(); t = time.perf_counter()
+                m = ctx.compress_device(src.data_ptr(), n, dst.data_ptr(), dst.numel())
+                torch.cuda.synchronize(); dt = time.perf_counter() - t
+                if it: best = dt if best is None or dt < best else best
+            s = ctx.stats()
+        print(f"{kind} {slabs:4d} slabs {st:28s} {best*1e3:7.2f} ms = {n/best/1e6:7.1f} MB/s  collect={s.ms_collect:.2f} part={s.ms_bwt_part:.2f} batch={s.ms_bwt_batch:.2f} ties={s.ms_bwt_fix:.2f} mtf={s.ms_mtf:.2f} enc={s.ms_encode:.2f}", flush=True)
+        for k in env: del os.environ[k]
