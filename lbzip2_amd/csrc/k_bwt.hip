@@ -1889,6 +1889,13 @@ __device__ __forceinline__ u64x2 deep_load16(const u8 *T, u32 n, u32 idx, u32 d)
  * as they stood when it began whatever its other workgroups are writing), and a bit map of the block's rotations says
  * which: a target without an entry became unique before launch DEEP_BUILD ended, so the text decides within the few dozen
  * symbols those launches covered, and the strip takes a text step instead.  From then on every change of rank is stored.  */
+/* The invariant the concurrent segment workgroups of a block rely on (round-4 review): a rank entry is ONE naturally aligned
+ * 64-bit word, read and written by single 8-byte global accesses (global_load_dwordx2 / global_store_dwordx2 are single-copy
+ * atomic on aligned addresses), so a reader sees a whole entry of some launch, never halves of two.  In the text rounds an
+ * entry may be written TWICE in a launch -- a tag-0 refresh {rank, rank, depth} when its strip starts, a tagged update
+ * {new rank, old rank, tag, depth} when the strip ends -- and a reader of either takes the rank as it stood when the launch
+ * began: the refresh carries it in both fields, the update in `rank before` (isa_before with the launch's tag).  The depth
+ * note is a lower bound in both.  The rank rounds (k_bwt_fixr) write an entry at most once per launch. */
 struct deep_ranks { u64 *isa; u32 *map; u32 tag, hcur; bool build, live; };
 __device__ __forceinline__ void deep_publish(deep_ranks R, u32 idx, u32 rank, u32 depth)
 {

@@ -1662,6 +1662,7 @@ struct wd_pool {
 };
 wd_pool g_wd;
 const unsigned WD_BATCH = 256u;
+const size_t WD_OUT_BUDGET = (size_t)1 << 30;   /* decoded bytes handed from the device to the callers per pass of a round */
 
 void wd_put(wd_state *st, uint64_t v, unsigned n)       /* n <= 32 bits, right-aligned in v */
 {
@@ -1774,18 +1775,34 @@ void wd_round(const std::vector<wd_req *> &batch)
     outb += rec.out_len;
     r->rec = rec;
   }
-  if (outb) {
-    wd_grow_dev(&c->d_out, &c->d_out_cap, outb);
-    wd_grow_host(&c->h_out, &c->h_out_cap, outb + 256u);
-    HIPDIE(hipMemcpyAsync(c->blocks, hrec, recs, hipMemcpyHostToDevice, q), "retrieve");
-    hipLaunchKernelGGL(k_demit, dim3(nb * 8u), dim3(256), 0, q, (const lbz_dblock *)c->blocks, nb, (const u8 *)c->W, (const u32 *)c->pinfo, c->d_out, (u64)c->d_out_cap, c->cap);
-    HIPDIE(hipMemcpyAsync(c->h_out, c->d_out, outb, hipMemcpyDeviceToHost, q), "retrieve");
-    HIPDIE(hipStreamSynchronize(q), "retrieve");
-    HIPDIE(hipGetLastError(), "retrieve");
-    for (u32 i = 0; i < nb; i++) {
-      wd_req *r = batch[i];
-      if (r->rec.err == 0u && !r->past) r->st->out.assign(c->h_out + r->rec.out_off, c->h_out + r->rec.out_off + r->rec.out_len);
+  /* The bytes, in passes of at most WD_OUT_BUDGET: a block of 900 000 bytes can hold runs worth 46 MB (the reference's own
+     zip-bomb case), so a round of 256 crafted blocks would ask for 12 GB of device and page-locked memory at once; the
+     reference hands its bytes out in out_granul pieces (expand.c:712-735).  A pass takes whole blocks, one at least. */
+  (void)outb;
+  std::vector<lbz_dblock> pass(nb);
+  for (u32 b0 = 0; b0 < nb;) {
+    size_t sum = 0;
+    u32 b1 = b0;
+    for (u32 i = 0; i < nb; i++) { pass[i] = hrec[i]; pass[i].out_len = 0; pass[i].err = 99u; }   /* (k_demit leaves a block with err alone) */
+    while (b1 < nb) {
+      const wd_req *r = batch[b1];
+      const size_t len = (r->rec.err == 0u && !r->past) ? r->rec.out_len : 0u;
+      if (b1 > b0 && sum + len > WD_OUT_BUDGET) break;
+      if (len) { pass[b1].out_len = (u32)len; pass[b1].out_off = sum; pass[b1].err = 0u; sum += len; }
+      b1++;
     }
+    if (sum) {
+      wd_grow_dev(&c->d_out, &c->d_out_cap, sum);
+      wd_grow_host(&c->h_out, &c->h_out_cap, sum + 256u);
+      HIPDIE(hipMemcpyAsync(c->blocks, pass.data(), recs, hipMemcpyHostToDevice, q), "retrieve");
+      hipLaunchKernelGGL(k_demit, dim3(nb * 8u), dim3(256), 0, q, (const lbz_dblock *)c->blocks, nb, (const u8 *)c->W, (const u32 *)c->pinfo, c->d_out, (u64)c->d_out_cap, c->cap);
+      HIPDIE(hipMemcpyAsync(c->h_out, c->d_out, sum, hipMemcpyDeviceToHost, q), "retrieve");
+      HIPDIE(hipStreamSynchronize(q), "retrieve");
+      HIPDIE(hipGetLastError(), "retrieve");
+      for (u32 i = b0; i < b1; i++)
+        if (pass[i].out_len) batch[i]->st->out.assign(c->h_out + pass[i].out_off, c->h_out + pass[i].out_off + pass[i].out_len);
+    }
+    b0 = b1;
   }
 }
 void wd_submit(wd_req *r)
