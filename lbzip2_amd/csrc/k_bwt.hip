@@ -90,7 +90,7 @@
 #endif
 #define DEEP_ROUNDS LBZ_DEEP_ROUNDS      /* launches of k_bwt_deep (lbz_kernels.h); what they leave tied goes to the rank rounds (k_bwt_fix*) */
 #define DEEP_HANDOVER LBZ_DEEP_HANDOVER /* the launch of k_bwt_deep at which a block with too many rows still tied is handed to the rank rounds */
-#define DEEP_BUILD 1u                   /* the rows still tied at the end of this launch of k_bwt_deep get rank entries: later launches may step by ranks */
+#define DEEP_BUILD LBZ_DEEP_BUILD       /* the rows still tied at the end of this launch of k_bwt_deep get rank entries: later launches may step by ranks */
 #define DEEP_STACK 48u
 #define DEEP_LEVELS 4u                  /* symbols a long run is split on in one launch */
 #define DEEP_CHUNK 256u                 /* list entries a wave claims at a time in k_bwt_deep */
@@ -1803,8 +1803,11 @@ k_bwt_batch(const u8 *Tbase, u8 *Bbase, lbz_block_meta *meta, lbz_layout L, u32 
  * Whatever is still tied after DEEP_ROUNDS launches (exactly periodic blocks, repeats of more than 6 KB) marks the
  * block for the rank rounds, which start at the least depth such a run has reached (deep_h0).                     */
 struct u64x2 { u64 x, y; };
+#ifndef DEEP_NEAR
+#define DEEP_NEAR 16u                   /* a strip whose longest run has at most this many rows counts a row's place among the keys of its own run (8 or 16) */
+#endif
 struct deep_wave {
-  alignas(16) u64 comp[64];             /* the strip's keys, read by every lane */
+  alignas(16) u64 comp[64 + DEEP_NEAR];   /* the strip's keys, read by every lane; the tail stays ~0 */
   u64 srt[64];                          /* (run, slice) in sorted order */
   u64 k2[64];                           /* the second slice travels with its row */
   u32 val[64];
@@ -1824,25 +1827,61 @@ struct deep_lds {
 __device__ __forceinline__ u32 deep_kmax(u32 round) { return round < 2u ? 2u : (round + 2u < DEEP_ROUNDS ? 2u << (round - 1u) : 256u); }
 
 /* Sort the strip inside its runs on `slice` (52 bits).  val and k2 move with their rows; hl (first lane of the lane's
- * run) and tied describe places, and are refined.  Lanes >= nv are not part of the strip.                         */
+ * run) and tied describe places, and are refined.  Lanes >= nv are not part of the strip.
+ * A row's place is the number of smaller keys, and the key begins with the run's first lane: every key of a run in front of
+ * mine is smaller, every key of a run behind it greater.  So only the keys of my OWN run need counting -- the rows from its
+ * first lane on, as many as the strip's longest run has (round 5: DEEP_NEAR) -- and the rest is the run's first lane itself.
+ * On text nine strips in ten hold no run of more than 16 rows: 2 to 16 compare-and-add pairs a row and slice at a per-lane
+ * LDS address instead of 64 at a broadcast one (the count was a third of the kernel's vector instructions: DESIGN 15.1).
+ * A strip with a longer run counts against all 64 keys as before. */
+__device__ __forceinline__ u32 deep_longest_run(u32 hl, u32 lane);
+template <u32 N>
+__device__ __forceinline__ u32 deep_count_near(const u64 *cp, u32 pos, u64 comp)
+{
+  constexpr u32 G = N < 16u ? N : 16u;
+#pragma unroll
+  for (u32 q0 = 0; q0 < N; q0 += G) {
+    u64 c[G];
+#pragma unroll
+    for (u32 q = 0; q < G; q++) c[q] = cp[q0 + q];
+#pragma unroll
+    for (u32 q = 0; q < G; q += 2u) pos = add_if_less2(pos, c[q], c[q + 1u], comp);
+  }
+  return pos;
+}
 __device__ __forceinline__ void deep_stage(deep_wave *W, u32 lane, u32 nv, u64 slice, u32 &val, u64 &k2, u32 &hl, bool &tied)
 {
   const bool in = lane < nv;
   const u64 ck = ((u64)hl << 52) | slice;
   const u64 comp = (ck << 6) | (u64)lane;
   W->comp[lane] = in ? comp : ~0ull;
+#ifndef DEEP_ALLPAIRS
+  /* the strip's longest run, from the first lanes of its runs (lanes >= nv are runs of one) */
+  const u32 lmax = deep_longest_run(hl, lane);
+#endif
   wave_sync();
   u32 pos = 0;
-  const u64x2 *cp = reinterpret_cast<const u64x2 *>(W->comp);
-  /* 16 keys at a time: eight broadcast reads in flight, then sixteen compare-and-add pairs */
+#ifndef DEEP_ALLPAIRS
+  if (lmax <= DEEP_NEAR) {
+    const u64 *cp = W->comp + hl;                          /* comp[64 .. 64 + DEEP_NEAR) hold ~0: a run at the strip's end reads on */
+    if (lmax <= 2u) pos = deep_count_near<2>(cp, hl, comp);
+    else if (lmax <= 4u) pos = deep_count_near<4>(cp, hl, comp);
+    else if (lmax <= 8u) pos = deep_count_near<8>(cp, hl, comp);
+    else pos = deep_count_near<16>(cp, hl, comp);
+  } else
+#endif
+  {
+    const u64x2 *cp = reinterpret_cast<const u64x2 *>(W->comp);
+    /* 16 keys at a time: eight broadcast reads in flight, then sixteen compare-and-add pairs */
 #pragma unroll
-  for (u32 b = 0; b < 4u; b++) {
-    if (16u * b < nv) {
-      u64x2 c2[8];
+    for (u32 b = 0; b < 4u; b++) {
+      if (16u * b < nv) {
+        u64x2 c2[8];
 #pragma unroll
-      for (u32 q = 0; q < 8u; q++) c2[q] = cp[8u * b + q];
+        for (u32 q = 0; q < 8u; q++) c2[q] = cp[8u * b + q];
 #pragma unroll
-      for (u32 q = 0; q < 8u; q++) pos = add_if_less2(pos, c2[q].x, c2[q].y, comp);
+        for (u32 q = 0; q < 8u; q++) pos = add_if_less2(pos, c2[q].x, c2[q].y, comp);
+      }
     }
   }
   if (in) { W->srt[pos] = ck; W->val[pos] = val; W->k2[pos] = k2; }
@@ -1859,6 +1898,15 @@ __device__ __forceinline__ void deep_stage(deep_wave *W, u32 lane, u32 nv, u64 s
   const bool nexthead = lane == 63u || ((hm >> (lane + 1u)) & 1ull);
   tied = in && !(head && nexthead);
   wave_sync();
+}
+
+/* The strip's longest run (wave-uniform; anything above DEEP_NEAR counts as "long"). */
+__device__ __forceinline__ u32 deep_longest_run(u32 hl, u32 lane)
+{
+  const u64 hm0 = __ballot(hl == lane);
+  const u64 ab = lane == 63u ? 0ull : hm0 >> (lane + 1u);
+  const u32 he = ab ? lane + 1u + (u32)__builtin_ctzll(ab) : 64u;
+  return wave_max(hl == lane ? he - lane : 0u);
 }
 
 /* text of rotation idx from symbol d on: 16 bytes, memory order (first symbol in the low byte of .a) */
@@ -1955,7 +2003,10 @@ __device__ void deep_big_run(deep_wave *W, u32 lane, u32 p, u32 g, deep_lists Ls
       }
       lc = wave_min(lc);
       d += lc;
-      if (lc < 16u) { split = true; break; }
+      if (lc < 16u) {
+        split = true;
+        break;
+      }
     }
     if (!split || d >= n || level >= DEEP_LEVELS) {
       /* nothing to split on yet (64 more symbols shared, or tied all the way round), or enough for one launch (a run that
@@ -1980,10 +2031,12 @@ __device__ void deep_big_run(deep_wave *W, u32 lane, u32 p, u32 g, deep_lists Ls
     wave_sync();
     for (u32 k0 = 0; k0 < len; k0 += 256u) {
       u32 v4[4], b4[4];
+      {
 #pragma unroll
-      for (u32 q = 0; q < 4u; q++) { const u32 k = k0 + 64u * q + lane; v4[q] = src[k < len ? k : 0u]; }
+        for (u32 q = 0; q < 4u; q++) { const u32 k = k0 + 64u * q + lane; v4[q] = src[k < len ? k : 0u]; }
 #pragma unroll
-      for (u32 q = 0; q < 4u; q++) { u32 at = SA_IDX(v4[q]) + d; if (at >= n) at -= n; b4[q] = T[at]; }
+        for (u32 q = 0; q < 4u; q++) { u32 at = SA_IDX(v4[q]) + d; if (at >= n) at -= n; b4[q] = T[at]; }
+      }
 #pragma unroll
       for (u32 q = 0; q < 4u; q++) if (k0 + 64u * q + lane < len) atomicAdd(&W->cnt[b4[q]], 1u);
     }
@@ -2028,10 +2081,12 @@ __device__ void deep_big_run(deep_wave *W, u32 lane, u32 p, u32 g, deep_lists Ls
     const u32 ob = shorttot ? wave_reserve(outn, shorttot) : 0u;
     for (u32 k0 = 0; k0 < len; k0 += 256u) {
       u32 v4[4], b4[4];
+      {
 #pragma unroll
-      for (u32 q = 0; q < 4u; q++) { const u32 k = k0 + 64u * q + lane; v4[q] = src[k < len ? k : 0u]; }
+        for (u32 q = 0; q < 4u; q++) { const u32 k = k0 + 64u * q + lane; v4[q] = src[k < len ? k : 0u]; }
 #pragma unroll
-      for (u32 q = 0; q < 4u; q++) { u32 at = SA_IDX(v4[q]) + d; if (at >= n) at -= n; b4[q] = T[at]; }
+        for (u32 q = 0; q < 4u; q++) { u32 at = SA_IDX(v4[q]) + d; if (at >= n) at -= n; b4[q] = T[at]; }
+      }
 #pragma unroll
       for (u32 q = 0; q < 4u; q++) {
         if (k0 + 64u * q + lane >= len) continue;
@@ -2062,11 +2117,12 @@ __device__ void deep_big_run(deep_wave *W, u32 lane, u32 p, u32 g, deep_lists Ls
   }
 }
 
-__global__ void __launch_bounds__(LBZ_WG, 4)
-k_bwt_deep(const u8 *Tbase, u8 *Bbase, lbz_block_meta *meta, lbz_layout L, u32 first, u32 count, u32 nblk, u32 segs,
-           u8 *ws, u64 slot_bytes, u8 *ws_spill, u64 spill_bytes, const u32 *slabs, u32 round, u32 handover)
+/* LIVE: the launch may step by ranks (launches behind DEEP_BUILD: k_bwt_deepr); the launches up to it order by the text alone
+   (k_bwt_deep) and carry none of that code -- 20 vector registers less, a wave more per SIMD */
+template <bool LIVE>
+__device__ __forceinline__ void deep_body(deep_lds &S, const u8 *Tbase, u8 *Bbase, lbz_block_meta *meta, lbz_layout L, u32 first, u32 count, u32 nblk, u32 segs,
+                                          u8 *ws, u64 slot_bytes, u8 *ws_spill, u64 spill_bytes, const u32 *slabs, u32 round, u32 handover)
 {
-  __shared__ deep_lds S;
   u32 bi, seg;
   if (!seg_item(nblk, segs, &bi, &seg)) return;
   const u32 blk = lbz_round_block(first, count, bi, slabs);
@@ -2128,11 +2184,13 @@ k_bwt_deep(const u8 *Tbase, u8 *Bbase, lbz_block_meta *meta, lbz_layout L, u32 f
     __syncthreads();
   }
   deep_wave *W = &S.w[wave_id()];
+  if (lane < DEEP_NEAR) W->comp[64u + lane] = ~0ull;
+  wave_sync();
   const deep_lists Ls = { sin, gin, din, sout, gout, dout };
   deep_ranks R;
   R.isa = s.isa; R.map = reinterpret_cast<u32 *>(s.k0);          /* the partition's key column is free since k_bwt_batch */
   R.tag = round + 1u; R.hcur = M->deep_hmin[round];
-  R.build = round == DEEP_BUILD; R.live = round > DEEP_BUILD;
+  R.build = round == DEEP_BUILD; R.live = LIVE;         /* (launch_sort: k_bwt_deepr for the launches behind DEEP_BUILD, k_bwt_deep up to it) */
 #ifdef DEEP_TICKS
   u64 tkb = 0, tks = 0, tkp = 0, tko = 0, tkn = 0;          /* long runs, strip set-up, steps, output; strips */
 #define DT_MARK(v) const u64 v = wall_clock64()
@@ -2202,7 +2260,7 @@ k_bwt_deep(const u8 *Tbase, u8 *Bbase, lbz_block_meta *meta, lbz_layout L, u32 f
       for (u32 step = 0; step < kmax; step++) {
         u32 at = SA_IDX(val) + d;
         if (at >= n) at -= n;
-        if (R.live) {
+        if (LIVE) {
           /* Runs whose rows all look up rotations WITH an entry step by ranks; the others by 13 symbols of text (the
              rotation without an entry was unique by the end of launch DEEP_BUILD: the text decides soon). */
           const bool canr = tied && d < n;
@@ -2372,6 +2430,22 @@ k_bwt_deep(const u8 *Tbase, u8 *Bbase, lbz_block_meta *meta, lbz_layout L, u32 f
     atomicAdd(&M->sort_elems, m);
     atomicAdd(&M->fticks[8 + (round < 7u ? round : 7u)], (u32)(wall_clock64() - tk0));
   }
+}
+
+__global__ void __launch_bounds__(LBZ_WG, 4)
+k_bwt_deep(const u8 *Tbase, u8 *Bbase, lbz_block_meta *meta, lbz_layout L, u32 first, u32 count, u32 nblk, u32 segs,
+           u8 *ws, u64 slot_bytes, u8 *ws_spill, u64 spill_bytes, const u32 *slabs, u32 round, u32 handover)
+{
+  __shared__ deep_lds S;
+  deep_body<false>(S, Tbase, Bbase, meta, L, first, count, nblk, segs, ws, slot_bytes, ws_spill, spill_bytes, slabs, round, handover);
+}
+
+__global__ void __launch_bounds__(LBZ_WG, 4)
+k_bwt_deepr(const u8 *Tbase, u8 *Bbase, lbz_block_meta *meta, lbz_layout L, u32 first, u32 count, u32 nblk, u32 segs,
+            u8 *ws, u64 slot_bytes, u8 *ws_spill, u64 spill_bytes, const u32 *slabs, u32 round, u32 handover)
+{
+  __shared__ deep_lds S;
+  deep_body<true>(S, Tbase, Bbase, meta, L, first, count, nblk, segs, ws, slot_bytes, ws_spill, spill_bytes, slabs, round, handover);
 }
 
 /* ---- kernels 3: the rank rounds (fall-back): prefix doubling, ONE LAUNCH PER ROUND ----

@@ -352,8 +352,12 @@ static void launch_sort(lbzamd_ctx *c, hipStream_t q, u32 first, u32 count, u32 
     const u32 R = lbz_fix_rounds(c->L.M);
     auto text_rounds = [&](u32 from, u32 to) {
       for (u32 r = from; r < to; r++)
-        hipLaunchKernelGGL(k_bwt_deep, g, dim3(LBZ_BWT_WG), deep_pad, q, (const u8 *)c->T, c->B, c->meta, c->L,
-                           first, count, nblk, segs, ws, (u64)c->slot_bytes, wsp, (u64)c->spill_bytes, lst, r, handover);
+        if (r <= LBZ_DEEP_BUILD)
+          hipLaunchKernelGGL(k_bwt_deep, g, dim3(LBZ_BWT_WG), deep_pad, q, (const u8 *)c->T, c->B, c->meta, c->L,
+                             first, count, nblk, segs, ws, (u64)c->slot_bytes, wsp, (u64)c->spill_bytes, lst, r, handover);
+        else                                             /* the launches that may step by ranks */
+          hipLaunchKernelGGL(k_bwt_deepr, g, dim3(LBZ_BWT_WG), deep_pad, q, (const u8 *)c->T, c->B, c->meta, c->L,
+                             first, count, nblk, segs, ws, (u64)c->slot_bytes, wsp, (u64)c->spill_bytes, lst, r, handover);
     };
     auto rank_rounds = [&](hipStream_t on, u32 which) {
       hipLaunchKernelGGL(k_bwt_fix0, g, dim3(LBZ_BWT_WG), 0, on, (const u8 *)c->T, c->B, c->meta, c->L,

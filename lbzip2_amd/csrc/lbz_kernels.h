@@ -77,8 +77,11 @@ __global__ void k_bwt_batch(const u8 *Tbase, u8 *Bbase, lbz_block_meta *meta, lb
 /* the text rounds: launch r of LBZ_DEEP_ROUNDS orders the short runs of tied rows k_bwt_batch listed, strip by strip */
 __global__ void k_bwt_deep(const u8 *Tbase, u8 *Bbase, lbz_block_meta *meta, lbz_layout L, u32 first,
                            u32 count, u32 nblk, u32 segs, u8 *ws, u64 slot_bytes, u8 *ws_spill, u64 spill_bytes, const u32 *slabs, u32 round, u32 handover);
+__global__ void k_bwt_deepr(const u8 *Tbase, u8 *Bbase, lbz_block_meta *meta, lbz_layout L, u32 first,
+                           u32 count, u32 nblk, u32 segs, u8 *ws, u64 slot_bytes, u8 *ws_spill, u64 spill_bytes, const u32 *slabs, u32 round, u32 handover);
 /* lbz_block_meta.periodic while the sorter runs: ties left for the rank rounds -- flagged before the third text launch (their
    chain of launches starts there, beside the later text launches), or by the last one (a second chain behind both) */
+#define LBZ_DEEP_BUILD 1u        /* the text launch whose leftovers get rank entries: the launches behind it (k_bwt_deepr) may step by ranks */
 #define LBZ_DEEP_HANDOVER 1u     /* the text launch that hands over a block with too many rows still tied */
 #define LBZ_HANDOVER0 850u       /* thousandths of a block's rows tied as the text rounds begin: above, the block skips them (0: no such rule).  Text-like
                                     blocks of real sources: 60-81 %, the blocks the first text launch used to hand over: 80-99 % (profiles/r05_rows_*.txt) */

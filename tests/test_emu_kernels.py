@@ -222,3 +222,24 @@ def test_oversized_runs_at_segment_bounds(emu):
             rng.choice([1, 9])
     assert (len(data), level) == (79835, 1)
     assert emu.compress(data, level) == L.orc_compress(data, level)
+
+
+def test_runs_of_every_length_in_the_text_rounds(emu):
+    """The strips of the text rounds count a row's place among the rows of its own run when the strip's longest run has at
+    most DEEP_NEAR rows (one pass, 14 symbols: deep_stage_near) and against all 64 keys otherwise (two passes of 52 bits).
+    Passages of 12 to 120 bytes occurring 2, 3, ... 40 times with different bytes behind them give runs of every length from
+    2 to 40 that tie for 9 to 100 and more symbols and split at different depths, side by side in the same strips; runs that
+    tie on whole passages and differ only behind them exercise the second word of the key.  Every stage against the oracle."""
+    import random
+    rng = random.Random(5)
+    base = bytes(gen("wiki", 30000, 51))
+    out = bytearray()
+    for mult in list(range(2, 41)) + [2, 3, 5, 9, 17, 33, 63, 64, 65]:
+        plen = rng.choice([12, 14, 15, 16, 22, 23, 27, 29, 40, 77, 120])
+        at = rng.randrange(0, len(base) - plen)
+        passage = base[at:at + plen]
+        for k in range(mult):
+            out += passage
+            out += bytes([65 + (k * 7 + mult) % 26]) * rng.choice([1, 1, 2]) + bytes(gen("text", rng.choice([3, 9, 30]), 1000 * mult + k))
+    _stages(emu, bytes(out[:99000]), 1)
+    _stages(emu, bytes(out[40000:] + out[:30000]), 2)

@@ -3,6 +3,7 @@ timed on every input.  usage: sweep_r5.py slabs kinds "K=V,K=V;K=V;..."   (LBZAM
 import os, sys, time, hashlib
 sys.path.insert(0, "/root/repo"); sys.path.insert(0, "/root/repo/tests"); sys.path.insert(0, "/root/repo/tests/tools")
 import torch, lbzip2_amd, inputs
+if os.environ.get("LBZ_LIB"): lbzip2_amd.LIB_PATH = os.environ["LBZ_LIB"]
 lib = lbzip2_amd.library()
 slabs = int(sys.argv[1]); kinds = sys.argv[2].split(","); settings = sys.argv[3].split(";")
 n = slabs * 900000
