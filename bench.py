@@ -7,7 +7,8 @@
 One "step" = one pass of the hot path (RLE1+CRC -> BWT -> MTF/ZRLE -> prefix codes -> bit
 packing -> stream assembly) over the workload, input already resident in HBM, the .bz2 bytes
 left in HBM.  Workload (BASELINE.json configs[1]): enwik9-sized text, 10^9 bytes, level -9, per
-GPU.  The real enwik9 is used if $LBZ_ENWIK9 points at it; otherwise the seeded ENWIK-LIKE
+GPU.  The real enwik9 is used if $LBZ_ENWIK9 points at it ($LBZ_ENWIK8, $LBZ_SILESIA, $LBZ_LINUX_TAR add legs on the other
+real corpora of BASELINE.json; each is checked on the box against the compiled reference); otherwise the seeded ENWIK-LIKE
 stand-in `wiki(10^9, seed 2+rank)` of lbzip2_amd/host/gen_inputs.c: XML page wrappers, wiki markup,
 Zipf words and phrases, UTF-8 interwiki text (191 distinct bytes -> 8-bit sort symbols) and verbatim
 passage repeats (deep ties) -- the profile of real English text (tied rows by depth within a few
@@ -35,6 +36,7 @@ Extra objects in the JSON line:
                 metric; `value` itself is the device-resident rate the bench contract asks for).
   configs       the other single-GPU BASELINE.json configurations (C1 10^8 text, C3 mixed -1/-9, C4's and
                 C5's per-GPU share) at full size, device-resident MB/s, each verified against its fixture.
+  value_file    the command `lbzamd FILE` on tmpfs (file -> file, process start to exit), stream checked against the fixture.
   decode        the inverse path on the stream just written (untimed by the driver): decoded MB/s, round trip checked.
   cpu_baseline  reference lbzip2's block codec (oracle/_ref: "reference") or the restatement
                 (oracle/: "port") on the box's host cores through the pthreads driver of
@@ -309,6 +311,50 @@ def decode_leg(lib, torch, kind, n, seed, level, local):
             "slowest_block_ms": {"codes": round(ds.ms_huff, 2), "sort": round(ds.ms_sort, 2), "walk": round(ds.ms_walk, 2)}}
 
 
+def file_leg(data, level, fixture):
+    """the command (lbzip2_amd/host/lbzamd: lbzip2's options over the batch path, lbzamd_io.c's readers,
+    pipelines and writers) file -> file on tmpfs, contexts and page-locked buffers included -- what a user of `lbzip2 FILE`
+    waits for.  The stream is checked against the reference fixture; the program's own report line gives the rate behind the
+    first context and how busy its reader and writer threads were."""
+    import re
+    import shutil
+    import subprocess
+    import tempfile
+    exe = os.path.join(ROOT, "lbzip2_amd", "host", "lbzamd")
+    base = "/dev/shm" if os.path.isdir("/dev/shm") and shutil.disk_usage("/dev/shm").free > 3 * len(data) else tempfile.gettempdir()
+    if not os.path.exists(exe):
+        return {"skipped": "lbzip2_amd/host/lbzamd is not built"}
+    d = tempfile.mkdtemp(prefix="lbzamd_bench_", dir=base)
+    try:
+        path = os.path.join(d, "input")
+        with open(path, "wb") as f:
+            f.write(data)
+        best, line = None, ""
+        for _ in range(2):
+            if os.path.exists(path + ".bz2"):
+                os.unlink(path + ".bz2")
+            t0 = time.perf_counter()
+            p = subprocess.run([exe, "-k", "-%d" % level, "--report", path], capture_output=True, timeout=600)
+            dt = time.perf_counter() - t0
+            if p.returncode != 0:
+                return {"error": p.stderr.decode(errors="replace")[-300:]}
+            if best is None or dt < best:
+                best, line = dt, p.stderr.decode(errors="replace").strip().splitlines()[-1]
+        h = hashlib.md5()
+        with open(path + ".bz2", "rb") as f:
+            for piece in iter(lambda: f.read(1 << 24), b""):
+                h.update(piece)
+        m = re.search(r"= (\d+) MB/s \(contexts included: first one ready after ([0-9.]+) s.*?; (\d+) MB/s behind the first context\)", line)
+        return {"value": round(len(data) / best / 1e6, 1), "unit": "MB/s", "seconds": round(best, 3), "where": base,
+                "verified": (h.hexdigest() == fixture["canon_md5"]) if fixture else None,
+                "first_context_s": float(m.group(2)) if m else None, "behind_first_context_MBps": int(m.group(3)) if m else None,
+                "report": line,
+                "what": "`lbzamd -k -9 --report FILE` on tmpfs, process start to exit (HIP initialisation, contexts, page-locked ring included); "
+                        "best of two"}
+    finally:
+        shutil.rmtree(d, ignore_errors=True)
+
+
 def find_fixture(kind, n, seed, level):
     try:
         for r in json.load(open(os.path.join(ROOT, "tests", "golden", "bench_fixtures.json"))):
@@ -530,6 +576,13 @@ def main():
                       "blocks": sq.nblocks, "verified": okq, "ms_block_chain": round(sq.ms_collect, 2),
                       "what": "lbzip2 -u blocking (blocks cut where they are full): the blocks' first pass is a chain on the device"}
 
+    value_file = None
+    if rank == 0 and not args.no_host and world == 1 and not strong and not os.environ.get("LBZ_NO_FILE_LEG"):
+        try:
+            value_file = file_leg(data, args.level, fixture)
+        except Exception as e:                                   # noqa: BLE001 -- a leg of its own: never the bench line's failure
+            value_file = {"error": repr(e)[:200]}
+
     legs = None
     if rank == 0 and not args.no_legs and world == 1 and not strong and args.kind == "wiki" and args.bytes == 1_000_000_000:
         del src, dst
@@ -638,6 +691,8 @@ def main():
         }
         if value_host:
             res["value_host"] = value_host
+        if value_file:
+            res["value_file"] = value_file
         if decode:
             res["decode"] = decode
         if sequential:
