@@ -2478,7 +2478,7 @@ k_bwt_fix0(const u8 *Tbase, u8 *Bbase, lbz_block_meta *meta, lbz_layout L, u32 f
   const u32 blk = lbz_round_block(first, count, bi, slabs);
   lbz_block_meta *M = &meta[blk];
   const u32 n = M->n;
-  if (n < 2u || M->periodic != which || seg >= M->nseg) return;
+  if (n < 2u || !lbz_ties_for(M->periodic, which) || seg >= M->nseg) return;
   const u32 lo = M->seg_lo[seg], hi = M->seg_lo[seg + 1u];
   if (lo >= hi) return;
   const u64 tk0 = wall_clock64();
@@ -2503,7 +2503,7 @@ k_bwt_fixr(const u8 *Tbase, u8 *Bbase, lbz_block_meta *meta, lbz_layout L, u32 f
   const u32 blk = lbz_round_block(first, count, bi, slabs);
   lbz_block_meta *M = &meta[blk];
   const u32 n = M->n;
-  if (n < 2u || M->periodic != which || seg >= M->nseg) return;
+  if (n < 2u || !lbz_ties_for(M->periodic, which) || seg >= M->nseg) return;
   const u32 m = M->seg_m[seg];
   if (m == 0u) return;
   const u64 tk0 = wall_clock64();
@@ -2534,7 +2534,7 @@ k_bwt_fixend(u8 *Bbase, lbz_block_meta *meta, lbz_layout L, u32 first, u32 count
   const u32 tid = threadIdx.x;
   const u32 blk = lbz_round_block(first, count, blockIdx.x, slabs);
   lbz_block_meta *M = &meta[blk];
-  if (M->n < 2u || M->periodic != which) return;
+  if (M->n < 2u || !lbz_ties_for(M->periodic, which)) return;
   const bwt_slot s = round_slot(ws, slot_bytes, ws_spill, spill_bytes, count, L, blockIdx.x);
   u8 *bwt = Bbase + lbz_elem_off(L, blk);
   {

@@ -346,7 +346,7 @@ static void launch_sort(lbzamd_ctx *c, hipStream_t q, u32 first, u32 count, u32 
     const char *e0 = getenv("LBZAMD_HANDOVER0"), *e1 = getenv("LBZAMD_HANDOVER1"), *es = getenv("LBZAMD_SPLIT_CHAIN");   /* (tuning; read per round) */
     const u32 ho0 = e0 ? (u32)atoi(e0) : LBZ_HANDOVER0;
     const u32 ho1 = e1 ? (u32)atoi(e1) : LBZ_HANDOVER1;
-    const bool split = !(es && atoi(es) == 0);
+    const bool split = es && atoi(es) != 0;              /* off by default: see below */
     const u32 handover = (ho0 & 0xFFFFu) | (ho1 << 16);
     const dim3 g(lbz_seg_grid(nblk, segs));
     const u32 R = lbz_fix_rounds(c->L.M);
@@ -370,9 +370,15 @@ static void launch_sort(lbzamd_ctx *c, hipStream_t q, u32 first, u32 count, u32 
     };
     /* The blocks handed over by k_bwt_batch or by the first launches of k_bwt_deep (LBZ_TIES_EARLY: a third of the blocks of a
        source tree) need 7-12 doublings, each a launch that a fraction of the round's workgroups take part in; the round's other
-       blocks need the remaining text launches, which thin out the same way.  The two chains touch different blocks, so they run
-       side by side: the early blocks' rank rounds on the lane's second stream, the text launches on its first, and what the
-       last text launch leaves tied (LBZ_TIES_LATE: long repeats, exactly periodic blocks) gets a chain behind both. */
+       blocks need the remaining text launches, which thin out the same way.  The two chains touch different blocks, so they CAN
+       run side by side (LBZAMD_SPLIT_CHAIN=1): the early blocks' rank rounds on the lane's second stream, the text launches on
+       its first, and what the last text launch leaves tied (LBZ_TIES_LATE: long repeats, exactly periodic blocks) gets a chain
+       behind both.  Measured (round 5, profiles/r05_trace_pysrc_split_chain.txt, r05_sweep_split_chain.txt): a round alone on
+       the device loses a quarter of its tie stages' time that way (47.7 -> 34 ms), three overlapping rounds gain nothing (the
+       other rounds' work filled those gaps already), and the second chain's 19 launches -- empty as a rule, but 45 000
+       workgroups each on a round of level-1 blocks -- cost the short rounds 6-8 %; with six streams per context on four
+       hardware queues the bench line's real-file legs lost 9 %.  So the default is ONE chain behind the last text launch, for
+       every block with ties left (which = 0). */
     lbzamd_ctx::aux_lane *al = nullptr;
     if (split) {
       for (auto &a : c->aux) if (a.q == q) al = &a;
@@ -397,12 +403,12 @@ static void launch_sort(lbzamd_ctx *c, hipStream_t q, u32 first, u32 count, u32 
       (void)hipEventRecord(al->done, al->aux);
       text_rounds(cut, LBZ_DEEP_ROUNDS);
       (void)hipStreamWaitEvent(q, al->done, 0);
+      rank_rounds(q, LBZ_TIES_LATE);
     } else {
-      (void)hipGetLastError();
+      if (split) (void)hipGetLastError();
       text_rounds(cut, LBZ_DEEP_ROUNDS);
-      rank_rounds(q, LBZ_TIES_EARLY);
+      rank_rounds(q, 0u);
     }
-    rank_rounds(q, LBZ_TIES_LATE);
   }
 }
 

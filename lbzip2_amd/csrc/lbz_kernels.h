@@ -88,6 +88,8 @@ __global__ void k_bwt_deepr(const u8 *Tbase, u8 *Bbase, lbz_block_meta *meta, lb
 #define LBZ_HANDOVER1 400u       /* ... still tied after the first text launch: above, the block goes to the rank rounds */
 #define LBZ_TIES_EARLY 2u
 #define LBZ_TIES_LATE 3u
+/* does a launch of the rank rounds for `which` (LBZ_TIES_EARLY, LBZ_TIES_LATE, or 0: every block with ties left) take this block? */
+static inline __host__ __device__ bool lbz_ties_for(u32 flag, u32 which) { return which ? flag == which : flag >= LBZ_TIES_EARLY; }
 __global__ void k_bwt_fix0(const u8 *Tbase, u8 *Bbase, lbz_block_meta *meta, lbz_layout L, u32 first,
                            u32 count, u32 nblk, u32 segs, u8 *ws, u64 slot_bytes, u8 *ws_spill, u64 spill_bytes, const u32 *slabs, u32 which);
 __global__ void k_bwt_fixr(const u8 *Tbase, u8 *Bbase, lbz_block_meta *meta, lbz_layout L, u32 first,

@@ -34,6 +34,7 @@ struct slot {                       /* one position of the ring: a chunk's input
   size_t len, out_len;
   int state;
   uint64_t seq;
+  uint64_t turn;                    /* the chunk this position takes next: position i holds chunks i, i + nslots, i + 2 nslots ... in that order */
 };
 struct chunk_note {                 /* what the muxer keeps of every chunk: 32 bytes, not its bytes */
   uint64_t off, out_len;
@@ -45,7 +46,8 @@ struct engine {
   int fd_in, fd_out, in_seek, out_seek;
   off_t in_base, out_base;
   size_t chunk_bytes, out_cap;
-  unsigned nslots, npipes, nreaders, nwriters, next_pipe_id;
+  unsigned nslots, npipes, nreaders, nwriters, next_pipe_id, ctx_ready;
+  volatile int watch_stop;
   struct slot *slots;
   pthread_mutex_t mu;
   pthread_cond_t cv;
@@ -110,6 +112,24 @@ static int write_fully(int fd, const uint8_t *buf, size_t n, int positioned, off
   return 0;
 }
 
+/* LBZAMD_IO_DEBUG=seconds: what every part of the engine is waiting for, on stderr, every so often (a stuck run shows it) */
+static void *watch_main(void *arg)
+{
+  struct engine *e = arg;
+  const char *ev = getenv("LBZAMD_IO_DEBUG");
+  const int every = ev && atoi(ev) > 0 ? atoi(ev) : 5;
+  for (;;) {
+    for (int i = 0; i < every * 10; i++) { usleep(100000); if (e->watch_stop) return NULL; }
+    pthread_mutex_lock(&e->mu);
+    fprintf(stderr, "lbzamd_io: read %llu of %lld, computed %llu, placed %llu, written %llu / next_write %llu, contexts %u of %u, failed %d; ring:",
+            (unsigned long long)e->next_read, e->total == UINT64_MAX ? -1ll : (long long)e->total, (unsigned long long)e->next_compute,
+            (unsigned long long)e->next_off_seq, (unsigned long long)e->written, (unsigned long long)e->next_write, e->ctx_ready, e->npipes, e->failed);
+    for (unsigned i = 0; i < e->nslots; i++) fprintf(stderr, " %llu:%d", (unsigned long long)e->slots[i].seq, e->slots[i].state);
+    fputc('\n', stderr);
+    pthread_mutex_unlock(&e->mu);
+  }
+}
+
 static void *reader_main(void *arg)
 {
   struct engine *e = arg;
@@ -118,7 +138,10 @@ static void *reader_main(void *arg)
     if (e->failed || e->next_read >= e->total) { pthread_mutex_unlock(&e->mu); return NULL; }
     const uint64_t seq = e->next_read++;
     struct slot *s = &e->slots[seq % e->nslots];
-    while (s->state != S_FREE && !e->failed) pthread_cond_wait(&e->cv, &e->mu);     /* the chunk nslots in front of this one is still on its way out */
+    /* the chunk nslots in front of this one is still on its way out -- or another reader is waiting for this position with
+       an EARLIER chunk (more readers than positions, or positions that are born late): that one goes first, or the chunks
+       behind it, which are compressed in order, would wait for a position that can only be freed by their own output */
+    while ((s->state != S_FREE || s->turn != seq) && !e->failed) pthread_cond_wait(&e->cv, &e->mu);
     if (e->failed || seq >= e->total) { pthread_mutex_unlock(&e->mu); return NULL; }
     s->state = S_READING;
     s->seq = seq;
@@ -136,7 +159,7 @@ static void *reader_main(void *arg)
       const uint64_t t_end = n ? seq + 1u : seq;
       if (t_end < e->total) e->total = t_end;
     }
-    if (n == 0) s->state = S_FREE;
+    if (n == 0) s->state = S_FREE;                          /* (behind the end of the input: nothing will ask for this position again) */
     else { s->len = (size_t)n; s->state = S_FULL; e->in_bytes += (uint64_t)n; }
     pthread_cond_broadcast(&e->cv);
     const int last = (size_t)n < e->chunk_bytes;
@@ -156,12 +179,15 @@ static void *pipeline_main(void *arg)
   const unsigned long mbs = e->cfg.level * 100000ul;
   if (lbzamd_create(&ctx, device, e->cfg.level, (unsigned)(e->chunk_bytes / mbs), 0)) {
     pthread_mutex_lock(&e->mu);
+    e->ctx_ready++;
     fail_locked(e, LBZAMD_IO_DEVICE, 0, lbzamd_last_error());
     pthread_mutex_unlock(&e->mu);
     return NULL;
   }
   pthread_mutex_lock(&e->mu);
   if (e->t_setup == 0.0) e->t_setup = now_s();
+  e->ctx_ready++;
+  pthread_cond_broadcast(&e->cv);
   pthread_mutex_unlock(&e->mu);
   for (;;) {
     pthread_mutex_lock(&e->mu);
@@ -243,6 +269,7 @@ static void *writer_main(void *arg)
     e->busy_w += dt;
     if (rc) { fail_locked(e, LBZAMD_IO_WRITE, err, "write()"); pthread_mutex_unlock(&e->mu); return NULL; }
     s->state = S_FREE;
+    s->turn += e->nslots;
     e->written++;
     pthread_cond_broadcast(&e->cv);
     pthread_mutex_unlock(&e->mu);
@@ -326,6 +353,11 @@ int lbzamd_io_compress(int fd_in, int fd_out, const struct lbzamd_io_cfg *cfg, s
   e.in_seek = positioned_ok(fd_in, 0, &e.in_base, &in_size);
   e.out_seek = positioned_ok(fd_out, 1, &e.out_base, NULL);
   const unsigned long mbs = cfg->level * 100000ul;
+  /* Defaults: chunks of 256 slabs on two pipelines per device.  What a file waits for before its first byte is compressed
+     is PAGE-LOCKED memory -- hipHostMalloc pins 5 GB a second (tests/tools/micro/alloc.hip), slower than the file is read, while
+     device memory up to some tens of GB usually costs nothing to get -- so the ring is page-locked position by position
+     while the first chunks are already on their way; smaller chunks make the ring cheaper and the rounds less efficient
+     (64 slabs on four pipelines: 0.3 s sooner, 4.1 instead of 5.4-6.2 GB/s behind the set-up; profiles/r05_filemode_*.txt). */
   e.npipes = (cfg->pipes ? cfg->pipes : 2u) * (cfg->ndev ? cfg->ndev : 1u);
   unsigned chunk_slabs = cfg->chunk_slabs ? cfg->chunk_slabs : 256u;
   if (e.in_seek && !cfg->chunk_slabs) {                   /* a small file: no bigger contexts than its share of slabs per pipeline */
@@ -360,11 +392,18 @@ int lbzamd_io_compress(int fd_in, int fd_out, const struct lbzamd_io_cfg *cfg, s
   /* The contexts take the longest (gigabytes of device memory each): their threads start first and create them side by side,
      while this thread page-locks the ring, position by position -- a position is S_UNBORN until its buffers exist, and the
      readers, which take chunks in order, begin as soon as the first ones do. */
-  for (unsigned i = 0; i < e.nslots; i++) e.slots[i].state = S_UNBORN;
+  for (unsigned i = 0; i < e.nslots; i++) { e.slots[i].state = S_UNBORN; e.slots[i].turn = i; }
   for (unsigned i = 0; i < e.npipes; i++) pthread_create(&th[nth++], NULL, pipeline_main, &e);
   for (unsigned i = 0; i < e.nreaders; i++) pthread_create(&th[nth++], NULL, reader_main, &e);
   for (unsigned i = 0; i < e.nwriters; i++) pthread_create(&th[nth++], NULL, writer_main, &e);
-  for (unsigned i = 0; i < e.nslots; i++) {
+  pthread_t watch;
+  const int watched = getenv("LBZAMD_IO_DEBUG") != NULL && pthread_create(&watch, NULL, watch_main, &e) == 0;
+  /* the contexts first (a tenth of a second for all of them when nothing else holds the runtime's lock; behind a queue of
+     hipHostMalloc calls they were ready only when the whole ring was: 0.7 s), then the ring */
+  pthread_mutex_lock(&e.mu);
+  while (e.ctx_ready < e.npipes && !e.failed) pthread_cond_wait(&e.cv, &e.mu);
+  pthread_mutex_unlock(&e.mu);
+  for (unsigned i = 0; i < e.nslots && !e.failed; i++) {
     uint8_t *in = lbzamd_pinned_alloc(e.chunk_bytes), *outb = lbzamd_pinned_alloc(e.out_cap);
     pthread_mutex_lock(&e.mu);
     e.slots[i].in = in;
@@ -383,6 +422,7 @@ int lbzamd_io_compress(int fd_in, int fd_out, const struct lbzamd_io_cfg *cfg, s
   }
   e.t_ring = now_s();
   for (unsigned i = 0; i < nth; i++) pthread_join(th[i], NULL);
+  if (watched) { e.watch_stop = 1; pthread_join(watch, NULL); }
   if (e.failed) { rc = e.failed; *sys_errno = e.sys_errno; snprintf(msg, msg_cap, "%s", e.msg); goto out; }
   {
     const uint32_t cc = e.cc;                                                              /* compress.c:304-321 */
