@@ -243,3 +243,24 @@ def test_runs_of_every_length_in_the_text_rounds(emu):
             out += bytes([65 + (k * 7 + mult) % 26]) * rng.choice([1, 1, 2]) + bytes(gen("text", rng.choice([3, 9, 30]), 1000 * mult + k))
     _stages(emu, bytes(out[:99000]), 1)
     _stages(emu, bytes(out[40000:] + out[:30000]), 2)
+
+
+def test_file_splitter_muxer_more_readers_than_ring_positions(emu, tmp_path):
+    """lbzamd_io.c under thread counts that make several readers wait for ONE ring position (8 readers, 3 pipelines: 8
+    positions; chunks of one slab): the position goes to the earliest chunk, or the chunks behind it -- compressed in order
+    -- would wait for a position that only their own output can free.  (Round 5: that deadlock showed on the GPU box as a
+    command that never ended; `LBZAMD_IO_DEBUG=seconds` prints what every part of the engine waits for.)"""
+    exe = os.path.join(EMU_DIR, "_build", "lbzamd_compress_emu")
+    data = bytes(gen("text", 2_600_000, 4))
+    want = L.orc_compress(data, 1)
+    src = tmp_path / "in.bin"
+    src.write_bytes(data)
+    env = dict(os.environ, LBZ_EMU_THREADS="2", LBZ_EMU_DEVICES="2")
+    for rep in range(2):
+        for c, p, r, w in ((1, 3, 8, 4), (1, 2, 16, 8), (1, 6, 4, 2)):
+            out = tmp_path / "out.bz2"
+            subprocess.run([exe, "-1", "-f", str(src), "-o", str(out), "-c", str(c), "-p", str(p), "-R", str(r), "-W", str(w)],
+                           env=env, check=True, timeout=120)
+            assert out.read_bytes() == want, (c, p, r, w)
+    z = subprocess.run([exe, "-1", "-f", "-", "-o", "-", "-c", "1", "-p", "5"], input=data, env=env, capture_output=True, timeout=120)
+    assert z.returncode == 0 and z.stdout == want
