@@ -398,11 +398,9 @@ int lbzamd_io_compress(int fd_in, int fd_out, const struct lbzamd_io_cfg *cfg, s
   for (unsigned i = 0; i < e.nwriters; i++) pthread_create(&th[nth++], NULL, writer_main, &e);
   pthread_t watch;
   const int watched = getenv("LBZAMD_IO_DEBUG") != NULL && pthread_create(&watch, NULL, watch_main, &e) == 0;
-  /* the contexts first (a tenth of a second for all of them when nothing else holds the runtime's lock; behind a queue of
-     hipHostMalloc calls they were ready only when the whole ring was: 0.7 s), then the ring */
-  pthread_mutex_lock(&e.mu);
-  while (e.ctx_ready < e.npipes && !e.failed) pthread_cond_wait(&e.cv, &e.mu);
-  pthread_mutex_unlock(&e.mu);
+  /* (Tried: the contexts first, then the ring beside the running pipelines.  The contexts are then ready after 0.1-0.3 s, but
+     every hipHostMalloc that follows holds the runtime's lock against the pipelines' copies and launches: 10^9 bytes 0.70-0.90 s
+     instead of 0.66, 3 * 10^9 1.3-1.5 s instead of 1.1.  Ring and contexts side by side it is.) */
   for (unsigned i = 0; i < e.nslots && !e.failed; i++) {
     uint8_t *in = lbzamd_pinned_alloc(e.chunk_bytes), *outb = lbzamd_pinned_alloc(e.out_cap);
     pthread_mutex_lock(&e.mu);
