@@ -1832,7 +1832,7 @@ __device__ __forceinline__ u32 deep_kmax(u32 round) { return round < 2u ? 2u : (
  * mine is smaller, every key of a run behind it greater.  So only the keys of my OWN run need counting -- the rows from its
  * first lane on, as many as the strip's longest run has (round 5: DEEP_NEAR) -- and the rest is the run's first lane itself.
  * On text nine strips in ten hold no run of more than 16 rows: 2 to 16 compare-and-add pairs a row and slice at a per-lane
- * LDS address instead of 64 at a broadcast one (the count was a third of the kernel's vector instructions: DESIGN 15.1).
+ * LDS address instead of 64 at a broadcast one (the count was a third of the kernel's vector instructions: DESIGN 3.2, 4).
  * A strip with a longer run counts against all 64 keys as before. */
 __device__ __forceinline__ u32 deep_longest_run(u32 hl, u32 lane);
 template <u32 N>

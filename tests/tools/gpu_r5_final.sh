@@ -5,11 +5,11 @@ cd /root/repo
 export PYTHONPATH=/root/repo:/root/repo/tests LD_LIBRARY_PATH=/opt/rocm/lib:$LD_LIBRARY_PATH
 TAG=${1:-r05_z}
 mkdir -p gpurun_out
-timeout 1500 python -m pytest tests -m gpu -x -q --durations=6 > gpurun_out/${TAG}_pytest.log 2>&1; echo "pytest rc=$?"; tail -12 gpurun_out/${TAG}_pytest.log
-bash tests/tools/run_profiles.sh $TAG > gpurun_out/${TAG}_profiles.log 2>&1; tail -5 gpurun_out/${TAG}_profiles.log
+timeout 600 python -m pytest tests -m gpu -x -q --durations=6 > gpurun_out/${TAG}_pytest.log 2>&1; echo "pytest rc=$?"; tail -12 gpurun_out/${TAG}_pytest.log
+timeout 600 bash tests/tools/run_profiles.sh $TAG > gpurun_out/${TAG}_profiles.log 2>&1; tail -5 gpurun_out/${TAG}_profiles.log
 cp gpurun_out/${TAG}_s1_pmc_traffic.json profiles/pmc_traffic.json
-bash tests/tools/run_pmc.sh ${TAG}p 556 wiki > gpurun_out/${TAG}_pmc.log 2>&1; grep -E "^k_bwt_deep |^k_bwt_deepr|^k_bwt_batch|^k_mtf" gpurun_out/${TAG}_pmc.log | cut -c1-400
-timeout 900 python bench.py > gpurun_out/${TAG}_bench.json 2> gpurun_out/${TAG}_bench.err; echo "bench rc=$?"; tail -c 600 gpurun_out/${TAG}_bench.err
+timeout 600 bash tests/tools/run_pmc.sh ${TAG}p 556 wiki > gpurun_out/${TAG}_pmc.log 2>&1; grep -E "^k_bwt_deep |^k_bwt_deepr|^k_bwt_batch|^k_mtf" gpurun_out/${TAG}_pmc.log | cut -c1-400
+timeout 600 python bench.py > gpurun_out/${TAG}_bench.json 2> gpurun_out/${TAG}_bench.err; echo "bench rc=$?"; tail -c 600 gpurun_out/${TAG}_bench.err
 python - <<PY
 import json
 r = json.loads(open("gpurun_out/${TAG}_bench.json").read().strip().splitlines()[-1])
