@@ -1955,131 +1955,6 @@ __device__ __forceinline__ void deep_publish(deep_ranks R, u32 idx, u32 rank, u3
 
 struct deep_lists { const u32 *sin, *gin, *din; u32 *sout, *gout, *dout; };
 
-/* A piece of 64 .. DEEP_MID rows of a long run, ordered in ONE pass (round 5).  The counting split below takes a piece apart one
- * symbol at a time -- common prefix, count, scan, placement: four latency-bound phases of 3-5 us each whatever the piece's
- * size -- and an average piece of a text block is 190 rows (profiles/r05_deep_ticks.txt: 2 600 pieces and 490 000 piece-rows
- * per block, 43 % of a text launch's wave time).  Here the piece's rows (four per lane) fetch their next 16 bytes once; the
- * symbols ALL of them share are skipped (lc, as below), the next up to seven become a 56-bit key with the row's place in the
- * piece in the low byte -- unique, so a row's new place is the number of smaller keys, counted against every key of the
- * piece at a broadcast LDS address (two keys a read, sixteen compare-and-add pairs for a lane's four rows).  The keys sit
- * where the split's counters do, the rows where its offsets do.  Rows alone with their key are final; the others -- tied on
- * up to seven more symbols, in sub-runs of any length -- go to the next list.  Returns false if the piece has to go the
- * other way (fewer than 16 symbols left in front of the block's end). */
-#ifndef DEEP_MID
-#define DEEP_MID 256u
-#endif
-__device__ __forceinline__ bool deep_mid_run(deep_wave *W, u32 lane, const u32 *src, u32 len, u32 d, u32 r0, u32 rank0, bool moved,
-                                             deep_lists Ls, const u8 *T, u32 n, u32 *sa, u8 *bwt, const u8 *inv, lbz_block_meta *M,
-                                             u32 *outn, u32 &hmin, bool late, deep_ranks R)
-{
-  const u32 nq = (len + 63u) >> 6;                         /* strips the piece fills (wave-uniform): 2 .. 4 */
-  u32 v4[4];
-  u64x2 x4[4];
-#pragma unroll
-  for (u32 q = 0; q < 4u; q++) { const u32 k = 64u * q + lane; v4[q] = src[k < len ? k : 0u]; }
-  /* symbols every row shares with the piece's first row: 16 at a time while all of them are shared (at most 64: a
-     template that a hundred rows share for 60 symbols costs four 16-byte steps, as in the counting split) */
-  u32 lc = 16u;
-  for (u32 it = 0; it < 4u; it++) {
-    if (d + 16u > n) return false;
-#pragma unroll
-    for (u32 q = 0; q < 4u; q++) x4[q] = deep_load16(T, n, SA_IDX(v4[q]), d);
-    const u64 ra = (u64)(u32)__builtin_amdgcn_readfirstlane((int)(u32)x4[0].x) | (u64)(u32)__builtin_amdgcn_readfirstlane((int)(u32)(x4[0].x >> 32)) << 32;
-    const u64 rb = (u64)(u32)__builtin_amdgcn_readfirstlane((int)(u32)x4[0].y) | (u64)(u32)__builtin_amdgcn_readfirstlane((int)(u32)(x4[0].y >> 32)) << 32;
-    lc = 16u;
-#pragma unroll
-    for (u32 q = 0; q < 4u; q++) {
-      const u64 xa = x4[q].x ^ ra, xb = x4[q].y ^ rb;
-      const u32 l = xa ? (u32)__builtin_ctzll(xa) >> 3 : (xb ? 8u + ((u32)__builtin_ctzll(xb) >> 3) : 16u);
-      if (64u * q + lane < len) lc = l < lc ? l : lc;
-    }
-    lc = wave_min(lc);
-    if (lc < 16u || it == 3u) break;
-    d += 16u;
-  }
-  const u32 nsym = 16u - lc < 7u ? 16u - lc : 7u;          /* symbols the key holds; 0: the piece shares all 16 */
-  u64 *K = reinterpret_cast<u64 *>(W->cnt);                /* cnt[256] + fill[256]: 256 keys */
-  u32 *V = reinterpret_cast<u32 *>(W->base);               /* base[256] + obase[256]: 256 rows */
-  u64 key[4];
-#pragma unroll
-  for (u32 q = 0; q < 4u; q++) {
-    const u32 k = 64u * q + lane;
-    const u64 hi = __builtin_bswap64(x4[q].x), lw = __builtin_bswap64(x4[q].y);      /* big-endian: integer order = string order */
-    /* the 128 bits shifted left by lc symbols, top 56 of them */
-    const u32 sh = 8u * lc;
-    const u64 top = sh == 0u ? hi : (sh < 64u ? (hi << sh) | (lw >> (64u - sh)) : (sh == 64u ? lw : lw << (sh - 64u)));
-    const u64 mask = nsym >= 7u ? ~0xFFull : (nsym == 0u ? 0ull : ~((1ull << (64u - 8u * nsym)) - 1ull));   /* (nsym = 0: 64 shared symbols and counting -- the piece goes on as it is) */
-    key[q] = k < len ? ((top & mask) & ~0xFFull) | (u64)k : ~0ull;
-    K[k] = key[q];
-  }
-  wave_sync();
-  u32 pos[4] = { 0u, 0u, 0u, 0u };
-  {
-    const u64x2 *kp = reinterpret_cast<const u64x2 *>(K);
-    const u32 pairs = (len + 1u) >> 1;
-    for (u32 j0 = 0; j0 < pairs; j0 += 4u) {               /* eight keys a trip: four broadcast reads in flight (registers: a wave more per SIMD is worth more than the reads) */
-      u64x2 c2[4];
-#pragma unroll
-      for (u32 t = 0; t < 4u; t++) c2[t] = kp[j0 + t < 128u ? j0 + t : 127u];
-#pragma unroll
-      for (u32 t = 0; t < 4u; t++) {
-        if (j0 + t < pairs) {
-#pragma unroll
-          for (u32 q = 0; q < 4u; q++) if (q < nq) pos[q] = add_if_less2(pos[q], c2[t].x, c2[t].y, key[q]);
-        }
-      }
-    }
-  }
-  wave_sync();                                             /* every lane has read the keys: their column is written in order now */
-#pragma unroll
-  for (u32 q = 0; q < 4u; q++) if (64u * q + lane < len) { K[pos[q]] = key[q] >> 8; V[pos[q]] = v4[q]; }
-  wave_sync();
-  /* the sorted piece: sub-runs of equal keys */
-  const u32 dnew = d + lc + nsym;
-  u32 hq[4], val[4];
-  bool td[4];
-  u32 carry = 0u, ntied = 0u;
-#pragma unroll
-  for (u32 q = 0; q < 4u; q++) {
-    const u32 k = 64u * q + lane;
-    const bool ok = k < len;
-    const u64 sk = ok ? K[k] : 0ull;
-    const bool head = ok && (k == 0u || K[k - 1u] != sk);
-    const bool nexthead = !ok || k + 1u >= len || K[k + 1u] != sk;
-    u32 h = wave_incl_max(head ? k : 0u);
-    if (h < carry) h = carry;
-    carry = (u32)__builtin_amdgcn_readlane((int)h, 63);
-    hq[q] = h;
-    td[q] = ok && !(head && nexthead);
-    val[q] = ok ? V[k] : 0u;
-    ntied += (u32)__popcll(__ballot(td[q]));
-  }
-  u32 ob = ntied ? wave_reserve(outn, ntied) : 0u;
-#pragma unroll
-  for (u32 q = 0; q < 4u; q++) {
-    const u32 k = 64u * q + lane;
-    const u64 tm = __ballot(td[q]);
-    if (k < len) {
-      const u32 row = r0 + k, rank = r0 + hq[q];
-      if (!td[q] || late) {
-        sa[row] = val[q] | ((td[q] && hq[q] != k) ? TIE_FLAG : 0u);
-        if (!td[q]) bwt[row] = inv[SA_CODE(val[q])];
-        if (SA_IDX(val[q]) == 0u) M->bwt_idx = row;
-      }
-      if (td[q]) {
-        const u32 o = ob + (u32)__popcll(tm & lanes_below());
-        Ls.sout[o] = val[q]; Ls.gout[o] = rank; Ls.dout[o] = dnew;
-        if (R.build) deep_publish(R, SA_IDX(val[q]), rank, dnew);
-      }
-      if (R.live && (moved || hq[q] != 0u)) R.isa[SA_IDX(val[q])] = ISA_ENTRY_D(rank, rank0, R.tag, dnew);   /* final for this launch: its rank changed */
-    }
-    ob += (u32)__popcll(tm);
-  }
-  if (ntied) hmin = dnew < hmin ? dnew : hmin;
-  wave_sync();
-  return true;
-}
-
 /* A run of g >= 64 tied rows (list entries [p, p + g)): too long for a strip.  Its wave takes it apart symbol by symbol:
  * it finds how many further symbols ALL rows of the piece share (compared with the piece's first row, 16 bytes a step, up
  * to 64), then splits the piece on the first symbol they do not all share -- a counting sort on one byte whose only state
@@ -2089,7 +1964,13 @@ __device__ __forceinline__ bool deep_mid_run(deep_wave *W, u32 lane, const u32 *
  * other of two scratch columns (the run's own stretch of the incoming list and the partition's value column, free by now)
  * and onto a small stack.  " of the ", four thousand rows of a text block, is thirty pieces after one symbol and short runs
  * after two or three; a template that a hundred rows share for 60 symbols costs four 16-byte steps.  A piece that shares
- * 64 further symbols (or overflows the stack) goes to the next list as it is, deeper, and the next launch carries on.    */
+ * 64 further symbols (or overflows the stack) goes to the next list as it is, deeper, and the next launch carries on.
+ * (Round 5, measured: 2 600 pieces and 490 000 piece-rows per text block, 43 % of a text launch's wave time, 3-5 us for
+ * each of a piece's four phases whatever its size -- profiles/r05_deep_ticks.txt.  Ordering pieces of up to 256 rows in one
+ * pass instead -- 16 bytes a row fetched once, a 56-bit key of the seven symbols behind the shared ones, all-pairs count
+ * over the piece's keys in LDS -- halves the long runs' wave time (46.9 -> 26.3 ms per block) and costs 24 vector registers:
+ * at five waves a SIMD the tie stages gain 2-4 % on text and lose 2 % on sources, at four they lose 8 %.  Taken out;
+ * commit "k_bwt_deep: deep_mid_run" has it.)                                                                              */
 __device__ void deep_big_run(deep_wave *W, u32 lane, u32 p, u32 g, deep_lists Ls, u32 *ping, u32 *pong, const u8 *T, u32 n,
                              u32 *sa, u8 *bwt, const u8 *inv, lbz_block_meta *M, u32 *outn, u32 &hmin, bool late, deep_ranks R)
 {
@@ -2109,9 +1990,6 @@ __device__ void deep_big_run(deep_wave *W, u32 lane, u32 p, u32 g, deep_lists Ls
     const u32 *src = (buf ? pong : ping) + p + off;
     u32 *dst = (buf ? ping : pong) + p + off;
     const u32 r0 = rank0 + off;                         /* the piece's rows are consecutive from here */
-#ifndef DEEP_NO_MID
-    if (len <= DEEP_MID && deep_mid_run(W, lane, src, len, d, r0, rank0, off != 0u, Ls, T, n, sa, bwt, inv, M, outn, hmin, late, R)) continue;
-#endif
     const u32 idx0 = SA_IDX(src[0]);
     bool split = false;
 #ifdef DEEP_TICKS

@@ -264,3 +264,23 @@ def test_file_splitter_muxer_more_readers_than_ring_positions(emu, tmp_path):
             assert out.read_bytes() == want, (c, p, r, w)
     z = subprocess.run([exe, "-1", "-f", "-", "-o", "-", "-c", "1", "-p", "5"], input=data, env=env, capture_output=True, timeout=120)
     assert z.returncode == 0 and z.stdout == want
+
+
+def test_long_runs_of_every_size(emu):
+    """Runs of 64 rows and more go to k_bwt_deep's long-run code (deep_big_run: common prefix, then a counting split on the first
+    symbol the rows do not all share, pieces of 64 rows and more split again).  Passages of 12 .. 200 bytes that occur 64 ..
+    300 times, with one to three different bytes and then different text behind them: pieces of every size, shared prefixes
+    shorter and longer than the 16 bytes a step loads (and longer than the 64 a launch follows), sub-runs that stay tied."""
+    import random
+    rng = random.Random(11)
+    base = bytes(gen("wiki", 20000, 77))
+    out = bytearray()
+    for mult, plen in ((64, 12), (70, 29), (130, 16), (200, 40), (256, 23), (257, 15), (300, 120), (90, 200), (65, 77)):
+        at = rng.randrange(0, len(base) - plen)
+        passage = base[at:at + plen]
+        for k in range(mult):
+            out += passage + bytes([97 + k % 3]) * (1 + k % 2) + bytes([65 + (k * 5) % 23]) + bytes(gen("text", rng.choice([2, 5, 11]), 3000 + 7 * k + mult))
+    data = bytes(out)
+    assert len(data) > 60000
+    _stages(emu, data[:99000], 1)
+    _stages(emu, data[50000:50000 + 180000], 2)
