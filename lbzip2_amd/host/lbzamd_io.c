@@ -13,6 +13,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <sys/mman.h>
 #include <sys/stat.h>
 #include <time.h>
 #include <unistd.h>
@@ -31,6 +32,7 @@ enum { S_FREE = 0, S_READING, S_FULL, S_BUSY, S_DONE, S_WRITING, S_UNBORN };
 
 struct slot {                       /* one position of the ring: a chunk's input and its compressed bytes, both page-locked */
   uint8_t *in, *out;
+  const uint8_t *src;               /* where the chunk's bytes are: `in`, or the chunk's place in the mapped input file */
   size_t len, out_len;
   int state;
   uint64_t seq;
@@ -45,6 +47,9 @@ struct engine {
   struct lbzamd_io_cfg cfg;
   int fd_in, fd_out, in_seek, out_seek;
   off_t in_base, out_base;
+  int plain_out;
+  const uint8_t *map;               /* the input file mapped (a regular file): chunks are ranges of it, nothing is read or page-locked */
+  uint64_t map_size;
   size_t chunk_bytes, out_cap;
   unsigned nslots, npipes, nreaders, nwriters, next_pipe_id, ctx_ready;
   volatile int watch_stop;
@@ -148,7 +153,15 @@ static void *reader_main(void *arg)
     pthread_mutex_unlock(&e->mu);
 
     const double t = now_s();
-    const ssize_t n = read_fully(e->fd_in, s->in, e->chunk_bytes, e->in_seek, e->in_base + (off_t)(seq * e->chunk_bytes));
+    ssize_t n;
+    if (e->map) {                                           /* nothing to read: the chunk is where the file is mapped */
+      const uint64_t at = seq * (uint64_t)e->chunk_bytes;
+      n = at >= e->map_size ? 0 : (ssize_t)(e->map_size - at < e->chunk_bytes ? e->map_size - at : e->chunk_bytes);
+      s->src = e->map + at;
+    } else {
+      n = read_fully(e->fd_in, s->in, e->chunk_bytes, e->in_seek, e->in_base + (off_t)(seq * e->chunk_bytes));
+      s->src = s->in;
+    }
     const int err = errno;
     const double dt = now_s() - t;
 
@@ -208,7 +221,7 @@ static void *pipeline_main(void *arg)
 
     lbzamd_part part;
     const double t = now_s();
-    const int rc = lbzamd_compress_host_body(ctx, s->in, s->len, s->out, e->out_cap, &s->out_len, &part);
+    const int rc = lbzamd_compress_host_body(ctx, s->src, s->len, s->out, e->out_cap, &s->out_len, &part);
     const double dt = now_s() - t;
 
     pthread_mutex_lock(&e->mu);
@@ -371,7 +384,20 @@ int lbzamd_io_compress(int fd_in, int fd_out, const struct lbzamd_io_cfg *cfg, s
   e.total = UINT64_MAX;
   if (e.in_seek) e.total = (in_size + e.chunk_bytes - 1u) / e.chunk_bytes;
   if (e.total != UINT64_MAX && e.total < e.npipes) e.npipes = e.total ? (unsigned)e.total : 1u;
-  e.nreaders = e.in_seek ? (cfg->readers ? cfg->readers : 4u) : 1u;
+  /* A regular input file is MAPPED, not read (round 5): what a file waited for was page-locked memory -- hipHostMalloc pins
+     5 GB a second, slower than the file is read -- and most of the ring was input.  A chunk is then a range of the mapping and
+     the runtime stages it across the link as it does any pageable buffer: 4.2-5.0 GB/s behind the set-up instead of 5.3-6.7
+     from page-locked buffers, but the set-up is 0.1-0.2 s instead of 0.6-0.7, which files of up to some tens of GB care about
+     more.  LBZAMD_IO_NOMAP=1: read into page-locked buffers as before (a pipe always is). */
+  if (e.in_seek && !getenv("LBZAMD_IO_NOMAP") && in_size > 0 && (e.in_base % (off_t)sysconf(_SC_PAGESIZE)) == 0) {
+    void *m = mmap(NULL, (size_t)in_size, PROT_READ, MAP_PRIVATE, fd_in, e.in_base);
+    if (m != MAP_FAILED) {
+      e.map = m;
+      e.map_size = in_size;
+      (void)madvise(m, (size_t)in_size, MADV_SEQUENTIAL);
+    }
+  }
+  e.nreaders = e.map ? 1u : (e.in_seek ? (cfg->readers ? cfg->readers : 4u) : 1u);
   e.nwriters = e.out_seek ? (cfg->writers ? cfg->writers : 2u) : 1u;
   if (e.total != UINT64_MAX && e.nreaders > e.total) e.nreaders = e.total ? (unsigned)e.total : 1u;
   e.nslots = 2u * e.npipes + 2u;                          /* per pipeline: one chunk in the device's hands, one arriving or leaving; + one being read, one being written */
@@ -402,11 +428,17 @@ int lbzamd_io_compress(int fd_in, int fd_out, const struct lbzamd_io_cfg *cfg, s
      every hipHostMalloc that follows holds the runtime's lock against the pipelines' copies and launches: 10^9 bytes 0.70-0.90 s
      instead of 0.66, 3 * 10^9 1.3-1.5 s instead of 1.1.  Ring and contexts side by side it is.) */
   for (unsigned i = 0; i < e.nslots && !e.failed; i++) {
-    uint8_t *in = lbzamd_pinned_alloc(e.chunk_bytes), *outb = lbzamd_pinned_alloc(e.out_cap);
+    /* With the input mapped the output positions are plain memory too: nothing is page-locked, the library stages the stream
+       through device memory and the runtime's own buffers (a quarter of the input's bytes on text).  10^9 bytes file -> file
+       0.47 s against 0.59 with page-locked output positions and 0.79-0.88 with the whole ring page-locked; 3 * 10^9: 0.75 s
+       against 1.05 and 1.12-1.22 (profiles/r05_filemode_p.txt).  LBZAMD_IO_PINNED_OUT=1: page-locked output positions. */
+    const int plain_out = e.map && getenv("LBZAMD_IO_PINNED_OUT") == NULL;
+    uint8_t *in = e.map ? NULL : lbzamd_pinned_alloc(e.chunk_bytes), *outb = plain_out ? malloc(e.out_cap) : lbzamd_pinned_alloc(e.out_cap);
+    e.plain_out = plain_out;
     pthread_mutex_lock(&e.mu);
     e.slots[i].in = in;
     e.slots[i].out = outb;
-    if (!in || !outb) {
+    if ((!in && !e.map) || !outb) {
       const int no_dev = lbzamd_device_count() < 1;
       fail_locked(&e, no_dev ? LBZAMD_IO_DEVICE : LBZAMD_IO_MEMORY, ENOMEM, no_dev ? "no HIP device (this program has no CPU path)" : "page-locked chunk buffers");
       pthread_mutex_unlock(&e.mu);
@@ -445,13 +477,17 @@ out:;
   if (cfg->report && !rc) {
     const double w = t1 - e.t0;
     fprintf(stderr, "file splitter/muxer: %llu B -> %llu B in %.3f s = %.0f MB/s (contexts included: first one ready after %.3f s, ring page-locked after %.3f s; %.0f MB/s behind the first context); "
-                    "%u pipeline(s) on %u device(s), chunks of %u slabs; %u reader(s) busy %.0f%% each, %u writer(s) busy %.0f%% each, pipelines busy %.0f%%\n",
+                    "%u pipeline(s) on %u device(s), chunks of %u slabs%s; %u reader(s) busy %.0f%% each, %u writer(s) busy %.0f%% each, pipelines busy %.0f%%\n",
             (unsigned long long)e.in_bytes, (unsigned long long)(e.next_off + TRAILER_SIZE), w, (double)e.in_bytes / w / 1e6,
             e.t_setup > 0.0 ? e.t_setup - e.t0 : 0.0, e.t_ring - e.t0, (double)e.in_bytes / (w - (e.t_setup > 0.0 ? e.t_setup - e.t0 : 0.0)) / 1e6,
-            e.npipes, cfg->ndev ? cfg->ndev : 1u, chunk_slabs,
+            e.npipes, cfg->ndev ? cfg->ndev : 1u, chunk_slabs, e.map ? " of the mapped input" : "",
             e.nreaders, 100.0 * e.busy_r / (w * e.nreaders), e.nwriters, 100.0 * e.busy_w / (w * e.nwriters), 100.0 * e.busy_p / (w * e.npipes));
   }
-  if (e.slots) for (unsigned i = 0; i < e.nslots; i++) { if (e.slots[i].in) lbzamd_pinned_free(e.slots[i].in); if (e.slots[i].out) lbzamd_pinned_free(e.slots[i].out); }
+  if (e.slots) for (unsigned i = 0; i < e.nslots; i++) {
+    if (e.slots[i].in) lbzamd_pinned_free(e.slots[i].in);
+    if (e.slots[i].out) { if (e.plain_out) free(e.slots[i].out); else lbzamd_pinned_free(e.slots[i].out); }
+  }
+  if (e.map) (void)munmap((void *)e.map, (size_t)e.map_size);
   free(e.slots);
   free(e.note);
   free(th);

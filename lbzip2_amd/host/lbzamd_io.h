@@ -5,8 +5,10 @@
  * What lbzip2 does with one reader thread, N worker threads and one writer thread (src/process.c:260-307 source,
  * :351-417 sink, src/compress.c:238-250 in-order mux) is done here with
  *
- *   readers    R threads.  A regular file is read at chunk offsets with pread() -- any thread takes the next chunk --
- *              into a ring of page-locked buffers; a pipe or a terminal is read by one thread in order;
+ *   readers    a regular file is MAPPED: a chunk is a range of the mapping, nothing is read or page-locked (the runtime stages
+ *              pageable memory across the link itself); LBZAMD_IO_NOMAP=1, or a file that cannot be mapped: R threads read
+ *              it at chunk offsets with pread() -- any thread takes the next chunk -- into a ring of page-locked buffers.
+ *              A pipe or a terminal is read by one thread in order into such a ring;
  *   pipelines  P per device, each with a device context of its own (created by the pipeline's thread, all at once):
  *              a chunk = a slab-aligned range compressed body-only (lbzamd_compress_host_body), so the H2D copies,
  *              kernels and D2H copies of consecutive chunks overlap;
