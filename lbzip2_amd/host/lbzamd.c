@@ -458,8 +458,8 @@ int main(int argc, char **argv)
   const char *slash = strrchr(argv[0], '/');
   G.prog = slash ? slash + 1 : argv[0];
   signal(SIGPIPE, SIG_DFL);
-  for (int s = 0; s < 3; s++) {
-    static const int sigs[] = { SIGINT, SIGTERM, SIGHUP };
+  for (int s = 0; s < 4; s++) {
+    static const int sigs[] = { SIGINT, SIGTERM, SIGHUP, SIGBUS };      /* (SIGBUS: a mapped input file that shrank under the program) */
     struct sigaction sa;
     memset(&sa, 0, sizeof sa);
     sa.sa_handler = on_signal;

@@ -116,6 +116,8 @@ def test_stdout_filter_and_sequential(tmp_path, emu_cli):
     assert rc == 0
     rc, out, _, _ = _both(tmp_path, emu_cli, {}, ["-1"], stdin=b"")                                   # the 14-byte stream of nothing
     assert rc == 0 and len(out) == 14
+    rc, _, _, tree = _both(tmp_path, emu_cli, {"empty": F(b""), "one": F(b"x")}, ["-1", "empty", "one"])        # ... as files
+    assert rc == 0 and set(tree) == {"empty.bz2", "one.bz2"}
     rc, out, err, _ = _both(tmp_path, emu_cli, {}, ["-1v"], stdin=SOUP)
     assert rc == 0 and b"compressing stdin to stdout" in err and b"stdin: compression ratio" in err
 
