@@ -1955,6 +1955,131 @@ __device__ __forceinline__ void deep_publish(deep_ranks R, u32 idx, u32 rank, u3
 
 struct deep_lists { const u32 *sin, *gin, *din; u32 *sout, *gout, *dout; };
 
+/* A piece of 64 .. DEEP_MID rows of a long run, ordered in ONE pass (round 5; k_bwt_long only).  The counting split below takes a piece apart one
+ * symbol at a time -- common prefix, count, scan, placement: four latency-bound phases of 3-5 us each whatever the piece's
+ * size -- and an average piece of a text block is 190 rows (profiles/r05_deep_ticks.txt: 2 600 pieces and 490 000 piece-rows
+ * per block, 43 % of a text launch's wave time).  Here the piece's rows (four per lane) fetch their next 16 bytes once; the
+ * symbols ALL of them share are skipped (lc, as below), the next up to seven become a 56-bit key with the row's place in the
+ * piece in the low byte -- unique, so a row's new place is the number of smaller keys, counted against every key of the
+ * piece at a broadcast LDS address (two keys a read, sixteen compare-and-add pairs for a lane's four rows).  The keys sit
+ * where the split's counters do, the rows where its offsets do.  Rows alone with their key are final; the others -- tied on
+ * up to seven more symbols, in sub-runs of any length -- go to the next list.  Returns false if the piece has to go the
+ * other way (fewer than 16 symbols left in front of the block's end). */
+#ifndef DEEP_MID
+#define DEEP_MID 256u
+#endif
+__device__ __forceinline__ bool deep_mid_run(deep_wave *W, u32 lane, const u32 *src, u32 len, u32 d, u32 r0, u32 rank0, bool moved,
+                                             deep_lists Ls, const u8 *T, u32 n, u32 *sa, u8 *bwt, const u8 *inv, lbz_block_meta *M,
+                                             u32 *outn, u32 &hmin, bool late, deep_ranks R)
+{
+  const u32 nq = (len + 63u) >> 6;                         /* strips the piece fills (wave-uniform): 2 .. 4 */
+  u32 v4[4];
+  u64x2 x4[4];
+#pragma unroll
+  for (u32 q = 0; q < 4u; q++) { const u32 k = 64u * q + lane; v4[q] = src[k < len ? k : 0u]; }
+  /* symbols every row shares with the piece's first row: 16 at a time while all of them are shared (at most 64: a
+     template that a hundred rows share for 60 symbols costs four 16-byte steps, as in the counting split) */
+  u32 lc = 16u;
+  for (u32 it = 0; it < 4u; it++) {
+    if (d + 16u > n) return false;
+#pragma unroll
+    for (u32 q = 0; q < 4u; q++) x4[q] = deep_load16(T, n, SA_IDX(v4[q]), d);
+    const u64 ra = (u64)(u32)__builtin_amdgcn_readfirstlane((int)(u32)x4[0].x) | (u64)(u32)__builtin_amdgcn_readfirstlane((int)(u32)(x4[0].x >> 32)) << 32;
+    const u64 rb = (u64)(u32)__builtin_amdgcn_readfirstlane((int)(u32)x4[0].y) | (u64)(u32)__builtin_amdgcn_readfirstlane((int)(u32)(x4[0].y >> 32)) << 32;
+    lc = 16u;
+#pragma unroll
+    for (u32 q = 0; q < 4u; q++) {
+      const u64 xa = x4[q].x ^ ra, xb = x4[q].y ^ rb;
+      const u32 l = xa ? (u32)__builtin_ctzll(xa) >> 3 : (xb ? 8u + ((u32)__builtin_ctzll(xb) >> 3) : 16u);
+      if (64u * q + lane < len) lc = l < lc ? l : lc;
+    }
+    lc = wave_min(lc);
+    if (lc < 16u || it == 3u) break;
+    d += 16u;
+  }
+  const u32 nsym = 16u - lc < 7u ? 16u - lc : 7u;          /* symbols the key holds; 0: the piece shares all 16 */
+  u64 *K = reinterpret_cast<u64 *>(W->cnt);                /* cnt[256] + fill[256]: 256 keys */
+  u32 *V = reinterpret_cast<u32 *>(W->base);               /* base[256] + obase[256]: 256 rows */
+  u64 key[4];
+#pragma unroll
+  for (u32 q = 0; q < 4u; q++) {
+    const u32 k = 64u * q + lane;
+    const u64 hi = __builtin_bswap64(x4[q].x), lw = __builtin_bswap64(x4[q].y);      /* big-endian: integer order = string order */
+    /* the 128 bits shifted left by lc symbols, top 56 of them */
+    const u32 sh = 8u * lc;
+    const u64 top = sh == 0u ? hi : (sh < 64u ? (hi << sh) | (lw >> (64u - sh)) : (sh == 64u ? lw : lw << (sh - 64u)));
+    const u64 mask = nsym >= 7u ? ~0xFFull : (nsym == 0u ? 0ull : ~((1ull << (64u - 8u * nsym)) - 1ull));   /* (nsym = 0: 64 shared symbols and counting -- the piece goes on as it is) */
+    key[q] = k < len ? ((top & mask) & ~0xFFull) | (u64)k : ~0ull;
+    K[k] = key[q];
+  }
+  wave_sync();
+  u32 pos[4] = { 0u, 0u, 0u, 0u };
+  {
+    const u64x2 *kp = reinterpret_cast<const u64x2 *>(K);
+    const u32 pairs = (len + 1u) >> 1;
+    for (u32 j0 = 0; j0 < pairs; j0 += 4u) {               /* eight keys a trip: four broadcast reads in flight (registers: a wave more per SIMD is worth more than the reads) */
+      u64x2 c2[4];
+#pragma unroll
+      for (u32 t = 0; t < 4u; t++) c2[t] = kp[j0 + t < 128u ? j0 + t : 127u];
+#pragma unroll
+      for (u32 t = 0; t < 4u; t++) {
+        if (j0 + t < pairs) {
+#pragma unroll
+          for (u32 q = 0; q < 4u; q++) if (q < nq) pos[q] = add_if_less2(pos[q], c2[t].x, c2[t].y, key[q]);
+        }
+      }
+    }
+  }
+  wave_sync();                                             /* every lane has read the keys: their column is written in order now */
+#pragma unroll
+  for (u32 q = 0; q < 4u; q++) if (64u * q + lane < len) { K[pos[q]] = key[q] >> 8; V[pos[q]] = v4[q]; }
+  wave_sync();
+  /* the sorted piece: sub-runs of equal keys */
+  const u32 dnew = d + lc + nsym;
+  u32 hq[4], val[4];
+  bool td[4];
+  u32 carry = 0u, ntied = 0u;
+#pragma unroll
+  for (u32 q = 0; q < 4u; q++) {
+    const u32 k = 64u * q + lane;
+    const bool ok = k < len;
+    const u64 sk = ok ? K[k] : 0ull;
+    const bool head = ok && (k == 0u || K[k - 1u] != sk);
+    const bool nexthead = !ok || k + 1u >= len || K[k + 1u] != sk;
+    u32 h = wave_incl_max(head ? k : 0u);
+    if (h < carry) h = carry;
+    carry = (u32)__builtin_amdgcn_readlane((int)h, 63);
+    hq[q] = h;
+    td[q] = ok && !(head && nexthead);
+    val[q] = ok ? V[k] : 0u;
+    ntied += (u32)__popcll(__ballot(td[q]));
+  }
+  u32 ob = ntied ? wave_reserve(outn, ntied) : 0u;
+#pragma unroll
+  for (u32 q = 0; q < 4u; q++) {
+    const u32 k = 64u * q + lane;
+    const u64 tm = __ballot(td[q]);
+    if (k < len) {
+      const u32 row = r0 + k, rank = r0 + hq[q];
+      if (!td[q] || late) {
+        sa[row] = val[q] | ((td[q] && hq[q] != k) ? TIE_FLAG : 0u);
+        if (!td[q]) bwt[row] = inv[SA_CODE(val[q])];
+        if (SA_IDX(val[q]) == 0u) M->bwt_idx = row;
+      }
+      if (td[q]) {
+        const u32 o = ob + (u32)__popcll(tm & lanes_below());
+        Ls.sout[o] = val[q]; Ls.gout[o] = rank; Ls.dout[o] = dnew;
+        if (R.build) deep_publish(R, SA_IDX(val[q]), rank, dnew);
+      }
+      if (R.live && (moved || hq[q] != 0u)) R.isa[SA_IDX(val[q])] = ISA_ENTRY_D(rank, rank0, R.tag, dnew);   /* final for this launch: its rank changed */
+    }
+    ob += (u32)__popcll(tm);
+  }
+  if (ntied) hmin = dnew < hmin ? dnew : hmin;
+  wave_sync();
+  return true;
+}
+
 /* A run of g >= 64 tied rows (list entries [p, p + g)): too long for a strip.  Its wave takes it apart symbol by symbol:
  * it finds how many further symbols ALL rows of the piece share (compared with the piece's first row, 16 bytes a step, up
  * to 64), then splits the piece on the first symbol they do not all share -- a counting sort on one byte whose only state
@@ -1971,6 +2096,7 @@ struct deep_lists { const u32 *sin, *gin, *din; u32 *sout, *gout, *dout; };
  * over the piece's keys in LDS -- halves the long runs' wave time (46.9 -> 26.3 ms per block) and costs 24 vector registers:
  * at five waves a SIMD the tie stages gain 2-4 % on text and lose 2 % on sources, at four they lose 8 %.  Taken out;
  * commit "k_bwt_deep: deep_mid_run" has it.)                                                                              */
+template <bool MID>
 __device__ void deep_big_run(deep_wave *W, u32 lane, u32 p, u32 g, deep_lists Ls, u32 *ping, u32 *pong, const u8 *T, u32 n,
                              u32 *sa, u8 *bwt, const u8 *inv, lbz_block_meta *M, u32 *outn, u32 &hmin, bool late, deep_ranks R)
 {
@@ -1990,6 +2116,7 @@ __device__ void deep_big_run(deep_wave *W, u32 lane, u32 p, u32 g, deep_lists Ls
     const u32 *src = (buf ? pong : ping) + p + off;
     u32 *dst = (buf ? ping : pong) + p + off;
     const u32 r0 = rank0 + off;                         /* the piece's rows are consecutive from here */
+    if (MID && len <= DEEP_MID && deep_mid_run(W, lane, src, len, d, r0, rank0, off != 0u, Ls, T, n, sa, bwt, inv, M, outn, hmin, late, R)) continue;
     const u32 idx0 = SA_IDX(src[0]);
     bool split = false;
 #ifdef DEEP_TICKS
@@ -2144,6 +2271,15 @@ __device__ void deep_big_run(deep_wave *W, u32 lane, u32 p, u32 g, deep_lists Ls
   }
 }
 
+/* (deep_body's hand-over rule, below; k_bwt_long decides the same.)  Bit 31 of `handover`: the launch's long runs have had a
+   launch of their own (k_bwt_long): this one passes over them. */
+__device__ __forceinline__ bool deep_handed_over(const lbz_block_meta *M, u32 n, u32 round, u32 tot, u32 handover)
+{
+  const u32 ho0 = handover & 0xFFFFu, ho1 = (handover >> 16) & 0x7FFFu;
+  return M->deep_skip || (u64)M->deep_long * 2ull > n || (ho0 && (u64)M->deep_tot[0] * 1000ull > (u64)n * ho0)
+         || (round == DEEP_HANDOVER && (u64)tot * 1000ull > (u64)n * ho1);
+}
+
 /* LIVE: the launch may step by ranks (launches behind DEEP_BUILD: k_bwt_deepr); the launches up to it order by the text alone
    (k_bwt_deep) and carry none of that code -- 20 vector registers less, a wave more per SIMD */
 template <bool LIVE>
@@ -2172,9 +2308,7 @@ __device__ __forceinline__ void deep_body(deep_lds &S, const u8 *Tbase, u8 *Bbas
      behind launch DEEP_HANDOVER, on a stream of their own, beside the later text launches of the round's other blocks
      (lbz_api.hip: launch_sort).  Only launches up to DEEP_HANDOVER flag: a later one would set the flag again on a block
      whose rank rounds may have finished by then. */
-  const u32 ho0 = handover & 0xFFFFu, ho1 = handover >> 16;
-  if (M->deep_skip || (u64)M->deep_long * 2ull > n || (ho0 && (u64)M->deep_tot[0] * 1000ull > (u64)n * ho0)
-      || (round == DEEP_HANDOVER && (u64)tot * 1000ull > (u64)n * ho1)) {
+  if (deep_handed_over(M, n, round, tot, handover)) {
     if (seg == 0u && threadIdx.x == 0u && round <= DEEP_HANDOVER) {
       atomicMax(&M->periodic, LBZ_TIES_EARLY); atomicMin(&M->deep_h0, M->deep_hmin[round]);
     }
@@ -2189,6 +2323,7 @@ __device__ __forceinline__ void deep_body(deep_lds &S, const u8 *Tbase, u8 *Bbas
   }
   const u32 m = M->seg_m[seg];
   if (m == 0u) return;
+  const bool longdone = (handover >> 31) != 0u;
   const u64 tk0 = wall_clock64();
   const u32 tid = threadIdx.x, lane = lane_id();
   const u32 lo = M->seg_lo[seg];
@@ -2207,7 +2342,7 @@ __device__ __forceinline__ void deep_body(deep_lds &S, const u8 *Tbase, u8 *Bbas
     const u32 ex = wg_excl_add(f, &tot, &S.sc);
     if (tot > 128u) { if (tid < 256u) S.inv[tid] = (u8)tid; }       /* bwt_setup's rule */
     else if (f) S.inv[ex] = (u8)tid;
-    if (tid == 0) { S.ticket = 0; S.outn = 0; S.h0min = 0xFFFFFFFFu; S.bad = 0; }
+    if (tid == 0) { S.ticket = 0; S.outn = longdone ? M->seg_long[seg] : 0u; S.h0min = 0xFFFFFFFFu; S.bad = 0; }   /* k_bwt_long's runs are in the next list already */
     __syncthreads();
   }
   deep_wave *W = &S.w[wave_id()];
@@ -2267,7 +2402,7 @@ __device__ __forceinline__ void deep_body(deep_lds &S, const u8 *Tbase, u8 *Bbas
           if (df) { len += (u32)__ffsll((long long)df) - 1u; break; }
           len += 64u;
         }
-        deep_big_run(W, lane, p, len, Ls, const_cast<u32 *>(sin), s.v0 + lo, T, n, s.sa, bwt, S.inv, M, &S.outn, hmin, late, R);
+        if (!longdone) deep_big_run<false>(W, lane, p, len, Ls, const_cast<u32 *>(sin), s.v0 + lo, T, n, s.sa, bwt, S.inv, M, &S.outn, hmin, late, R);
         p += len;
         DT_MARK(t9); DT_ADD(tkb, t0, t9);
         continue;
@@ -2473,6 +2608,114 @@ k_bwt_deepr(const u8 *Tbase, u8 *Bbase, lbz_block_meta *meta, lbz_layout L, u32 
 {
   __shared__ deep_lds S;
   deep_body<true>(S, Tbase, Bbase, meta, L, first, count, nblk, segs, ws, slot_bytes, ws_spill, spill_bytes, slabs, round, handover);
+}
+
+/* The long runs (64 rows and more) of text launch `round`, in a launch of their own IN FRONT of it (round 5; launch_sort: the
+ * launches up to DEEP_BUILD, where nine tenths of the long runs' rows are).  Same grid, same lists, same hand-over rule as
+ * k_bwt_deep: a wave walks its chunks of the segment's list 256 entries a trip, and what it finds between two run heads 64 or
+ * more entries apart goes through deep_big_run -- WITH the one-pass ordering of pieces of up to DEEP_MID rows (deep_mid_run),
+ * which costs 24 vector registers that the strips' kernel cannot spare (a wave less per SIMD there cost more than the pieces
+ * gained: DESIGN 3.2, 4) and this kernel can.  The runs it leaves tied are the first entries of the next list; their number
+ * is seg_long[seg], where k_bwt_deep (bit 31 of `handover` set) starts appending and whose long runs it passes over. */
+__global__ void __launch_bounds__(LBZ_WG, 4)
+k_bwt_long(const u8 *Tbase, u8 *Bbase, lbz_block_meta *meta, lbz_layout L, u32 first, u32 count, u32 nblk, u32 segs,
+           u8 *ws, u64 slot_bytes, u8 *ws_spill, u64 spill_bytes, const u32 *slabs, u32 round, u32 handover)
+{
+  __shared__ deep_lds S;
+  u32 bi, seg;
+  if (!seg_item(nblk, segs, &bi, &seg)) return;
+  const u32 blk = lbz_round_block(first, count, bi, slabs);
+  lbz_block_meta *M = &meta[blk];
+  const u32 n = M->n;
+  if (n < 2u || seg >= M->nseg) return;
+  const u32 tid = threadIdx.x, lane = lane_id();
+  if (tid == 0) M->seg_long[seg] = 0u;
+  const u32 tot = M->deep_tot[round];
+  if (tot == 0u || deep_handed_over(M, n, round, tot, handover)) return;
+  const u32 m = M->seg_m[seg];
+  if (m <= 64u) return;                                 /* (a run of 64 at the end of the list is a strip: k_bwt_deep's rule) */
+  const bwt_slot s = round_slot(ws, slot_bytes, ws_spill, spill_bytes, count, L, bi);
+  const u32 lo = M->seg_lo[seg];
+  const u32 cap = bi < count ? L.cap_a : L.cap_b;
+  const size_t off = lbz_elem_off(L, blk);
+  const u8 *T = Tbase + off;
+  u8 *bwt = Bbase + off;
+  u32 *colA[3] = { s.sufx + lo, s.grp + lo, s.pos + lo };
+  u32 *colB[3] = { s.v1 + lo, reinterpret_cast<u32 *>(s.k1) + lo, reinterpret_cast<u32 *>(s.k1) + cap + lo };
+  const u32 *sin = (round & 1u) ? colB[0] : colA[0], *gin = (round & 1u) ? colB[1] : colA[1], *din = (round & 1u) ? colB[2] : colA[2];
+  u32 *sout = (round & 1u) ? colA[0] : colB[0], *gout = (round & 1u) ? colA[1] : colB[1], *dout = (round & 1u) ? colA[2] : colB[2];
+  {
+    u32 nuse;
+    const u32 f = (tid < 256u && M->inuse[tid]) ? 1u : 0u;
+    const u32 ex = wg_excl_add(f, &nuse, &S.sc);
+    if (nuse > 128u) { if (tid < 256u) S.inv[tid] = (u8)tid; }      /* bwt_setup's rule */
+    else if (f) S.inv[ex] = (u8)tid;
+    if (tid == 0) { S.ticket = 0; S.outn = 0; S.h0min = 0xFFFFFFFFu; S.bad = 0; }
+    __syncthreads();
+  }
+  deep_wave *W = &S.w[wave_id()];
+  const deep_lists Ls = { sin, gin, din, sout, gout, dout };
+  deep_ranks R;
+  R.isa = s.isa; R.map = reinterpret_cast<u32 *>(s.k0);
+  R.tag = round + 1u; R.hcur = M->deep_hmin[round];
+  R.build = round == DEEP_BUILD; R.live = false;        /* (launch_sort: no launch behind DEEP_BUILD has this kernel in front of it) */
+  const bool late = round + 1u == DEEP_ROUNDS || round + 1u == DEEP_HANDOVER;
+  const u32 chunk = m < 16u * DEEP_CHUNK ? 64u : DEEP_CHUNK;        /* k_bwt_deep's chunks: a run is the chunk's in which it starts */
+  u32 hmin = 0xFFFFFFFFu;
+  for (;;) {
+    const u32 a = wave_claim(&S.ticket) * chunk;
+    if (a >= m) break;
+    const u32 e = a + chunk < m ? a + chunk : m;
+    u32 cur = 0;                                        /* the last run head seen: entry 0 is one */
+    if (a) {
+      cur = e;
+      for (u32 w0 = a; w0 < e; w0 += 64u) {
+        const u32 k = w0 + lane;
+        const u32 g1 = k < m ? gin[k] : 0u, g0 = k - 1u < m ? gin[k - 1u] : 0u;
+        const u64 hd = __ballot(k < e && g1 != g0);
+        if (hd) { cur = w0 + (u32)__ffsll((long long)hd) - 1u; break; }
+      }
+    }
+    u32 w0 = cur + 1u;
+    while (cur < e) {
+      /* heads among the next 256 entries, 64 a ballot.  Two heads inside one ballot are less than 64 apart: only the distance
+         from the last head seen to a ballot's first one can be a long run */
+      u64 hd4[4];
+      {
+        u32 g1[4], g0[4];
+#pragma unroll
+        for (u32 q = 0; q < 4u; q++) {
+          const u32 k = w0 + 64u * q + lane;
+          g1[q] = k < m ? gin[k] : 0u; g0[q] = k < m ? gin[k - 1u] : 0u;
+        }
+#pragma unroll
+        for (u32 q = 0; q < 4u; q++) hd4[q] = __ballot(w0 + 64u * q + lane < m && g1[q] != g0[q]);
+      }
+      bool done = false;
+#pragma unroll 1
+      for (u32 q = 0; q < 4u; q++) {
+        const u64 hd = q == 0u ? hd4[0] : (q == 1u ? hd4[1] : (q == 2u ? hd4[2] : hd4[3]));
+        const u32 b0 = w0 + 64u * q;
+        const bool endw = b0 + 64u >= m;                                   /* the list ends here: so does the run */
+        if (!hd && !endw) continue;
+        const u32 firsth = hd ? b0 + (u32)__builtin_ctzll(hd) : m, lasth = hd ? b0 + 63u - (u32)__builtin_clzll(hd) : m;
+        if (firsth - cur >= 64u && m - cur > 64u)
+          deep_big_run<true>(W, lane, cur, firsth - cur, Ls, const_cast<u32 *>(sin), s.v0 + lo, T, n, s.sa, bwt, S.inv, M, &S.outn, hmin, late, R);
+        cur = lasth;                                                       /* (a run that starts in the list's last 64 entries is not a long one) */
+        if (cur >= e || endw) { done = true; break; }
+      }
+      if (done) break;
+      w0 += 256u;
+    }
+  }
+  hmin = wave_min(hmin);
+  if (lane == 0u && hmin != 0xFFFFFFFFu) atomicMin(&S.h0min, hmin);
+  __syncthreads();
+  if (tid == 0) {
+    M->seg_long[seg] = S.outn;
+    if (S.outn) atomicMin(&M->deep_hmin[round + 1u], S.h0min);
+    if (round + 1u == DEEP_ROUNDS && S.outn) atomicMin(&M->deep_h0, S.h0min);
+  }
 }
 
 /* ---- kernels 3: the rank rounds (fall-back): prefix doubling, ONE LAUNCH PER ROUND ----

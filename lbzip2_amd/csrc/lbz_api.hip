@@ -350,12 +350,19 @@ static void launch_sort(lbzamd_ctx *c, hipStream_t q, u32 first, u32 count, u32 
     const u32 handover = (ho0 & 0xFFFFu) | (ho1 << 16);
     const dim3 g(lbz_seg_grid(nblk, segs));
     const u32 R = lbz_fix_rounds(c->L.M);
+    const char *el = getenv("LBZAMD_LONG_ROUNDS");         /* (tuning) text launches whose long runs get a launch of their own */
+    u32 long_rounds = el ? (u32)atoi(el) : LBZ_LONG_ROUNDS;
+    if (long_rounds > LBZ_DEEP_BUILD + 1u) long_rounds = LBZ_DEEP_BUILD + 1u;
     auto text_rounds = [&](u32 from, u32 to) {
       for (u32 r = from; r < to; r++)
-        if (r <= LBZ_DEEP_BUILD)
+        if (r <= LBZ_DEEP_BUILD) {
+          if (r < long_rounds)
+            hipLaunchKernelGGL(k_bwt_long, g, dim3(LBZ_BWT_WG), 0, q, (const u8 *)c->T, c->B, c->meta, c->L,
+                               first, count, nblk, segs, ws, (u64)c->slot_bytes, wsp, (u64)c->spill_bytes, lst, r, handover);
           hipLaunchKernelGGL(k_bwt_deep, g, dim3(LBZ_BWT_WG), deep_pad, q, (const u8 *)c->T, c->B, c->meta, c->L,
-                             first, count, nblk, segs, ws, (u64)c->slot_bytes, wsp, (u64)c->spill_bytes, lst, r, handover);
-        else                                             /* the launches that may step by ranks */
+                             first, count, nblk, segs, ws, (u64)c->slot_bytes, wsp, (u64)c->spill_bytes, lst, r,
+                             handover | (r < long_rounds ? 0x80000000u : 0u));
+        } else                                             /* the launches that may step by ranks */
           hipLaunchKernelGGL(k_bwt_deepr, g, dim3(LBZ_BWT_WG), deep_pad, q, (const u8 *)c->T, c->B, c->meta, c->L,
                              first, count, nblk, segs, ws, (u64)c->slot_bytes, wsp, (u64)c->spill_bytes, lst, r, handover);
     };

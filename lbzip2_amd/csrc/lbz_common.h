@@ -87,6 +87,7 @@ typedef struct lbz_block_meta {
   uint32_t deep_hmin[LBZ_DEEP_ROUNDS + 1];  /* ... and the least depth any of them is known to share */
   uint32_t seg_lo[LBZ_BWT_MAXSEGS + 1];
   uint32_t seg_m[LBZ_BWT_MAXSEGS];         /* length of the segment's list of tied rows (k_bwt_batch -> k_bwt_deep rounds; k_bwt_fix* build their own) */
+  uint32_t seg_long[LBZ_BWT_MAXSEGS];      /* ... of which k_bwt_long wrote this many (the runs the launch's long runs left tied): k_bwt_deep appends behind them */
   uint32_t ticks[8];   /* wall_clock64 ticks of k_bwt_part / k_bwt_batch phases (diagnostic) */
   uint32_t fticks[16];  /* wall_clock64 ticks of k_bwt_fix phases (diagnostic) */
   uint8_t  inuse[256]; /* used-byte map (encode.c:63) */

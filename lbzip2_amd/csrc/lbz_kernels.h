@@ -79,6 +79,13 @@ __global__ void k_bwt_deep(const u8 *Tbase, u8 *Bbase, lbz_block_meta *meta, lbz
                            u32 count, u32 nblk, u32 segs, u8 *ws, u64 slot_bytes, u8 *ws_spill, u64 spill_bytes, const u32 *slabs, u32 round, u32 handover);
 __global__ void k_bwt_deepr(const u8 *Tbase, u8 *Bbase, lbz_block_meta *meta, lbz_layout L, u32 first,
                            u32 count, u32 nblk, u32 segs, u8 *ws, u64 slot_bytes, u8 *ws_spill, u64 spill_bytes, const u32 *slabs, u32 round, u32 handover);
+/* the long runs (64 rows and more) of text launch `round`, in front of it (launches < LBZ_LONG_ROUNDS): k_bwt_deep is then launched with bit 31
+   of `handover` set and passes over them */
+__global__ void k_bwt_long(const u8 *Tbase, u8 *Bbase, lbz_block_meta *meta, lbz_layout L, u32 first,
+                           u32 count, u32 nblk, u32 segs, u8 *ws, u64 slot_bytes, u8 *ws_spill, u64 spill_bytes, const u32 *slabs, u32 round, u32 handover);
+#ifndef LBZ_LONG_ROUNDS
+#define LBZ_LONG_ROUNDS 2u       /* at most LBZ_DEEP_BUILD + 1: k_bwt_long does not step by ranks */
+#endif
 /* lbz_block_meta.periodic while the sorter runs: ties left for the rank rounds -- flagged before the third text launch (their
    chain of launches starts there, beside the later text launches), or by the last one (a second chain behind both) */
 #define LBZ_DEEP_BUILD 1u        /* the text launch whose leftovers get rank entries: the launches behind it (k_bwt_deepr) may step by ranks */
