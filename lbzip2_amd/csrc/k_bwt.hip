@@ -1445,6 +1445,7 @@ k_bwt_hist(const u8 *Tbase, lbz_block_meta *meta, lbz_layout L, u32 first, u32 c
   if (j == 0u && tid == 0) {                  /* the segment workgroups add to these */
     M->periodic = 0; M->rounds = 0; M->sort_elems = 0; M->deep_rows = 0; M->nseg = 0; M->deep_h0 = 0xFFFFFFFFu; M->deep_skip = 0; M->deep_long = 0;
     for (u32 i = 0; i <= LBZ_DEEP_ROUNDS; i++) { M->deep_tot[i] = 0; M->deep_hmin[i] = 0xFFFFFFFFu; }
+    for (u32 i = 0; i < LBZ_BWT_MAXSEGS; i++) M->seg_long[i] = 0;
     M->msd_bits = MSD_BITS;
     for (u32 i = 0; i < 8u; i++) M->ticks[i] = 0;
     for (u32 i = 0; i < 16u; i++) M->fticks[i] = 0;
@@ -1583,6 +1584,7 @@ k_bwt_part(const u8 *Tbase, lbz_block_meta *meta, lbz_layout L, u32 first, u32 c
   if (tid == 0) {                             /* the sorter's part of the block record: the segment workgroups add to it */
     M->periodic = 0; M->rounds = 0; M->sort_elems = 0; M->deep_rows = 0; M->nseg = 0; M->deep_h0 = 0xFFFFFFFFu; M->deep_skip = 0; M->deep_long = 0;
     for (u32 i = 0; i <= LBZ_DEEP_ROUNDS; i++) { M->deep_tot[i] = 0; M->deep_hmin[i] = 0xFFFFFFFFu; }
+    for (u32 i = 0; i < LBZ_BWT_MAXSEGS; i++) M->seg_long[i] = 0;
     M->msd_bits = MSD_BITS;
     for (u32 i = 0; i < 8u; i++) M->ticks[i] = 0;
     for (u32 i = 0; i < 16u; i++) M->fticks[i] = 0;
@@ -2102,6 +2104,7 @@ __device__ void deep_big_run(deep_wave *W, u32 lane, u32 p, u32 g, deep_lists Ls
 {
   const u32 rank0 = Ls.gin[p];
   const u32 d0 = Ls.din[p];
+  wave_sync();                                          /* (every lane has read the empty stack of the run before: k_bwt_long calls this twice with no collective between) */
   if (lane == 0u) { W->st_off[0] = 0u; W->st_len[0] = g; W->st_dep[0] = d0; W->st_buf[0] = 0u; W->sp = 1u; }
   if (R.live)                                                     /* as for the strips: rank and depth at the start of the launch */
     for (u32 k = lane; k < g; k += 64u) R.isa[SA_IDX(ping[p + k])] = ISA_ENTRY_D(rank0, rank0, 0u, d0);
@@ -2583,6 +2586,7 @@ __device__ __forceinline__ void deep_body(deep_lds &S, const u8 *Tbase, u8 *Bbas
   __syncthreads();
   if (tid == 0) {
     M->seg_m[seg] = S.outn;
+    if (longdone) M->seg_long[seg] = 0u;              /* (for the k_bwt_long launch in front of the next k_bwt_deep) */
     if (S.bad) M->err = 7u;
     if (S.outn) { atomicAdd(&M->deep_tot[round + 1u], S.outn); atomicMin(&M->deep_hmin[round + 1u], S.h0min); }
     if (round + 1u == DEEP_ROUNDS && S.outn) { atomicMax(&M->periodic, LBZ_TIES_LATE); atomicMin(&M->deep_h0, S.h0min); }
@@ -2611,29 +2615,38 @@ k_bwt_deepr(const u8 *Tbase, u8 *Bbase, lbz_block_meta *meta, lbz_layout L, u32 
 }
 
 /* The long runs (64 rows and more) of text launch `round`, in a launch of their own IN FRONT of it (round 5; launch_sort: the
- * launches up to DEEP_BUILD, where nine tenths of the long runs' rows are).  Same grid, same lists, same hand-over rule as
- * k_bwt_deep: a wave walks its chunks of the segment's list 256 entries a trip, and what it finds between two run heads 64 or
- * more entries apart goes through deep_big_run -- WITH the one-pass ordering of pieces of up to DEEP_MID rows (deep_mid_run),
- * which costs 24 vector registers that the strips' kernel cannot spare (a wave less per SIMD there cost more than the pieces
- * gained: DESIGN 3.2, 4) and this kernel can.  The runs it leaves tied are the first entries of the next list; their number
- * is seg_long[seg], where k_bwt_deep (bit 31 of `handover` set) starts appending and whose long runs it passes over. */
-__global__ void __launch_bounds__(LBZ_WG, 4)
+ * launches up to DEEP_BUILD, where nine tenths of the long runs' rows are).  Same lists, same hand-over rule as k_bwt_deep; what
+ * lies between two run heads 64 or more entries apart goes through deep_big_run -- WITH the one-pass ordering of pieces of up
+ * to DEEP_MID rows (deep_mid_run), which costs 24 vector registers that the strips' kernel cannot spare (a wave less per SIMD
+ * there cost more than the pieces gained: DESIGN 3.2, 4) and this kernel can.
+ * A long run is one wave's job, a chain of round trips (" of the ", four thousand rows: thirty pieces one after the other), and
+ * next to the strips of its workgroup's other waves that did not matter.  Alone it does: with k_bwt_deep's workgroups of four
+ * waves three of them held their places idle while the fourth worked (measured: a quarter of the wave slots busy, the launch
+ * longer than what it took out of k_bwt_deep).  So a workgroup here is ONE wave: LONG_SUB of them per segment, each walks its
+ * share of the segment's list (256 entries a trip) and is gone when its own runs are done.
+ * The runs they leave tied are the first entries of the next list; they count them in seg_long[seg] (zero when the launch
+ * begins: k_bwt_part / the k_bwt_deep launch before), where k_bwt_deep (bit 31 of `handover` set) starts appending and whose
+ * long runs it passes over. */
+struct long_lds { u8 inv[256]; deep_wave w; };
+__global__ void __launch_bounds__(64, 4)
 k_bwt_long(const u8 *Tbase, u8 *Bbase, lbz_block_meta *meta, lbz_layout L, u32 first, u32 count, u32 nblk, u32 segs,
            u8 *ws, u64 slot_bytes, u8 *ws_spill, u64 spill_bytes, const u32 *slabs, u32 round, u32 handover)
 {
-  __shared__ deep_lds S;
-  u32 bi, seg;
-  if (!seg_item(nblk, segs, &bi, &seg)) return;
+  __shared__ long_lds S;
+  u32 bi, vseg;
+  if (!seg_item(nblk, segs * LBZ_LONG_SUB, &bi, &vseg)) return;
+  const u32 seg = vseg / LBZ_LONG_SUB, sub = vseg % LBZ_LONG_SUB;
   const u32 blk = lbz_round_block(first, count, bi, slabs);
   lbz_block_meta *M = &meta[blk];
   const u32 n = M->n;
   if (n < 2u || seg >= M->nseg) return;
-  const u32 tid = threadIdx.x, lane = lane_id();
-  if (tid == 0) M->seg_long[seg] = 0u;
+  const u32 lane = lane_id();
   const u32 tot = M->deep_tot[round];
   if (tot == 0u || deep_handed_over(M, n, round, tot, handover)) return;
   const u32 m = M->seg_m[seg];
   if (m <= 64u) return;                                 /* (a run of 64 at the end of the list is a strip: k_bwt_deep's rule) */
+  const u32 a = (u32)((u64)m * sub / LBZ_LONG_SUB), e = (u32)((u64)m * (sub + 1u) / LBZ_LONG_SUB);   /* the runs that START in [a, e) are this wave's */
+  if (a >= e) return;
   const bwt_slot s = round_slot(ws, slot_bytes, ws_spill, spill_bytes, count, L, bi);
   const u32 lo = M->seg_lo[seg];
   const u32 cap = bi < count ? L.cap_a : L.cap_b;
@@ -2644,77 +2657,75 @@ k_bwt_long(const u8 *Tbase, u8 *Bbase, lbz_block_meta *meta, lbz_layout L, u32 f
   u32 *colB[3] = { s.v1 + lo, reinterpret_cast<u32 *>(s.k1) + lo, reinterpret_cast<u32 *>(s.k1) + cap + lo };
   const u32 *sin = (round & 1u) ? colB[0] : colA[0], *gin = (round & 1u) ? colB[1] : colA[1], *din = (round & 1u) ? colB[2] : colA[2];
   u32 *sout = (round & 1u) ? colA[0] : colB[0], *gout = (round & 1u) ? colA[1] : colB[1], *dout = (round & 1u) ? colA[2] : colB[2];
-  {
-    u32 nuse;
-    const u32 f = (tid < 256u && M->inuse[tid]) ? 1u : 0u;
-    const u32 ex = wg_excl_add(f, &nuse, &S.sc);
-    if (nuse > 128u) { if (tid < 256u) S.inv[tid] = (u8)tid; }      /* bwt_setup's rule */
-    else if (f) S.inv[ex] = (u8)tid;
-    if (tid == 0) { S.ticket = 0; S.outn = 0; S.h0min = 0xFFFFFFFFu; S.bad = 0; }
-    __syncthreads();
+  u32 cur = 0;                                          /* the last run head seen: entry 0 is one */
+  if (a) {
+    cur = e;
+    for (u32 w0 = a; w0 < e; w0 += 64u) {
+      const u32 k = w0 + lane;
+      const u32 g1 = k < m ? gin[k] : 0u, g0 = k - 1u < m ? gin[k - 1u] : 0u;
+      const u64 hd = __ballot(k < e && g1 != g0);
+      if (hd) { cur = w0 + (u32)__ffsll((long long)hd) - 1u; break; }
+    }
   }
-  deep_wave *W = &S.w[wave_id()];
+  bool ready = false;                                   /* the symbol table (for the BWT bytes of rows that come out alone) is made when the first long run turns up */
+  deep_wave *W = &S.w;
   const deep_lists Ls = { sin, gin, din, sout, gout, dout };
   deep_ranks R;
   R.isa = s.isa; R.map = reinterpret_cast<u32 *>(s.k0);
   R.tag = round + 1u; R.hcur = M->deep_hmin[round];
   R.build = round == DEEP_BUILD; R.live = false;        /* (launch_sort: no launch behind DEEP_BUILD has this kernel in front of it) */
   const bool late = round + 1u == DEEP_ROUNDS || round + 1u == DEEP_HANDOVER;
-  const u32 chunk = m < 16u * DEEP_CHUNK ? 64u : DEEP_CHUNK;        /* k_bwt_deep's chunks: a run is the chunk's in which it starts */
   u32 hmin = 0xFFFFFFFFu;
-  for (;;) {
-    const u32 a = wave_claim(&S.ticket) * chunk;
-    if (a >= m) break;
-    const u32 e = a + chunk < m ? a + chunk : m;
-    u32 cur = 0;                                        /* the last run head seen: entry 0 is one */
-    if (a) {
-      cur = e;
-      for (u32 w0 = a; w0 < e; w0 += 64u) {
-        const u32 k = w0 + lane;
-        const u32 g1 = k < m ? gin[k] : 0u, g0 = k - 1u < m ? gin[k - 1u] : 0u;
-        const u64 hd = __ballot(k < e && g1 != g0);
-        if (hd) { cur = w0 + (u32)__ffsll((long long)hd) - 1u; break; }
-      }
-    }
-    u32 w0 = cur + 1u;
-    while (cur < e) {
-      /* heads among the next 256 entries, 64 a ballot.  Two heads inside one ballot are less than 64 apart: only the distance
-         from the last head seen to a ballot's first one can be a long run */
-      u64 hd4[4];
-      {
-        u32 g1[4], g0[4];
+  u32 w0 = cur + 1u;
+  while (cur < e) {
+    /* heads among the next 256 entries, 64 a ballot.  Two heads inside one ballot are less than 64 apart: only the distance
+       from the last head seen to a ballot's first one can be a long run */
+    u64 hd4[4];
+    {
+      u32 g1[4], g0[4];
 #pragma unroll
-        for (u32 q = 0; q < 4u; q++) {
-          const u32 k = w0 + 64u * q + lane;
-          g1[q] = k < m ? gin[k] : 0u; g0[q] = k < m ? gin[k - 1u] : 0u;
-        }
-#pragma unroll
-        for (u32 q = 0; q < 4u; q++) hd4[q] = __ballot(w0 + 64u * q + lane < m && g1[q] != g0[q]);
-      }
-      bool done = false;
-#pragma unroll 1
       for (u32 q = 0; q < 4u; q++) {
-        const u64 hd = q == 0u ? hd4[0] : (q == 1u ? hd4[1] : (q == 2u ? hd4[2] : hd4[3]));
-        const u32 b0 = w0 + 64u * q;
-        const bool endw = b0 + 64u >= m;                                   /* the list ends here: so does the run */
-        if (!hd && !endw) continue;
-        const u32 firsth = hd ? b0 + (u32)__builtin_ctzll(hd) : m, lasth = hd ? b0 + 63u - (u32)__builtin_clzll(hd) : m;
-        if (firsth - cur >= 64u && m - cur > 64u)
-          deep_big_run<true>(W, lane, cur, firsth - cur, Ls, const_cast<u32 *>(sin), s.v0 + lo, T, n, s.sa, bwt, S.inv, M, &S.outn, hmin, late, R);
-        cur = lasth;                                                       /* (a run that starts in the list's last 64 entries is not a long one) */
-        if (cur >= e || endw) { done = true; break; }
+        const u32 k = w0 + 64u * q + lane;
+        g1[q] = k < m ? gin[k] : 0u; g0[q] = k < m ? gin[k - 1u] : 0u;
       }
-      if (done) break;
-      w0 += 256u;
+#pragma unroll
+      for (u32 q = 0; q < 4u; q++) hd4[q] = __ballot(w0 + 64u * q + lane < m && g1[q] != g0[q]);
     }
+    bool done = false;
+#pragma unroll 1
+    for (u32 q = 0; q < 4u; q++) {
+      const u64 hd = q == 0u ? hd4[0] : (q == 1u ? hd4[1] : (q == 2u ? hd4[2] : hd4[3]));
+      const u32 b0 = w0 + 64u * q;
+      const bool endw = b0 + 64u >= m;                                     /* the list ends here: so does the run */
+      if (!hd && !endw) continue;
+      const u32 firsth = hd ? b0 + (u32)__builtin_ctzll(hd) : m, lasth = hd ? b0 + 63u - (u32)__builtin_clzll(hd) : m;
+      if (firsth - cur >= 64u && m - cur > 64u) {
+        if (!ready) {
+          u32 f[4], nuse = 0, ex = 0;
+#pragma unroll
+          for (u32 t = 0; t < 4u; t++) { f[t] = M->inuse[64u * t + lane] ? 1u : 0u; nuse += (u32)__popcll(__ballot(f[t] != 0u)); }
+#pragma unroll
+          for (u32 t = 0; t < 4u; t++) {
+            const u64 bm = __ballot(f[t] != 0u);
+            if (nuse > 128u) S.inv[64u * t + lane] = (u8)(64u * t + lane);           /* bwt_setup's rule */
+            else if (f[t]) S.inv[ex + (u32)__popcll(bm & lanes_below())] = (u8)(64u * t + lane);
+            ex += (u32)__popcll(bm);
+          }
+          wave_sync();
+          ready = true;
+        }
+        deep_big_run<true>(W, lane, cur, firsth - cur, Ls, const_cast<u32 *>(sin), s.v0 + lo, T, n, s.sa, bwt, S.inv, M, &M->seg_long[seg], hmin, late, R);
+      }
+      cur = lasth;                                                         /* (a run that starts in the list's last 64 entries is not a long one) */
+      if (cur >= e || endw) { done = true; break; }
+    }
+    if (done) break;
+    w0 += 256u;
   }
   hmin = wave_min(hmin);
-  if (lane == 0u && hmin != 0xFFFFFFFFu) atomicMin(&S.h0min, hmin);
-  __syncthreads();
-  if (tid == 0) {
-    M->seg_long[seg] = S.outn;
-    if (S.outn) atomicMin(&M->deep_hmin[round + 1u], S.h0min);
-    if (round + 1u == DEEP_ROUNDS && S.outn) atomicMin(&M->deep_h0, S.h0min);
+  if (lane == 0u && hmin != 0xFFFFFFFFu) {
+    atomicMin(&M->deep_hmin[round + 1u], hmin);
+    if (round + 1u == DEEP_ROUNDS) atomicMin(&M->deep_h0, hmin);
   }
 }
 

@@ -357,7 +357,7 @@ static void launch_sort(lbzamd_ctx *c, hipStream_t q, u32 first, u32 count, u32 
       for (u32 r = from; r < to; r++)
         if (r <= LBZ_DEEP_BUILD) {
           if (r < long_rounds)
-            hipLaunchKernelGGL(k_bwt_long, g, dim3(LBZ_BWT_WG), 0, q, (const u8 *)c->T, c->B, c->meta, c->L,
+            hipLaunchKernelGGL(k_bwt_long, dim3(lbz_seg_grid(nblk, segs * LBZ_LONG_SUB)), dim3(64), 0, q, (const u8 *)c->T, c->B, c->meta, c->L,
                                first, count, nblk, segs, ws, (u64)c->slot_bytes, wsp, (u64)c->spill_bytes, lst, r, handover);
           hipLaunchKernelGGL(k_bwt_deep, g, dim3(LBZ_BWT_WG), deep_pad, q, (const u8 *)c->T, c->B, c->meta, c->L,
                              first, count, nblk, segs, ws, (u64)c->slot_bytes, wsp, (u64)c->spill_bytes, lst, r,

@@ -83,6 +83,9 @@ __global__ void k_bwt_deepr(const u8 *Tbase, u8 *Bbase, lbz_block_meta *meta, lb
    of `handover` set and passes over them */
 __global__ void k_bwt_long(const u8 *Tbase, u8 *Bbase, lbz_block_meta *meta, lbz_layout L, u32 first,
                            u32 count, u32 nblk, u32 segs, u8 *ws, u64 slot_bytes, u8 *ws_spill, u64 spill_bytes, const u32 *slabs, u32 round, u32 handover);
+#ifndef LBZ_LONG_SUB
+#define LBZ_LONG_SUB 8u          /* one-wave workgroups per segment in k_bwt_long: grid = lbz_seg_grid(nblk, segs * LBZ_LONG_SUB), 64 threads */
+#endif
 #ifndef LBZ_LONG_ROUNDS
 #define LBZ_LONG_ROUNDS 2u       /* at most LBZ_DEEP_BUILD + 1: k_bwt_long does not step by ranks */
 #endif

@@ -47,6 +47,7 @@ struct Wave {
   unsigned arrived;       /* lanes waiting at the current wave collective */
   unsigned live;          /* lanes not yet DONE */
   unsigned gen;           /* number of completed wave collectives */
+  int site[64]; const char *sitefile[64];          /* LBZ_EMU_CHECK_SITES: where each lane entered the current collective */
 };
 
 struct Fiber {
@@ -115,14 +116,44 @@ void sync_block()
 }
 
 /* all live lanes of the wave rendezvous; returns after everyone has arrived */
-static void wave_rendezvous()
+/* LBZ_EMU_CHECK_SITES=1: the lanes of a wave must enter a collective from the same place in the code -- lanes that come from
+   different places have diverged (a collective under a lane-dependent condition), and what they exchange is not what a GPU
+   wave would see */
+static const int check_sites = getenv("LBZ_EMU_CHECK_SITES") ? atoi(getenv("LBZ_EMU_CHECK_SITES")) : 0;   /* 1: report each pair of places once, 2: abort */
+static bool site_pair_is_new(const char *fa, int la, const char *fb, int lb)
+{
+  static std::mutex mu;
+  static std::vector<std::pair<std::pair<const char *, int>, std::pair<const char *, int>>> seen;
+  std::lock_guard<std::mutex> g(mu);
+  for (auto &p : seen) if (p.first.first == fa && p.first.second == la && p.second.first == fb && p.second.second == lb) return false;
+  seen.push_back({{fa, la}, {fb, lb}});
+  return true;
+}
+thread_local int site_ = 0;
+thread_local const char *sitefile_ = "";
+static void wave_rendezvous_at(int site);
+static void wave_rendezvous() { wave_rendezvous_at(site_); }
+static void wave_rendezvous_at(int site)
 {
   BlockCtx *c = ctx;
   unsigned t = c->cur;
   Wave &w = c->wave[t >> 6];
   unsigned my_gen = w.gen;
+  w.site[t & 63] = site; w.sitefile[t & 63] = sitefile_;
   w.arrived++;
-  if (w.arrived == w.live) { w.arrived = 0; w.gen++; return; }
+  if (w.arrived == w.live) {
+    if (check_sites)
+      for (unsigned l = 0; l < 64; l++) {
+        const unsigned tt = (t & ~63u) + l;
+        if (tt < c->nthreads && c->fib[tt].state != DONE && w.site[l] != site && site_pair_is_new(sitefile_, site, w.sitefile[l], w.site[l])) {
+          fprintf(stderr, "emu: lanes %u and %u of block %u entered a wave collective from different places (%s:%d and %s:%d)\n",
+                  t & 63, l, blockIdx_.x, sitefile_, site, w.sitefile[l], w.site[l]);
+          if (check_sites > 1) abort();
+          break;
+        }
+      }
+    w.arrived = 0; w.gen++; return;
+  }
   c->fib[t].state = WAIT_WAVE;
   c->fib[t].wave_gen_seen = my_gen;
   yield_to_sched();

@@ -46,6 +46,8 @@ extern thread_local Idx threadIdx_, blockIdx_, blockDim_, gridDim_;
 void launch(const std::function<void()> &body, dim3 grid, dim3 block, size_t shmem);
 void sync_block();
 void sync_wave();
+extern thread_local const char *sitefile_;
+extern thread_local int site_;   /* LBZ_EMU_CHECK_SITES: source line of the collective the fiber is about to enter */
 unsigned long long wave_exchange(unsigned long long v, int src_lane);   /* value of src_lane (or own if dead) */
 unsigned long long wave_ballot(int pred);
 }
@@ -63,7 +65,7 @@ typedef struct ihipEvent_t *hipEvent_t;
 
 /* ---- synchronisation & wave collectives ---- */
 static inline void __syncthreads() { emu::sync_block(); }
-static inline void __builtin_amdgcn_wave_barrier() { emu::sync_wave(); }
+static inline void __builtin_amdgcn_wave_barrier(int line = __builtin_LINE(), const char *file = __builtin_FILE()) { emu::site_ = line; emu::sitefile_ = file; emu::sync_wave(); }
 static inline void __builtin_amdgcn_s_barrier() { emu::sync_block(); }
 static inline void __builtin_amdgcn_s_waitcnt(int) {}
 static inline void __threadfence() { std::atomic_thread_fence(std::memory_order_seq_cst); }
@@ -73,9 +75,9 @@ static inline void __builtin_amdgcn_s_sleep(int) { usleep(50); }   /* a spinning
 static inline unsigned long long wall_clock64() { return 0; }
 static inline unsigned long long clock64() { return 0; }
 
-static inline unsigned long long __ballot(int pred) { return emu::wave_ballot(pred); }
-static inline int __any(int pred) { return emu::wave_ballot(pred) != 0; }
-static inline int __all(int pred) { return emu::wave_ballot(!pred) == 0; }
+static inline unsigned long long __ballot(int pred, int line = __builtin_LINE(), const char *file = __builtin_FILE()) { emu::site_ = line; emu::sitefile_ = file; return emu::wave_ballot(pred); }
+static inline int __any(int pred, int line = __builtin_LINE(), const char *file = __builtin_FILE()) { emu::site_ = line; emu::sitefile_ = file; return emu::wave_ballot(pred) != 0; }
+static inline int __all(int pred, int line = __builtin_LINE(), const char *file = __builtin_FILE()) { emu::site_ = line; emu::sitefile_ = file; return emu::wave_ballot(!pred) == 0; }
 
 template <class T> static inline T emu_xchg(T v, int src)
 {
@@ -87,36 +89,42 @@ template <class T> static inline T emu_xchg(T v, int src)
   memcpy(&r, &raw, sizeof(T));
   return r;
 }
-template <class T> static inline T __shfl(T v, int src, int width = 64)
+template <class T> static inline T __shfl(T v, int src, int width = 64, int line = __builtin_LINE(), const char *file = __builtin_FILE())
 {
+  emu::site_ = line; emu::sitefile_ = file;
   int lane = threadIdx.x & 63;
   int base = lane & ~(width - 1);
   return emu_xchg(v, base + (src & (width - 1)));
 }
-template <class T> static inline T __shfl_up(T v, unsigned d, int width = 64)
+template <class T> static inline T __shfl_up(T v, unsigned d, int width = 64, int line = __builtin_LINE(), const char *file = __builtin_FILE())
 {
+  emu::site_ = line; emu::sitefile_ = file;
   int lane = threadIdx.x & 63;
   int s = lane - (int)d;
   return emu_xchg(v, (s < (lane & ~(width - 1))) ? lane : s);
 }
-template <class T> static inline T __shfl_down(T v, unsigned d, int width = 64)
+template <class T> static inline T __shfl_down(T v, unsigned d, int width = 64, int line = __builtin_LINE(), const char *file = __builtin_FILE())
 {
+  emu::site_ = line; emu::sitefile_ = file;
   int lane = threadIdx.x & 63;
   int s = lane + (int)d;
   return emu_xchg(v, (s > (lane | (width - 1))) ? lane : s);
 }
-template <class T> static inline T __shfl_xor(T v, int m, int width = 64)
+template <class T> static inline T __shfl_xor(T v, int m, int width = 64, int line = __builtin_LINE(), const char *file = __builtin_FILE())
 {
+  emu::site_ = line; emu::sitefile_ = file;
   int lane = threadIdx.x & 63;
   (void)width;
   return emu_xchg(v, lane ^ m);
 }
-static inline int __builtin_amdgcn_readfirstlane(int v)
+static inline int __builtin_amdgcn_readfirstlane(int v, int line = __builtin_LINE(), const char *file = __builtin_FILE())
 {
+  emu::site_ = line; emu::sitefile_ = file;
   unsigned long long live = emu::wave_ballot(1);
+  emu::site_ = line; emu::sitefile_ = file;        /* (other fibers have run since) */
   return emu_xchg(v, __builtin_ctzll(live));
 }
-static inline int __builtin_amdgcn_readlane(int v, int lane) { return emu_xchg(v, lane); }
+static inline int __builtin_amdgcn_readlane(int v, int lane, int line = __builtin_LINE(), const char *file = __builtin_FILE()) { emu::site_ = line; emu::sitefile_ = file; return emu_xchg(v, lane); }
 static inline unsigned __builtin_amdgcn_mbcnt_lo(unsigned m, unsigned acc)
 { unsigned lane = threadIdx.x & 63; return acc + __builtin_popcount(m & (lane >= 32 ? 0xFFFFFFFFu : ((1u << lane) - 1))); }
 static inline unsigned __builtin_amdgcn_mbcnt_hi(unsigned m, unsigned acc)
