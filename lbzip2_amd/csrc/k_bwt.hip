@@ -2096,8 +2096,8 @@ __device__ __forceinline__ bool deep_mid_run(deep_wave *W, u32 lane, const u32 *
  * each of a piece's four phases whatever its size -- profiles/r05_deep_ticks.txt.  Ordering pieces of up to 256 rows in one
  * pass instead -- 16 bytes a row fetched once, a 56-bit key of the seven symbols behind the shared ones, all-pairs count
  * over the piece's keys in LDS -- halves the long runs' wave time (46.9 -> 26.3 ms per block) and costs 24 vector registers:
- * at five waves a SIMD the tie stages gain 2-4 % on text and lose 2 % on sources, at four they lose 8 %.  Taken out;
- * commit "k_bwt_deep: deep_mid_run" has it.)                                                                              */
+ * at five waves a SIMD the tie stages gain 2-4 % on text and lose 2 % on sources, at four they lose 8 %.  So k_bwt_deep
+ * runs this without it (MID = false); k_bwt_long, the long runs in a launch of their own, with it.)                          */
 template <bool MID>
 __device__ void deep_big_run(deep_wave *W, u32 lane, u32 p, u32 g, deep_lists Ls, u32 *ping, u32 *pong, const u8 *T, u32 n,
                              u32 *sa, u8 *bwt, const u8 *inv, lbz_block_meta *M, u32 *outn, u32 &hmin, bool late, deep_ranks R)
@@ -2626,7 +2626,10 @@ k_bwt_deepr(const u8 *Tbase, u8 *Bbase, lbz_block_meta *meta, lbz_layout L, u32 
  * share of the segment's list (256 entries a trip) and is gone when its own runs are done.
  * The runs they leave tied are the first entries of the next list; they count them in seg_long[seg] (zero when the launch
  * begins: k_bwt_part / the k_bwt_deep launch before), where k_bwt_deep (bit 31 of `handover` set) starts appending and whose
- * long runs it passes over. */
+ * long runs it passes over.
+ * Measured on the MI355X (profiles/r05_long_*.txt): this launch 26 ms a 1 GB pass, k_bwt_deep 20 ms shorter, the pass as fast
+ * with as without on text, a tar and sources -- a piece is latency, and here it has no strips to hide behind.  Off by default
+ * (LBZ_LONG_ROUNDS; LBZAMD_LONG_ROUNDS=2 turns it on; tests/test_emu_kernels.py and tests/test_gpu_parity.py run it). */
 struct long_lds { u8 inv[256]; deep_wave w; };
 __global__ void __launch_bounds__(64, 4)
 k_bwt_long(const u8 *Tbase, u8 *Bbase, lbz_block_meta *meta, lbz_layout L, u32 first, u32 count, u32 nblk, u32 segs,

@@ -87,7 +87,8 @@ __global__ void k_bwt_long(const u8 *Tbase, u8 *Bbase, lbz_block_meta *meta, lbz
 #define LBZ_LONG_SUB 8u          /* one-wave workgroups per segment in k_bwt_long: grid = lbz_seg_grid(nblk, segs * LBZ_LONG_SUB), 64 threads */
 #endif
 #ifndef LBZ_LONG_ROUNDS
-#define LBZ_LONG_ROUNDS 2u       /* at most LBZ_DEEP_BUILD + 1: k_bwt_long does not step by ranks */
+#define LBZ_LONG_ROUNDS 0u       /* text launches with a k_bwt_long launch in front (at most LBZ_DEEP_BUILD + 1: it does not step by ranks).  0: measured on the
+                                    MI355X the same throughput with and without (profiles/r05_long_*.txt); LBZAMD_LONG_ROUNDS=2 turns it on */
 #endif
 /* lbz_block_meta.periodic while the sorter runs: ties left for the rank rounds -- flagged before the third text launch (their
    chain of launches starts there, beside the later text launches), or by the last one (a second chain behind both) */

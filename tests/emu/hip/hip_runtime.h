@@ -8,6 +8,8 @@
  * run on a small pool of OS threads.  It models semantics (64-lane waves, LDS shared by
  * the workgroup, atomics), not performance, and is never part of the product: the
  * shipped library is built by hipcc for gfx950 only (lbzip2_amd/csrc/Makefile).
+ * LBZ_EMU_CHECK_SITES=1|2: the wrappers below hand the source line of every wave collective to the runtime, which
+ * reports (1) or aborts on (2) lanes of one wave that meet in a collective from different lines (emu_runtime.cpp).
  */
 #ifndef LBZ_EMU_HIP_RUNTIME_H
 #define LBZ_EMU_HIP_RUNTIME_H

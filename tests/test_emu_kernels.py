@@ -284,3 +284,29 @@ def test_long_runs_of_every_size(emu):
     assert len(data) > 60000
     _stages(emu, data[:99000], 1)
     _stages(emu, data[50000:50000 + 180000], 2)
+
+
+def test_long_runs_in_a_launch_of_their_own(emu, monkeypatch):
+    """LBZAMD_LONG_ROUNDS=1 / 2: the long runs of the first text launches go through k_bwt_long -- one-wave workgroups, eight per
+    segment, pieces of up to 256 rows ordered in one pass (deep_mid_run), the runs they leave tied in front of the next list --
+    and k_bwt_deep passes over them (lbz_api.hip: launch_sort; off by default).  Same stream as without, on inputs with long runs
+    of every size, two of them next to each other in a list (the stack hazard the emulator's call-site check found), rounds
+    of many blocks and of few."""
+    import random
+    rng = random.Random(12)
+    base = bytes(gen("wiki", 20000, 78))
+    out = bytearray()
+    for mult, plen in ((64, 12), (65, 13), (70, 29), (77, 9), (130, 16), (256, 23), (257, 15), (300, 120), (700, 8), (90, 200)):
+        at = rng.randrange(0, len(base) - plen)
+        passage = base[at:at + plen]
+        for k in range(mult):
+            out += passage + bytes([97 + k % 3]) * (1 + k % 2) + bytes([65 + (k * 5) % 23]) + bytes(gen("text", rng.choice([2, 5, 11]), 4000 + 7 * k + mult))
+    many = bytes(gen("wiki", 1_130_000, 6) + gen("text", 520_000, 8) + gen("rand", 400_000, 9))       # 21 slabs at -1
+    cases = ((bytes(out)[:99000], 1, 1, 1), (bytes(out), 2, 2, 2), (many, 1, 21, 21), (many, 1, 21, 4))
+    for data, level, max_slabs, nslots in cases:
+        want = L.orc_compress(data, level)
+        for rounds in ("1", "2"):
+            monkeypatch.setenv("LBZAMD_LONG_ROUNDS", rounds)
+            with emu.context(level, max_slabs, nslots) as ctx:
+                assert ctx.compress(data) == want, (len(data), level, nslots, rounds)
+    monkeypatch.delenv("LBZAMD_LONG_ROUNDS")

@@ -494,6 +494,21 @@ def test_round_schedule(lib, monkeypatch, streams, nslots, max_slabs):
             assert ctx.compress(data) == want
 
 
+@pytest.mark.parametrize("knob,value", [("LBZAMD_LONG_ROUNDS", "2"), ("LBZAMD_LONG_ROUNDS", "1"), ("LBZAMD_SPLIT_CHAIN", "1")])
+def test_opt_in_launch_shapes(lib, monkeypatch, knob, value):
+    """The sorter's launch shapes that are off by default (lbz_api.hip: launch_sort) -- the long runs of the first text launches
+    in a launch of their own (k_bwt_long), the rank rounds of the blocks handed over early on a stream of their own -- write
+    the reference's stream too: text (long runs in every block), sources and a tar of this image's files, rounds of 5 slabs."""
+    import bench
+    made = bench.real_tar(4_000_000)
+    data = bytes(gen("wiki", 9_000_000, 31)) + bytes(gen("lines", 2_000_000, 32)) + (bytes(made[0]) if made else b"")
+    want = cpu_reference(data, 9)[0]
+    monkeypatch.setenv(knob, value)
+    with lib.context(9, 17, 5) as ctx:
+        for _ in range(2):
+            assert ctx.compress(data) == want
+
+
 def test_fuzz_vs_oracle(lib):
     """Structured random inputs (tests/fuzz_gpu.py): tiny alphabets (oversized groups, pre-split,
     trimmed batches), runs at the RLE1 limits, near-periodic and periodic text, word soups."""
