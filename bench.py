@@ -628,7 +628,7 @@ def main():
             pt = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
             if pt.get("workload") == f"{args.kind} -{args.level}":
                 tk = pt["kernels"]
-                cand = {"k_bwt_part": ["k_bwt_part2", "k_bwt_part"], "k_bwt_batch": ["k_bwt_batch", "k_bwt_deep", "k_bwt_deepr", "k_bwt_fix", "k_bwt_fix0", "k_bwt_fixr", "k_bwt_fixend"]}.get(dom, [dom])
+                cand = {"k_bwt_part": ["k_bwt_part2", "k_bwt_part"], "k_bwt_batch": ["k_bwt_batch", "k_bwt_long", "k_bwt_deep", "k_bwt_deepr", "k_bwt_fix", "k_bwt_fix0", "k_bwt_fixr", "k_bwt_fixend"]}.get(dom, [dom])
                 kb = sum(2.0 * tk[c]["fetch_kb_per_slab"] + tk[c]["write_kb_per_slab"] for c in cand if c in tk)
                 if kb > 0:
                     traffic = round(kb * 1024.0 * nslabs * args.steps / launches)
