@@ -647,6 +647,7 @@ template <u32 T, u32 LOG> struct walk_lds {
   u32 fn[T];             /* chunk maps, 3 bits per start state */
   u32 olen[T];           /* decoded bytes of the chunk, then the exclusive prefix */
   u32 ctr, ctr2, period, total;
+  u32 endstate;          /* RLE1 state behind the block's last byte: 4 = four equal bytes and no count (decode.c:1009, 1104: ERR_RUNLEN) */
   u32 xr[T / 64u];
 };
 
@@ -863,6 +864,7 @@ template <u32 T, u32 LOG> __device__ __forceinline__ void dwalk_block(lbz_dblock
   if (tid == 0u) {                                    /* start state of every chunk (kept in fn[]) */
     u32 c = 0;
     for (u32 t = 0; t < T; t++) { const u32 f = S.fn[t]; S.fn[t] = c; c = (f >> (3u * c)) & 7u; }
+    S.endstate = c;
   }
   __syncthreads();
   /* decoded length, CRC from 0 and the per-piece records (offsets relative to the chunk for now) */
@@ -914,7 +916,10 @@ template <u32 T, u32 LOG> __device__ __forceinline__ void dwalk_block(lbz_dblock
     cc = ~cc;
     D->computed_crc = cc;
     D->out_len = total;
-    if (cc != D->stored_crc) D->err = 11;
+    /* the reference's emit() stops at a block that ends where a run's count should stand; a block it took to the end is
+       checked against its CRC (expand.c:730-733: only a block whose status is OK) */
+    if (S.endstate == 4u) D->err = 12;
+    else if (cc != D->stored_crc) D->err = 11;
     D->wk[0] = (u32)(w1 - w0); D->wk[1] = (u32)(w2 - w1); D->wk[2] = (u32)(w3 - w2); D->wk[3] = (u32)(wall_clock64() - w3);
   }
 }
@@ -970,7 +975,7 @@ dblock_body(const u8 *in, u64 nbytes, lbz_dblock *blocks, u32 nblk, u8 *tt8_base
       u32 err = U.h.err2;
       const u32 n = U.h.nout;
       if (!err && (n == 0u || D->orig_ptr >= n)) err = 9;
-      D->nblock = err ? 0u : n;
+      D->nblock = (err && err != 9u) ? 0u : n;          /* (9 with n > 0: the origin pointer lies behind the block, ERR_BWTIDX; with n == 0: ERR_EMPTY) */
       D->err = err;
     }
   }

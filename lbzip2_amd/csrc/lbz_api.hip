@@ -1041,6 +1041,24 @@ extern "C" int lbzamd_decompress_device(lbzamd_dctx *c, const void *d_in_v, size
     *level = (unsigned)(head[3] - '0');
     return 1;
   };
+  /* What the reference's parser says when the chain ends at bit `at` with no magic there (parse.c:152-262): it takes a header
+     16 bits at a time and stops at the first word that does not fit -- ERR_HEADER -- or that is not all there -- ERR_EOF. */
+  auto no_magic_at = [&](uint64_t at) -> int {
+    const uint64_t nbits = ((uint64_t)len + 3u) / 4u * 32u, by = at >> 3;   /* the reference takes its input in 32-bit words, the last one filled up with zero bytes (expand.c:835-842) */
+    std::vector<uint8_t> h(12, 0);
+    if (by < len && hipMemcpy(h.data(), d_in + by, std::min<size_t>(11, len - by), hipMemcpyDeviceToHost) != hipSuccess) return RE_HEADER;
+    auto word = [&](unsigned k) -> int { return at + 16u * (k + 1u) > nbits ? -1 : (int)(rd_be32_bits(h, (at & 7u) + 16u * k) >> 16); };
+    static const int blk[3] = { 0x3141, 0x5926, 0x5359 }, eos[3] = { 0x1772, 0x4538, 0x5090 };
+    const int w0 = word(0);
+    if (w0 < 0) return RE_EOF;
+    const int *m = w0 == eos[0] ? eos : blk;
+    for (unsigned k = 0; k < 3u; k++) {
+      const int w = word(k);
+      if (w < 0) return RE_EOF;
+      if (w != m[k]) return RE_HEADER;
+    }
+    return RE_EOF;                               /* a whole magic and no mark: its CRC words are cut off */
+  };
   unsigned level0 = 0;
   {
     const int h = header_at(0, &level0);
@@ -1143,9 +1161,11 @@ extern "C" int lbzamd_decompress_device(lbzamd_dctx *c, const void *d_in_v, size
         continue;
       }
       lbz_dblock &b = hb[ci];
-      const bool kernel_ok = !b.err || b.err == 11u;            /* decoded to its last code (11: only the CRC differs) */
-      bool behind_the_block = b.err == 11u || b.err == 9u;     /* errors found with the block's bits all taken: the chain itself goes on */
-      if (!b.err && b.nblock > level * 100000u) { b.err = 8; behind_the_block = true; }   /* more bytes than the stream's block size allows (expand.c:726) */
+      const bool kernel_ok = !b.err || b.err == 11u || b.err == 12u;   /* decoded to its last code (11: only the CRC differs; 12: it ends where a run's count should stand) */
+      bool behind_the_block = b.err == 11u || b.err == 12u || b.err == 9u;   /* errors found with the block's bits all taken: the chain itself goes on */
+      /* more bytes than the stream's block size allows: the muxer looks at that first, whatever else the block's status is
+         (expand.c:725-726), then at the status, and at the CRC only of a block that is OK (:730-733) */
+      if (kernel_ok && b.nblock > level * 100000u) { b.err = 8; behind_the_block = true; }
       if (b.err) {
         char buf[128];
         snprintf(buf, sizeof buf, "lbzamd_decompress: block %u: %s (code %u)", nblocks, b.err == 11 ? "CRC mismatch" : "malformed block", b.err);
@@ -1170,7 +1190,12 @@ extern "C" int lbzamd_decompress_device(lbzamd_dctx *c, const void *d_in_v, size
       expect = b.bit_used;
       nblocks++; stream_blocks++;
     }
-    if (last_batch && in_stream) { g_err = "lbzamd_decompress: stream without end-of-stream marker (truncated?)"; g_err_code = RE_EOF; return -3; }
+    if (last_batch && in_stream) {
+      g_err_code = no_magic_at(expect);
+      g_err = g_err_code == RE_EOF ? "lbzamd_decompress: stream without end-of-stream marker (truncated?)"
+                                   : "lbzamd_decompress: no block or end-of-stream magic where the previous block ends (damaged or overrun block)";
+      return -3;
+    }
     if (c->grow_out && nb && total > out_cap && !pend_code) {
       /* the size is known only now (the blocks of this pass are decoded, their bytes not yet in place): a larger buffer,
          sized for the passes still to come as the blocks so far suggest, keeps what the earlier passes have written */
@@ -1208,6 +1233,7 @@ extern "C" int lbzamd_decompress_device(lbzamd_dctx *c, const void *d_in_v, size
       const size_t nbytes = std::min<size_t>(8, len - by);
       HIPCHK(hipMemcpy(tail.data(), d_in + by, nbytes, hipMemcpyDeviceToHost));
       std::vector<uint8_t> h(tail.begin(), tail.begin() + nbytes);
+      if (tr.bit + 80u > ((uint64_t)len + 3u) / 4u * 32u) { g_err = "lbzamd_decompress: the end-of-stream marker's CRC is cut off"; g_err_code = RE_EOF; return -3; }   /* parse.c:276 */
       const uint32_t want = rd_be32_bits(h, (tr.bit + 48) & 7u);
       if (want != tr.cc) { g_err = "lbzamd_decompress: stream CRC mismatch"; g_err_code = RE_STRMCRC; return -3; }
     }
@@ -1661,6 +1687,7 @@ struct wd_state {
   std::vector<uint8_t> out;               /* the decoded block */
   size_t pos = 0;                         /* bytes emit() has handed out */
   uint32_t crc = 0;
+  bool runlen = false;                    /* the block ends where a run's count should stand: emit() says so (decode.c:1009, 1104) */
 };
 struct wd_req {
   wd_state *st;
@@ -1723,7 +1750,7 @@ int wd_error(uint32_t code, uint32_t nblock)
   }
 }
 }  // namespace
-static int dec_error(int code, uint32_t nblock) { return code == 11 ? RE_BLKCRC : wd_error((uint32_t)code, nblock); }
+static int dec_error(int code, uint32_t nblock) { return code == 11 ? RE_BLKCRC : (code == 12 ? (int)WD_ERR_RUNLEN : wd_error((uint32_t)code, nblock)); }
 namespace {
 void wd_grow_host(u8 **p, size_t *cap, size_t want)
 {
@@ -1784,9 +1811,11 @@ void wd_round(const std::vector<wd_req *> &batch)
     wd_req *r = batch[i];
     lbz_dblock &rec = hrec[i];
     const uint64_t used = rec.bit_used - (u64)off[i] * 8u;
-    r->past = used > r->avail || (rec.err && rec.err != 11u && used + 64u > r->avail);
+    const bool emit_level = rec.err == 11u || rec.err == 12u;    /* what emit() finds: retrieve() and decode() are done with the block */
+    r->past = used > r->avail || (rec.err && !emit_level && used + 64u > r->avail);
     rec.bit_used = used;
-    if (r->past || (rec.err && rec.err != 11u)) { rec.err = rec.err ? rec.err : 99u; rec.out_len = 0; r->rec = rec; continue; }
+    if (r->past || (rec.err && !emit_level)) { rec.err = rec.err ? rec.err : 99u; rec.out_len = 0; r->rec = rec; continue; }
+    r->st->runlen = rec.err == 12u;
     rec.err = 0;                                                 /* (11: the stand-in CRC does not match, of course) */
     rec.out_off = outb;
     outb += rec.out_len;
@@ -1931,6 +1960,7 @@ extern "C" int lbzamd_emit(struct decoder_state *ds, void *buf, size_t *buf_sz)
   st->pos += n;
   *buf_sz -= n;
   if (st->pos < st->out.size()) return WD_MORE;
+  if (st->runlen) return WD_ERR_RUNLEN;
   ds->crc = st->crc;                                           /* decode.c:1141 */
   return WD_OK;
 }

@@ -112,3 +112,86 @@ def crafted_stream(magic=BLOCK_MAGIC, level=9, filler=60):
     s += "0" * (-len(s) % 8)
     stream = b"BZh" + bytes([48 + level]) + int(s, 2).to_bytes(len(s) // 8, "big")
     return stream, data
+
+
+def _bwt(t):
+    """(last column, row of rotation 0) of the sorted rotations of t -- naive, for blocks of a few hundred bytes."""
+    n = len(t)
+    rows = sorted(range(n), key=lambda i: (t[i:] + t[:i], i))
+    return [t[(i - 1) % n] for i in rows], rows.index(0)
+
+
+def _encode_symbols(L, used):
+    """move-to-front + zero runs (RUNA / RUNB, bijective base 2) of the BWT string -> symbols without the end-of-block one"""
+    order = list(used)
+    syms, run = [], 0
+
+    def flush():
+        nonlocal run
+        while run:
+            run -= 1
+            syms.append(run & 1)
+            run >>= 1
+
+    for b in L:
+        j = order.index(b)
+        if j == 0:
+            run += 1
+            continue
+        flush()
+        syms.append(j + 1)
+        order.insert(0, order.pop(j))
+    flush()
+    return syms
+
+
+def block_stream(rle1, level=9, orig=None, stored_crc=None, cut_bits=None, tail=b""):
+    """A one-block .bz2 stream whose block -- the bytes BEHIND the initial run-length coding -- is `rle1` (bytes out of
+    A..F, all six of them in use: eight symbols with 3-bit codes, as crafted_stream).  The block need not be what an
+    encoder would write: it may end where a run's count should stand, `orig` may point behind it, `stored_crc` may be wrong.
+    cut_bits: the stream is cut after that many bits (then padded to a byte); tail: bytes appended.
+    Returns (stream, bytes a decoder that accepts the block writes, or None if the block ends inside a run's count)."""
+    used = [65, 66, 67, 68, 69, 70]
+    t = list(rle1)
+    assert set(t) <= set(used) and (len(set(t)) == 6 or not t)
+    L, o = _bwt(t) if t else ([], 0)
+    syms = _encode_symbols(L, used)
+    assert _decode_symbols(syms, used) == L
+    state, prev = 0, None                                          # the run-length state behind the last byte (4: a count is due)
+    for b in t:
+        if state == 4:
+            state, prev = 0, None
+            continue
+        state = state + 1 if b == prev else 1
+        prev = b
+    ends_in_count = state == 4
+    data = None if ends_in_count else _inverse_rle1(t)
+    crc = _crc32_bz(data) if data is not None else 0
+    if stored_crc is not None:
+        crc = stored_crc
+    bits = []
+
+    def put(nb, v):
+        bits.append(format(v, "0%db" % nb))
+
+    put(48, BLOCK_MAGIC); put(32, crc); put(1, 0); put(24, o if orig is None else orig)
+    put(16, 1 << (15 - 4))
+    put(16, sum(1 << (15 - (u - 64)) for u in used))
+    all_syms = syms + [7]
+    nsel = (len(all_syms) + 49) // 50
+    put(3, 2); put(15, nsel)
+    for _ in range(nsel):
+        put(1, 0)
+    for _ in range(2):
+        put(5, 3)
+        for _ in range(8):
+            put(1, 0)
+    for s in all_syms:
+        put(3, s)
+    put(48, END_MAGIC); put(32, crc)
+    s = "".join(bits)
+    if cut_bits is not None:
+        s = s[:max(0, len(s) + cut_bits)] if cut_bits < 0 else s[:cut_bits]          # negative: that many bits off the end
+    s += "0" * (-len(s) % 8)
+    stream = b"BZh" + bytes([48 + level]) + (int(s, 2).to_bytes(len(s) // 8, "big") if s else b"") + tail
+    return stream, data

@@ -87,6 +87,12 @@ def expand_cases():
     return json.load(open(path))["cases"]
 
 
+def damaged_cases():
+    import json
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "damaged_cases.json")
+    return json.load(open(path))["cases"]
+
+
 def check_expand_case(lib, c):
     """one case of the reference's decompressor suite (its tests/README: 32767 selectors, 20-bit codes, a zip bomb,
     randomised and cyclic blocks, the largest origin pointer, concatenated streams, gaps and trailing garbage, block
@@ -105,6 +111,20 @@ def check_expand_case(lib, c):
 @pytest.mark.parametrize("c", [c for c in expand_cases() if c["out_len"] < 10**6], ids=lambda c: c["name"])
 def test_reference_expand_suite(emu, c):
     check_expand_case(emu, c)
+
+
+def test_damaged_streams_are_refused_with_the_reference_s_error(emu):
+    """tests/golden/damaged_cases.json through the library call: refused (or, the one good stream, decoded), and
+    lbzamd_last_error_code() is the reference's `enum error` value of the diagnostic the compiled reference printed
+    (common.h:54-76; tests/test_cli.py compares the command's words)."""
+    names = ["bad stream header magic", "bad block header magic", "empty source alphabet", "bad number of trees", "no coding groups",
+             "invalid selector", "invalid delta code", "invalid prefix code", "incomplete prefix code", "empty block", "unterminated block",
+             "missing run length", "block CRC mismatch", "stream CRC mismatch", "block overflow", "primary index too large", "unexpected end of file"]
+    for c in damaged_cases():
+        check_expand_case(emu, c)
+        if not c["ok"] and "compressed data error: " in c["ref_message"]:
+            want = 3 + names.index(c["ref_message"].split("compressed data error: ")[1])
+            assert emu.lib.lbzamd_last_error_code() == want, (c["name"], emu.lib.lbzamd_last_error_code(), want)
 
 
 def suite_streams(step):
