@@ -45,6 +45,8 @@ template <u32 T> struct dec_lds {
   u8 seq2unseq[256];
   u8 wl[T / 64u][256];             /* dmtf_expand: the list a wave's chunk starts with */
   u32 nsym, nout, err2;
+  u32 cerr;                           /* what stopped the bit chain (0: the end-of-block code), kept while the symbols it did read are measured */
+  u8 tbad[8];                         /* per table: 0, or the error a group that SELECTS it ends in (13: incomplete code, 6: oversubscribed; decode.c:232, :640) */
   u32 prod, fin;                      /* symbols the bit chain has handed over (a multiple of DM_CHUNK); 1 once it is done and nsym stands */
   u32 ring[260];                      /* dhuff_block: 256 dwords of the stream around the cursor (+ ring[0] again) */
   u32 ctr[2];                         /* chunk tickets of dmtf_chunks / dmtf_expand */
@@ -183,7 +185,8 @@ template <u32 T> __device__ __forceinline__ void dhuff_block(const u8 *in, u64 n
   const u32 alpha = ninuse + 2u, eob = alpha - 1u;
   const u32 ngroups = ub_get(&b, 3);
   const u32 nsel = ub_get(&b, 15);
-  if (!err && (ngroups < 2u || ngroups > LBZ_MAX_TREES || nsel < 1u)) err = 2;
+  if (!err && (ngroups < 2u || ngroups > LBZ_MAX_TREES)) err = 2;
+  if (!err && nsel < 1u) err = 14;                              /* decode.c:562: no coding groups */
   /* selectors: unary move-to-front codes; the six-entry list is a word of nibbles */
   if (!err) {
     u32 order = 0x543210u, acc = 0;
@@ -231,6 +234,17 @@ template <u32 T> __device__ __forceinline__ void dhuff_block(const u8 *in, u64 n
     for (u32 k = 0; k < 5u; k++) if (ln[k]) { mn = ln[k] < mn ? ln[k] : mn; mx = ln[k] > mx ? ln[k] : mx; }
     mn = rfl(wave_min(mn)); mx = rfl(wave_max(mx));
     if (lane == 0u) { S.minlen[t] = (u8)mn; S.maxlen[t] = (u8)mx; }
+    {
+      /* the reference takes a table only if its lengths fill the code space exactly (Kraft's sum = 1, decode.c:226-235) and
+         says so when a group first SELECTS the table, not when it reads it: an unused bad table is no error */
+      u32 kr = 0;
+#pragma unroll
+      for (u32 k = 0; k < 5u; k++) if (ln[k]) kr += 1u << (20u - ln[k]);
+      kr = rfl(wave_sum(kr));
+      const u32 bad = kr == (1u << 20) ? 0u : (kr < (1u << 20) ? 13u : 6u);
+      if (lane == 0u) S.tbad[t] = (u8)bad;
+      if (bad) continue;
+    }
     u32 pp = 0, vec = 0;
     for (u32 l = mn; l <= mx; l++) {
       u32 below = 0;
@@ -289,6 +303,7 @@ template <u32 T> __device__ __forceinline__ void dhuff_block(const u8 *in, u64 n
       if (k == LBZ_GROUP) {                                      /* a group: LBZ_GROUP symbols of one tree */
         if (groupno >= nsel) { err = 5; break; }
         t = groupno < DEC_MAX_SEL ? (rfl(S.sel[groupno >> 3]) >> (4u * (groupno & 7u))) & 15u : 0u;
+        { const u32 tb = rfl((u32)S.tbad[t]); if (tb) { err = tb; break; } }
         groupno++;
         if (nsym > maxn + 1u) { err = 8; break; }                /* every symbol but the last is at least one byte */
         k = 0;
@@ -400,7 +415,12 @@ template <u32 T> __device__ __forceinline__ void dhuff_block(const u8 *in, u64 n
     D->nblock = 0;
     D->err = err;
     D->bit_used = G - b.lead;
-    S.nsym = err ? 0u : nsym;
+    /* A chain that stopped at a group (no selector left, a bad table) or on a code that no symbol has: the reference has been
+       writing the runs out as it went, and if they passed the block's capacity BEFORE that point it has already said "block
+       overflow" (decode.c:695, :776).  So the symbols read so far are still measured (dmtf_chunks, dmtf_scan). */
+    const bool measured = err == 0u || err == 5u || err == 6u || err == 13u;
+    S.cerr = err;
+    S.nsym = measured ? nsym : 0u;
   }
   lds_publish(&S.fin, 1u);
 }
@@ -950,7 +970,7 @@ dblock_body(const u8 *in, u64 nbytes, lbz_dblock *blocks, u32 nblk, u8 *tt8_base
   u8 *lists = reinterpret_cast<u8 *>(tt) + loff;
   u32 *lens = reinterpret_cast<u32 *>(lists + (size_t)((cap + 128u) / DM_CHUNK + 2u) * 256u);
   const u64 k0 = wall_clock64();
-  if (tid == 0u) { U.h.ctr[0] = 0; U.h.ctr[1] = 0; U.h.err2 = 0; U.h.nout = 0; U.h.prod = 0; U.h.fin = 0; U.h.nsym = 0; }
+  if (tid == 0u) { U.h.ctr[0] = 0; U.h.ctr[1] = 0; U.h.err2 = 0; U.h.cerr = 0; U.h.nout = 0; U.h.prod = 0; U.h.fin = 0; U.h.nsym = 0; }
   __syncthreads();
   /* wave 0 walks the codes; the others turn chunks of symbols into chunks of list indices as they come, and wave 0
      joins them when it has reached the end of the block */
@@ -969,10 +989,10 @@ dblock_body(const u8 *in, u64 nbytes, lbz_dblock *blocks, u32 nblk, u8 *tt8_base
     if (tid < 64u && !U.h.err2) dmtf_scan(lists, lens, D->max_block < cap ? D->max_block : cap, U.h);
     __threadfence_block();
     __syncthreads();
-    if (!U.h.err2) dmtf_expand(sym16, lists, lens, tt8, U.h);
+    if (!U.h.err2 && !U.h.cerr) dmtf_expand(sym16, lists, lens, tt8, U.h);
     __syncthreads();
     if (tid == 0u) {
-      u32 err = U.h.err2;
+      u32 err = U.h.err2 ? 8u : U.h.cerr;               /* (7: a zero run of more than twenty digits, 8: more bytes than a block holds -- both "block overflow") */
       const u32 n = U.h.nout;
       if (!err && (n == 0u || D->orig_ptr >= n)) err = 9;
       D->nblock = (err && err != 9u) ? 0u : n;          /* (9 with n > 0: the origin pointer lies behind the block, ERR_BWTIDX; with n == 0: ERR_EMPTY) */

@@ -1744,7 +1744,9 @@ int wd_error(uint32_t code, uint32_t nblock)
     case 4: return WD_ERR_DELTA;
     case 5: return WD_ERR_UNTERM;
     case 6: return WD_ERR_PREFIX;
-    case 8: return WD_ERR_OVERFLOW;
+    case 7: case 8: return WD_ERR_OVERFLOW;
+    case 13: return WD_ERR_INCOMPLT;
+    case 14: return WD_ERR_GROUPS;
     case 9: return nblock == 0u ? WD_ERR_EMPTY : WD_ERR_BWTIDX;
     default: return WD_ERR_PREFIX;
   }

@@ -145,7 +145,19 @@ def _encode_symbols(L, used):
     return syms
 
 
-def block_stream(rle1, level=9, orig=None, stored_crc=None, cut_bits=None, tail=b""):
+def _canonical(lens):
+    """bzip2's code assignment: lengths ascending, symbols ascending inside a length -> {symbol: (length, code)}"""
+    code, out = 0, {}
+    for l in range(1, 21):
+        for s_, ls in enumerate(lens):
+            if ls == l:
+                out[s_] = (l, code)
+                code += 1
+        code <<= 1
+    return out
+
+
+def block_stream(rle1, level=9, orig=None, stored_crc=None, cut_bits=None, tail=b"", tables=None, selectors=None, nsel=None):
     """A one-block .bz2 stream whose block -- the bytes BEHIND the initial run-length coding -- is `rle1` (bytes out of
     A..F, all six of them in use: eight symbols with 3-bit codes, as crafted_stream).  The block need not be what an
     encoder would write: it may end where a run's count should stand, `orig` may point behind it, `stored_crc` may be wrong.
@@ -178,16 +190,26 @@ def block_stream(rle1, level=9, orig=None, stored_crc=None, cut_bits=None, tail=
     put(16, 1 << (15 - 4))
     put(16, sum(1 << (15 - (u - 64)) for u in used))
     all_syms = syms + [7]
-    nsel = (len(all_syms) + 49) // 50
-    put(3, 2); put(15, nsel)
-    for _ in range(nsel):
-        put(1, 0)
-    for _ in range(2):
-        put(5, 3)
-        for _ in range(8):
+    ngroups = (len(all_syms) + 49) // 50
+    tables = tables or [[3] * 8, [3] * 8]                          # tables: code lengths of the 8 symbols, 2..6 tables
+    selectors = selectors or [0] * ngroups                         # table of each group of 50 symbols
+    put(3, len(tables)); put(15, ngroups if nsel is None else nsel)
+    order = list(range(len(tables)))
+    for t in (selectors if nsel is None else selectors[:nsel]):    # move-to-front, unary
+        j = order.index(t)
+        put(j + 1, (1 << (j + 1)) - 2)
+        order.insert(0, order.pop(j))
+    for lens in tables:
+        put(5, lens[0])
+        cur = lens[0]
+        for l in lens:
+            while cur != l:
+                put(2, 2 if l > cur else 3)
+                cur += 1 if l > cur else -1
             put(1, 0)
-    for s in all_syms:
-        put(3, s)
+    for i, s_ in enumerate(all_syms):
+        l, code = _canonical(tables[selectors[i // 50]])[s_]
+        put(l, code)
     put(48, END_MAGIC); put(32, crc)
     s = "".join(bits)
     if cut_bits is not None:

@@ -61,8 +61,11 @@ def _run(prog, argv, cwd, env=None, stdin=b"", argv0=None, timeout=600):
     return p.returncode, p.stdout, err
 
 
-def _both(tmp_path, cli, files, argv, env=None, stdin=b"", argv0=None, prepare=None, same_stdout=True):
-    """the same files, the same command line, each program in a directory of its own; everything observable must agree"""
+def _both(tmp_path, cli, files, argv, env=None, stdin=b"", argv0=None, prepare=None, same_stdout=True, racy_words=False):
+    """the same files, the same command line, each program in a directory of its own; everything observable must agree
+    (racy_words: the reference's decompressor threads race on WHICH error a damaged stream is refused with -- one run says
+    one thing, the next another; such streams are compared in everything but the words, and the streams whose diagnostic is
+    the same in every run are pinned in tests/golden/damaged_cases.json)"""
     res = []
     for tag, prog in (("ref", STOCK), ("gpu", cli)):
         d = tmp_path / tag
@@ -77,8 +80,11 @@ def _both(tmp_path, cli, files, argv, env=None, stdin=b"", argv0=None, prepare=N
         if prepare:
             prepare(d)
         rc, out, err = _run(prog, argv, str(d), env, stdin, argv0)
-        res.append((rc, out if same_stdout else b"", err, _tree(str(d))))
-    assert res[0] == res[1], (argv, res[0][0], res[1][0], res[0][2][-300:], res[1][2][-300:])
+        res.append((rc, out if same_stdout else b"", b"" if racy_words else err, _tree(str(d))))
+        last_err = err
+    if racy_words:
+        res[1] = res[1][:2] + (last_err,) + res[1][3:]
+    assert res[0][:2] + res[0][3:] == res[1][:2] + res[1][3:] and (racy_words or res[0][2] == res[1][2]), (argv, res[0][0], res[1][0], res[0][2][-300:], res[1][2][-300:])
     return res[1]
 
 
@@ -148,7 +154,7 @@ def test_decompress_names_test_mode_and_damage(tmp_path, emu_cli):
     # damaged: a flipped payload bit, a truncated file, not bzip2 at all -- lbzip2's words, status 1, no output left behind
     bad = bytearray(z); bad[len(bad) // 2] ^= 0x10
     for data in (bytes(bad), z[:len(z) * 2 // 3], z[:10], b"plain text, not bzip2\n", b""):
-        rc, _, err, tree = _both(tmp_path, emu_cli, {"a.bz2": F(data)}, ["-d", "a.bz2"])
+        rc, _, err, tree = _both(tmp_path, emu_cli, {"a.bz2": F(data)}, ["-d", "a.bz2"], racy_words=data in (bytes(bad), z[:len(z) * 2 // 3]))
         assert rc == 1 and set(tree) == {"a.bz2"} and (b"compressed data error" in err or b"not a valid bzip2 file" in err)
     # -dfc copies what is not bzip2 (process.c:675-678)
     rc, out, _, _ = _both(tmp_path, emu_cli, {}, ["-dfc"], stdin=b"plain text, not bzip2\n")
@@ -292,7 +298,7 @@ def test_gpu_cli_speaks_like_the_reference_on_its_decompressor_suite(tmp_path):
         if c["ok"]:
             assert len(out) == c["out_len"] and hashlib.md5(out).hexdigest() == c["out_md5"], c["name"]
         else:
-            assert msg.replace("lbzamd:", "lbzip2_stock:") == c["ref_message"], (c["name"], msg, c["ref_message"])
+            assert msg.replace("lbzamd:", "lbzip2_stock:") in [c["ref_message"]] + c.get("also", []), (c["name"], msg, c["ref_message"])
 
 
 def test_damaged_streams_get_the_reference_s_diagnostic(emu_cli, tmp_path):
@@ -305,12 +311,12 @@ def test_damaged_streams_get_the_reference_s_diagnostic(emu_cli, tmp_path):
     randomly damaged ones are those for which eight runs of the reference agree (for a third of such streams they do not: its
     threads race).  Same status, same words, and for the one stream that is accepted the same bytes."""
     cases = json.load(open(os.path.join(GOLD, "damaged_cases.json")))["cases"]
-    assert len(cases) >= 30
+    assert len(cases) >= 45
     for c in cases:
         rc, out, err = _run(emu_cli, ["-dc"], str(tmp_path), stdin=bytes.fromhex(c["bz2_hex"]))[:3]
         msg = err.decode(errors="replace").strip()
         assert rc == c["ref_exit"], (c["name"], rc, msg)
         if c["ok"]:
             assert len(out) == c["out_len"] and hashlib.md5(out).hexdigest() == c["out_md5"], c["name"]
-        else:
-            assert msg == c["ref_message"].replace("lbzip2_stock: ", ""), (c["name"], msg, c["ref_message"])
+        else:                     # ("also": a defect in a block's tables or codes -- the reference's threads race between the block's own error and the parser's)
+            assert msg in [m.replace("lbzip2_stock: ", "") for m in [c["ref_message"]] + c.get("also", [])], (c["name"], msg, c["ref_message"])

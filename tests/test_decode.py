@@ -123,8 +123,8 @@ def test_damaged_streams_are_refused_with_the_reference_s_error(emu):
     for c in damaged_cases():
         check_expand_case(emu, c)
         if not c["ok"] and "compressed data error: " in c["ref_message"]:
-            want = 3 + names.index(c["ref_message"].split("compressed data error: ")[1])
-            assert emu.lib.lbzamd_last_error_code() == want, (c["name"], emu.lib.lbzamd_last_error_code(), want)
+            want = [3 + names.index(m.split("compressed data error: ")[1]) for m in [c["ref_message"]] + c.get("also", [])]
+            assert emu.lib.lbzamd_last_error_code() in want, (c["name"], emu.lib.lbzamd_last_error_code(), want)
 
 
 def suite_streams(step):
