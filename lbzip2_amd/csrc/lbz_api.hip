@@ -998,11 +998,31 @@ extern "C" int lbzamd_decompress_device(lbzamd_dctx *c, const void *d_in_v, size
   if (len < 14) {
     /* no room for a header and a trailer.  As the reference tells the two apart (process.c:664-681, expand.c:435): without
        "BZh1".."BZh9" in front it is not a bzip2 file, with it the file ends too early */
-    uint8_t h4[4] = { 0, 0, 0, 0 };
-    if (len >= 4) HIPCHK(hipMemcpy(h4, d_in, 4, hipMemcpyDeviceToHost));
+    uint8_t h4[16] = { 0 };
+    if (len) HIPCHK(hipMemcpy(h4, d_in, len, hipMemcpyDeviceToHost));
     const bool hdr = len >= 4 && h4[0] == 'B' && h4[1] == 'Z' && h4[2] == 'h' && h4[3] >= '1' && h4[3] <= '9';
     g_err = "lbzamd_decompress: not a bzip2 stream (too short)";
-    g_err_code = hdr ? RE_EOF : RE_MAGIC;
+    g_err_code = RE_MAGIC;
+    if (hdr) {
+      /* what follows the header, a 16-bit word at a time over the input filled up to 32-bit words (parse.c:152-262,
+         expand.c:835-842): the first word that does not fit is a bad magic, the first that is not there the end of the file */
+      const size_t words = (len + 3u) / 4u * 2u;                         /* 16-bit words there are, the zero filling included */
+      static const unsigned blk[3] = { 0x3141, 0x5926, 0x5359 }, eos[3] = { 0x1772, 0x4538, 0x5090 };
+      auto word = [&](size_t k) -> int { return k < words ? (int)((unsigned)h4[2 * k] << 8 | h4[2 * k + 1]) : -1; };
+      g_err_code = RE_EOF;
+      const unsigned *m = word(2) == (int)eos[0] ? eos : blk;
+      for (size_t k = 0; k < 3u && g_err_code == RE_EOF; k++) {
+        if (word(2 + k) < 0) break;
+        if (word(2 + k) != (int)m[k]) g_err_code = RE_HEADER;
+      }
+      /* 13 bytes are 16 with the filling: the CRC words are "there".  A block header with nothing behind it ends at what is
+         not a magic; an end-of-stream marker with a CRC other than zero is a wrong CRC (with three zero bytes the reference
+         misses the fourth: the end of the file) */
+      if (g_err_code == RE_EOF && words >= 8u && word(4) >= 0) {
+        if (m == blk) g_err_code = RE_HEADER;
+        else if (h4[10] | h4[11] | h4[12]) g_err_code = RE_STRMCRC;
+      }
+    }
     return -3;
   }
   /* 1. magics */
@@ -1180,7 +1200,9 @@ extern "C" int lbzamd_decompress_device(lbzamd_dctx *c, const void *d_in_v, size
           if (!pend_code) { pend_code = dec_error((int)b.err, b.nblock); pend_msg = buf; }
         } else {
           g_err = buf;
-          g_err_code = behind_the_block ? dec_error((int)b.err, b.nblock) : RE_HEADER;
+          /* (c) a block whose codes ran past the last byte of the file (what it read there were zeros): retrieve() asked
+             for more input and there was none -- ERR_EOF (decode.c:393-399) */
+          g_err_code = behind_the_block ? dec_error((int)b.err, b.nblock) : (b.bit_used > ((uint64_t)len + 3u) / 4u * 32u ? RE_EOF : RE_HEADER);
           return -3;
         }
       }

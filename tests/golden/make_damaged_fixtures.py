@@ -70,6 +70,17 @@ for keep, tail in ((0, b"\x17\x73\x45\x38\x50\x90\0\0\0\0"), (0, b"\x31\x41\x59\
                    (32, b"\x50\x91\0\0\0\0"), (0, b"\xAB"), (0, b"\xAB\xCD"), (0, b"\x17\x72"), (0, b"\x17\x72\x45"), (0, b"\x31\x41\x59\x26\x53\x59\x00\x00")):
     made.append(("trailer-%d-bits-then-%s" % (keep, tail.hex()), C.block_stream(plain, cut_bits=-(80 - keep), tail=tail)[0]))
 
+# files of 0..15 bytes: a header and what fits behind it (14 bytes are the shortest whole stream); the verdict is the
+# parser's, a 16-bit word at a time over the zero-filled last 32-bit word
+full = b"BZh9" + bytes.fromhex("177245385090") + b"\0\0\0\0"
+seen_short = set()
+for n in range(0, 16):
+    for k, v in enumerate((full[:n], (full[:max(0, n - 1)] + b"\x31") if n else b"", (b"BZh9" + bytes.fromhex("314159265359") + b"\1\2\3\4\5\6")[:n],
+                           (b"BZh9" + bytes.fromhex("177245385090") + b"\0\0\1\0")[:n], (full[:n] + b"\0" * (15 - n)) if n < 15 else full)):
+        if v not in seen_short:
+            seen_short.add(v)
+            made.append(("short-%02d-bytes-%d" % (len(v), k), v))
+
 # code tables and selectors (decode.c:226-235, :554-563, :640): a table whose lengths do not fill the code space exactly is an
 # error only where a group SELECTS it -- python's bz2 takes an incomplete table that the reference refuses
 inc, over, skew = [3] * 7 + [4], [3] * 7 + [2], [1, 2, 3, 4, 5, 6, 7, 7]
