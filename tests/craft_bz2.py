@@ -157,15 +157,17 @@ def _canonical(lens):
     return out
 
 
-def block_stream(rle1, level=9, orig=None, stored_crc=None, cut_bits=None, tail=b"", tables=None, selectors=None, nsel=None):
+def block_stream(rle1, level=9, orig=None, stored_crc=None, cut_bits=None, tail=b"", tables=None, selectors=None, nsel=None, used=None):
     """A one-block .bz2 stream whose block -- the bytes BEHIND the initial run-length coding -- is `rle1` (bytes out of
     A..F, all six of them in use: eight symbols with 3-bit codes, as crafted_stream).  The block need not be what an
     encoder would write: it may end where a run's count should stand, `orig` may point behind it, `stored_crc` may be wrong.
     cut_bits: the stream is cut after that many bits (then padded to a byte); tail: bytes appended.
     Returns (stream, bytes a decoder that accepts the block writes, or None if the block ends inside a run's count)."""
-    used = [65, 66, 67, 68, 69, 70]
+    default_alphabet = used is None
+    used = [65, 66, 67, 68, 69, 70] if used is None else sorted(used)   # used: the bytes of the block's map (with `tables` of len(used) + 2 lengths each)
     t = list(rle1)
-    assert set(t) <= set(used) and (len(set(t)) == 6 or not t)
+    assert set(t) <= set(used) and (not default_alphabet or len(set(t)) == 6 or not t)
+    eob = len(used) + 1
     L, o = _bwt(t) if t else ([], 0)
     syms = _encode_symbols(L, used)
     assert _decode_symbols(syms, used) == L
@@ -187,11 +189,13 @@ def block_stream(rle1, level=9, orig=None, stored_crc=None, cut_bits=None, tail=
         bits.append(format(v, "0%db" % nb))
 
     put(48, BLOCK_MAGIC); put(32, crc); put(1, 0); put(24, o if orig is None else orig)
-    put(16, 1 << (15 - 4))
-    put(16, sum(1 << (15 - (u - 64)) for u in used))
-    all_syms = syms + [7]
+    put(16, sum(1 << (15 - i) for i in range(16) if any(u >> 4 == i for u in used)))
+    for i in range(16):
+        if any(u >> 4 == i for u in used):
+            put(16, sum(1 << (15 - (u & 15)) for u in used if u >> 4 == i))
+    all_syms = syms + [eob]
     ngroups = (len(all_syms) + 49) // 50
-    tables = tables or [[3] * 8, [3] * 8]                          # tables: code lengths of the 8 symbols, 2..6 tables
+    tables = tables or [[3] * 8, [3] * 8]                          # tables: code lengths of the len(used) + 2 symbols, 2..6 tables
     selectors = selectors or [0] * ngroups                         # table of each group of 50 symbols
     put(3, len(tables)); put(15, ngroups if nsel is None else nsel)
     order = list(range(len(tables)))
@@ -217,3 +221,57 @@ def block_stream(rle1, level=9, orig=None, stored_crc=None, cut_bits=None, tail=
     s += "0" * (-len(s) % 8)
     stream = b"BZh" + bytes([48 + level]) + (int(s, 2).to_bytes(len(s) // 8, "big") if s else b"") + tail
     return stream, data
+
+
+def random_block_streams(seed, count):
+    """VALID one-block streams no encoder would write: alphabets of 1..256 bytes, 2..6 code tables with lengths up to 20 (random
+    trees and combs), a random table for every group of 50 symbols, blocks of 1..450 bytes with runs of every length.
+    Yields (stream, the bytes it decodes to)."""
+    import random
+    rng = random.Random(seed)
+
+    def rand_code(n, maxlen):
+        L = [1, 1]
+        while len(L) < n:
+            i = rng.randrange(len(L))
+            if L[i] >= maxlen:
+                continue
+            l = L.pop(i)
+            L += [l + 1, l + 1]
+        rng.shuffle(L)
+        return L
+
+    def comb_code(n):                                # c leaves at depths 1..c, the other n - c in a subtree below depth c
+        c = rng.randrange(1, min(n - 1, 13))
+        rest = n - c
+        while (1 << (20 - c)) < rest:
+            c -= 1
+            rest += 1
+        sub = rand_code(rest, 20 - c) if rest > 1 else None
+        L = list(range(1, c + 1)) + ([c + x for x in sub] if sub else [c])
+        rng.shuffle(L)
+        return L
+
+    made = 0
+    while made < count:
+        k = rng.choice([1, 2, 3, 6, 17, 40, 120, 256])
+        used = sorted(rng.sample(range(256), k))
+        n = rng.choice([1, 2, 5, 60, 200, 450])
+        t = bytearray()
+        while len(t) < n:
+            t += bytes([rng.choice(used)]) * rng.choice([1, 1, 1, 2, 3, 4, 5, 9])
+            if len(t) >= 4 and t[-1] == t[-2] == t[-3] == t[-4]:
+                t.append(used[rng.randrange(min(len(used), 6))])       # a count that is one of the block's bytes
+        t = bytes(t)
+        alpha = k + 2
+        tabs = [comb_code(alpha) if alpha > 3 and rng.random() < 0.3 else rand_code(alpha, 20) for _ in range(rng.randrange(2, 7))]
+        nsyms = len(_encode_symbols(_bwt(list(t))[0], used)) + 1
+        sel = [rng.randrange(len(tabs)) for _ in range((nsyms + 49) // 50)]
+        z, data = block_stream(t, level=rng.choice([1, 5, 9]), used=used, tables=tabs, selectors=sel)
+        if data is None:                             # the block happens to end where a count is due
+            continue
+        if rng.random() < 0.3:
+            z2, d2 = block_stream(b"ABCDEF" * 3 + b"FED")
+            z, data = z + z2, data + d2
+        made += 1
+        yield z, data
