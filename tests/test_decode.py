@@ -130,7 +130,7 @@ def test_damaged_streams_are_refused_with_the_reference_s_error(emu):
 def test_hand_made_blocks_with_random_tables(emu):
     """tests/craft_bz2.py: random_block_streams -- valid streams that no encoder writes (any alphabet, up to six tables of random
     shape with codes of up to 20 bits, a random table per group, runs and counts of every kind): decoded to the bytes they were
-    made from, and as Python's bz2 decodes them.  (A differential run of 2 400 such streams, some of them made invalid, against
+    made from, and as Python's bz2 decodes them.  (A differential run of 2 000 such streams, some of them made invalid, against
     the compiled reference program found no difference: DESIGN 10.)"""
     import craft_bz2
     with emu.decoder(4) as d:
