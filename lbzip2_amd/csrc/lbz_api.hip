@@ -1836,7 +1836,9 @@ void wd_round(const std::vector<wd_req *> &batch)
     lbz_dblock &rec = hrec[i];
     const uint64_t used = rec.bit_used - (u64)off[i] * 8u;
     const bool emit_level = rec.err == 11u || rec.err == 12u;    /* what emit() finds: retrieve() and decode() are done with the block */
-    r->past = used > r->avail || (rec.err && !emit_level && used + 64u > r->avail);
+    /* (an error the kernel found with `used` bits taken is the block's own if those bits were all there -- a code is decided by
+       its own bits, a header field by the bits it takes; only "no symbol has this code" (6) looks at bits ahead of the cursor) */
+    r->past = used > r->avail || (rec.err == 6u && used + 64u > r->avail);
     rec.bit_used = used;
     if (r->past || (rec.err && !emit_level)) { rec.err = rec.err ? rec.err : 99u; rec.out_len = 0; r->rec = rec; continue; }
     r->st->runlen = rec.err == 12u;
@@ -1946,13 +1948,10 @@ extern "C" int lbzamd_retrieve(struct decoder_state *ds, struct bitstream *bs)
   /* A malformed block: the error, and the caller's stream taken as consumed -- where it stands means nothing then, and an
      error position in front of THIS call's bits (it lay in the pad bits of the call before and came back as MORE) must
      not be turned into a pointer. */
-  if (rec.err || rec.bit_used < 32u + before) {
-    bs->live = 0; bs->buff = 0; bs->data = bs->limit;
-    return wd_error(rec.err, rec.nblock);
-  }
-  /* the caller's stream stands behind the block's last code */
-  {
-    const uint64_t used = rec.bit_used - 32u - before;         /* bits of THIS call's input */
+  /* the caller's stream stands behind the last bit the block took: behind its last code, or -- a malformed block -- where
+     retrieve() stopped, as the reference's does (the parser goes on from there and finds what is not a magic: which of the
+     two errors the program reports is a race in the reference too) */
+  auto stand_behind = [&](uint64_t used) {                        /* `used` bits of THIS call's input */
     if (used <= live0) { bs->buff = used < 64u ? buff0 << used : 0ull; bs->live = live0 - (unsigned)used; bs->data = data0; }
     else {
       const uint64_t c2 = used - live0;
@@ -1962,7 +1961,13 @@ extern "C" int lbzamd_retrieve(struct decoder_state *ds, struct bitstream *bs)
       else { bs->buff = 0; bs->live = 0; }
       bs->data = p;
     }
+  };
+  if (rec.err || rec.bit_used < 32u + before) {
+    if (rec.bit_used >= 32u + before && rec.bit_used <= r.avail) stand_behind(rec.bit_used - 32u - before);
+    else { bs->live = 0; bs->buff = 0; bs->data = bs->limit; }
+    return wd_error(rec.err, rec.nblock);
   }
+  stand_behind(rec.bit_used - 32u - before);
   ds->rand = rec.randomised != 0u;
   ds->bwt_idx = rec.orig_ptr;
   ds->block_size = rec.nblock;

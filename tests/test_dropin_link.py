@@ -112,6 +112,36 @@ def test_reference_cli_decompresses_through_the_library(programs):
         assert q.returncode != 0 and p.returncode == q.returncode, (p.returncode, q.returncode, p.stderr[-300:], q.stderr[-300:])
 
 
+def _damaged_cases_through(exe, env):
+    import json
+    cases = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "damaged_cases.json")))["cases"]
+    name = os.path.basename(exe)
+    for c in cases:
+        p = subprocess.run([exe, "-dc"], input=bytes.fromhex(c["bz2_hex"]), capture_output=True, timeout=300, env=dict(os.environ, **env))
+        msg = p.stderr.decode(errors="replace").strip().replace(name + ":", "lbzip2_stock:")
+        assert p.returncode == c["ref_exit"], (c["name"], p.returncode, msg)
+        if c["ok"]:
+            assert len(p.stdout) == c["out_len"] and hashlib.md5(p.stdout).hexdigest() == c["out_md5"], c["name"]
+        else:
+            assert msg in [c["ref_message"]] + c.get("also", []), (c["name"], msg, c["ref_message"])
+
+
+def test_damaged_streams_through_the_decoder_s_work_unit_boundary(programs):
+    """tests/golden/damaged_cases.json (103 hand-made and damaged streams with the compiled reference's verdict) through the
+    reference's OWN expand.c and parse.c over this library's retrieve / decode / emit: the diagnostic is then the reference's
+    scheduler's, made from what retrieve() and emit() return and from where retrieve() leaves the bit stream (at the point it
+    stopped, as the reference's does -- the parser goes on from there)."""
+    _damaged_cases_through(os.path.join(REFDIR, "lbzip2_dropin_d_emu"), {"LBZ_EMU_THREADS": "2", "LBZAMD_POOL_SLABS": "4"})
+
+
+@pytest.mark.gpu
+def test_damaged_streams_through_the_decoder_s_work_unit_boundary_on_the_gpu():
+    exe = os.path.join(REFDIR, "lbzip2_dropin_d_gpu")
+    if not os.path.exists(exe):
+        pytest.skip("oracle/_ref/lbzip2_dropin_d_gpu not built (needs the reference sources at build time)")
+    _damaged_cases_through(exe, {})
+
+
 @pytest.mark.gpu
 def test_reference_cli_decompresses_on_the_gpu():
     """oracle/_ref/lbzip2_dropin_d_gpu = the reference's program without encode.c, divbwt.c AND decode.c, linked against
