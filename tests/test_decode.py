@@ -336,10 +336,12 @@ def test_foreign_streams_on_the_gpu():
 
 def test_retrieve_error_just_in_front_of_a_chunk_boundary():
     """decode.h's retrieve() (lbz_api.hip section D) fed in two pieces, with a malformed field (7 coding tables: ERR_TREES,
-    decode.c) a few bits in front of the first piece's end.  The first call cannot tell the error from running out of bits
-    (what it read there may have been pad bits) and asks for MORE; the second sees the same error at a bit position that
-    now lies in front of its own input -- it must come back as the reference's error code with the caller's bitstream left
-    consumed, not as a position computed from a negative offset (round-4 review: wild pointer)."""
+    decode.c) a few bits in front of the first piece's end.  The kernel reads the 15-bit selector count behind the field
+    before it looks at either, so a first piece that ends inside that count is "ran past the bits there are": MORE; the
+    second call sees the same error at a bit position that now lies in front of its own input -- it must come back as the
+    reference's error code with the caller's bitstream left consumed, not as a position computed from a negative offset
+    (round-4 review: wild pointer).  A first piece that holds both fields gets the error at once, the stream left where
+    the walk stopped (as the reference's retrieve() leaves it)."""
     import ctypes as C
     import struct
     import subprocess
@@ -361,12 +363,17 @@ def test_retrieve_error_just_in_front_of_a_chunk_boundary():
     lib.lbzamd_decoder_init.argtypes = [C.POINTER(DecoderState)]
     lib.lbzamd_decoder_free.argtypes = [C.POINTER(DecoderState)]
     ERR_TREES, MORE, OK = 6, 1, 0           # common.h:54-76
-    data = bytes(gen("text", 20000, 3))
-    z = L.orc_compress(data, 1)
-    body = bytearray(z[14:]) + bytes(16)    # behind "BZh1", the block magic and the stored CRC: what retrieve() reads
-    # randomised (1) + origin pointer (24) + 16-bit map of ranges + 16 bits per used range, then the 3-bit table count
-    nranges = bin(int.from_bytes(body[3:6], "big") >> 7 & 0xFFFF).count("1")
-    pos = 1 + 24 + 16 + 16 * nranges
+    for extra in (b"", b"Q", b"Q~", b"Q~\x01"):   # (more 16-byte ranges in use: the fields move by 16 bits)
+        data = bytes(gen("text", 20000, 3)) + extra
+        z = L.orc_compress(data, 1)
+        body = bytearray(z[14:]) + bytes(16)    # behind "BZh1", the block magic and the stored CRC: what retrieve() reads
+        # randomised (1) + origin pointer (24) + 16-bit map of ranges + 16 bits per used range, then the 3-bit table count
+        nranges = bin(int.from_bytes(body[3:6], "big") >> 7 & 0xFFFF).count("1")
+        pos = 1 + 24 + 16 + 16 * nranges
+        if 32 * ((pos + 3 + 31) // 32) < pos + 18:      # a whole number of words ends inside the selector count
+            break
+    else:
+        raise AssertionError("no variant puts a word boundary inside the selector count")
     def words(b):
         b = bytes(b) + bytes(-len(b) % 4)
         return (C.c_uint32 * (len(b) // 4)).from_buffer_copy(b)     # big-endian words as they lie in the file (decode.c:404)
@@ -402,7 +409,13 @@ def test_retrieve_error_just_in_front_of_a_chunk_boundary():
     assert rc == MORE and at == cut and live == 0
     rc, at, live = call(ds, w, cut, len(w), False)
     assert rc == ERR_TREES, rc
-    assert at == len(w) and live == 0
+    assert 32 * at - live == pos + 18, (at, live, pos)          # where the walk stopped: behind the selector count
+    lib.lbzamd_decoder_free(C.byref(ds))
+    # a first piece that holds the selector count too: the error at once, the stream where the walk stopped
+    ds = DecoderState()
+    lib.lbzamd_decoder_init(C.byref(ds))
+    rc, at, live = call(ds, w, 0, cut + 1, False)
+    assert rc == ERR_TREES and 32 * at - live == pos + 18, (rc, at, live, pos)
     lib.lbzamd_decoder_free(C.byref(ds))
     # the same damage with nothing behind it and end of file: the error itself, not "unexpected end of file"
     ds = DecoderState()
