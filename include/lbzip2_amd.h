@@ -183,11 +183,14 @@ typedef struct lbzamd_dstats {
 int  lbzamd_dcreate(lbzamd_dctx **ctx, int device, unsigned max_blocks);
 void lbzamd_ddestroy(lbzamd_dctx *ctx);
 /* 0 ok; -1 bad argument / HIP error; -2 output buffer too small (*out_len = bytes needed);
- * -3 malformed stream or CRC mismatch (lbzamd_last_error() says which block).                        */
+ * -3 malformed stream or CRC mismatch (lbzamd_last_error() says which block): *out_len is then the number of bytes IN FRONT
+ *    of the error that were decoded and are in place -- the whole blocks before the first one that was refused -- as the
+ *    reference has written what it decoded by then (expand.c:735 writes every buffer that reaches the muxer in order).   */
 int  lbzamd_decompress_device(lbzamd_dctx *ctx, const void *d_in, size_t len, void *d_out, size_t out_cap, size_t *out_len);
 /* For callers that do not know the decoded size: ONE pass, the result in a malloc'ed buffer (*out, release with
  * lbzamd_free).  (lbzamd_decompress_host with out_cap too small returns -2 and the size AFTER decoding every block;
- * calling it again decodes them again.)  Same return codes otherwise.                                             */
+ * calling it again decodes them again.)  Same return codes otherwise; on -3 with bytes in front of the error *out holds them
+ * (release it) and *out_len says how many.                                                                         */
 int  lbzamd_decompress_alloc(lbzamd_dctx *ctx, const uint8_t *in, size_t len, uint8_t **out, size_t *out_len);
 void lbzamd_free(void *p);
 int  lbzamd_decompress_host(lbzamd_dctx *ctx, const uint8_t *in, size_t len, uint8_t *out, size_t out_cap, size_t *out_len);

@@ -388,7 +388,13 @@ class Decoder:
             p = C.POINTER(C.c_uint8)()
             rc = self.L.lib.lbzamd_decompress_alloc(self.h, data, len(data), C.byref(p), C.byref(n))
             if rc:
-                raise LbzError("lbzamd_decompress_alloc: " + self.L.error())
+                why = self.L.error()
+                e = LbzError("lbzamd_decompress_alloc: " + why)
+                e.decoded_in_front = b""                      # -3: the whole blocks in front of the one that was refused
+                if p:
+                    e.decoded_in_front = C.string_at(p, n.value)
+                    self.L.lib.lbzamd_free(p)
+                raise e
             try:
                 return C.string_at(p, n.value)
             finally:

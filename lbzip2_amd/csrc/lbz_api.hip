@@ -995,6 +995,7 @@ extern "C" int lbzamd_decompress_device(lbzamd_dctx *c, const void *d_in_v, size
   c->stats = lbzamd_dstats{};
   c->stats.n_in = len;
   g_err_code = 0;
+  *out_len = 0;
   if (len < 14) {
     /* no room for a header and a trailer.  As the reference tells the two apart (process.c:664-681, expand.c:435): without
        "BZh1".."BZh9" in front it is not a bzip2 file, with it the file ends too early */
@@ -1118,6 +1119,11 @@ extern "C" int lbzamd_decompress_device(lbzamd_dctx *c, const void *d_in_v, size
   uint32_t cc = 0, nblocks = 0, stream_blocks = 0;
   int pend_code = 0;                            /* the first block-level error met on the chain (see the walk) */
   std::string pend_msg;
+  /* On an error (-3) the bytes IN FRONT of it are still delivered, as the reference has written what it decoded by then:
+     *out_len bytes, the whole blocks in front of the first one that is refused.  `taken`: the candidates whose bytes count. */
+  std::vector<uint8_t> taken(hb.size(), 0);
+  uint64_t pend_total = 0, emitted = 0;
+  bool stop = false;                            /* the walk met an error of the parser's kind: the chain ends there */
   for (size_t b0 = 0; b0 < hb.size() || b0 == 0; b0 += c->max_blocks) {
     const u32 nb = (u32)std::min<size_t>(c->max_blocks, hb.size() - b0);
     if (nb) {
@@ -1153,7 +1159,6 @@ extern "C" int lbzamd_decompress_device(lbzamd_dctx *c, const void *d_in_v, size
     }
     /* the walk: marks in stream order, up to the last candidate of this batch */
     const bool last_batch = b0 + nb >= hb.size();
-    const uint64_t before = total;                             /* bytes the earlier passes have put in place */
     for (; mi < marks.size(); mi++) {
       const long ci = cand_of[mi];
       if (ci >= (long)(b0 + nb)) break;                     /* not decoded yet */
@@ -1167,7 +1172,8 @@ extern "C" int lbzamd_decompress_device(lbzamd_dctx *c, const void *d_in_v, size
         g_err = stream_blocks ? "lbzamd_decompress: no block or end-of-stream magic where the previous block ends (damaged or overrun block)"
                               : "lbzamd_decompress: no block magic behind the stream header";
         g_err_code = RE_HEADER;
-        return -3;
+        stop = true;
+        break;
       }
       if (is_end) {
         trailers.push_back({ bit, cc });
@@ -1197,34 +1203,40 @@ extern "C" int lbzamd_decompress_device(lbzamd_dctx *c, const void *d_in_v, size
            block's last code (CRC, size against the stream's level) is remembered, the walk goes on, and it is reported only
            if the parser finds nothing of its own further down (the reference's decompressor suite: crc2). */
         if (behind_the_block && kernel_ok) {
-          if (!pend_code) { pend_code = dec_error((int)b.err, b.nblock); pend_msg = buf; }
+          if (!pend_code) { pend_code = dec_error((int)b.err, b.nblock); pend_msg = buf; pend_total = total; }
         } else {
           g_err = buf;
           /* (c) a block whose codes ran past the last byte of the file (what it read there were zeros): retrieve() asked
              for more input and there was none -- ERR_EOF (decode.c:393-399) */
           g_err_code = behind_the_block ? dec_error((int)b.err, b.nblock) : (b.bit_used > ((uint64_t)len + 3u) / 4u * 32u ? RE_EOF : RE_HEADER);
-          return -3;
+          stop = true;
+          break;
         }
       }
+      if (pend_code) { b.err = 99; b.out_len = 0; }            /* the walk goes on (the parser may still find something of its own); no bytes from here on */
+      else taken[ci] = 1;
       b.out_off = total;
       total += b.out_len;
       cc = ((cc << 1) | (cc >> 31)) ^ b.stored_crc;            /* encode.h:38 written for the inverted values */
       expect = b.bit_used;
       nblocks++; stream_blocks++;
     }
-    if (last_batch && in_stream) {
+    if (!stop && last_batch && in_stream) {
       g_err_code = no_magic_at(expect);
       g_err = g_err_code == RE_EOF ? "lbzamd_decompress: stream without end-of-stream marker (truncated?)"
                                    : "lbzamd_decompress: no block or end-of-stream magic where the previous block ends (damaged or overrun block)";
-      return -3;
+      stop = true;
     }
-    if (c->grow_out && nb && total > out_cap && !pend_code) {
+    for (u32 i = 0; i < nb; i++)                               /* what the walk did not take: off the chain, behind an error, the refused block itself */
+      if (!taken[b0 + i]) { hb[b0 + i].err = hb[b0 + i].err ? hb[b0 + i].err : 99u; hb[b0 + i].out_len = 0; }
+    const uint64_t emit_total = pend_code ? pend_total : total;   /* bytes of the blocks taken so far */
+    if (c->grow_out && nb && emit_total > out_cap) {
       /* the size is known only now (the blocks of this pass are decoded, their bytes not yet in place): a larger buffer,
          sized for the passes still to come as the blocks so far suggest, keeps what the earlier passes have written */
-      const uint64_t prev = before;                           /* (not hb[b0].out_off: the batch's first candidate may be off the chain -- a
+      const uint64_t prev = emitted;                           /* (not hb[b0].out_off: the batch's first candidate may be off the chain -- a
                                                                   magic inside a payload -- and never get an offset) */
-      uint64_t want = total + total / 16u + 4096u;
-      if (b0 + nb < hb.size()) want = (uint64_t)((double)total * (double)hb.size() / (double)(b0 + nb) * 1.0625) + 4096u;
+      uint64_t want = emit_total + emit_total / 16u + 4096u;
+      if (b0 + nb < hb.size()) want = (uint64_t)((double)emit_total * (double)hb.size() / (double)(b0 + nb) * 1.0625) + 4096u;
       u8 *bigger = nullptr;
       HIPCHK(hipMalloc((void **)&bigger, want + 256u));
       if (prev) HIPCHK(hipMemcpyAsync(bigger, c->d_out, prev, hipMemcpyDeviceToDevice, q));
@@ -1233,7 +1245,7 @@ extern "C" int lbzamd_decompress_device(lbzamd_dctx *c, const void *d_in_v, size
       c->d_out = bigger; c->d_out_cap = want;
       d_out = bigger; out_cap = want;
     }
-    if (nb && total <= out_cap && d_out && !pend_code) {
+    if (nb && emit_total <= out_cap && d_out && emit_total > emitted) {
       HIPCHK(hipMemcpyAsync(c->blocks, hb.data() + b0, nb * sizeof(lbz_dblock), hipMemcpyHostToDevice, q));
       HIPCHK(hipEventRecord(c->ev[5], q));
       hipLaunchKernelGGL(k_demit, dim3(nb * 8u), dim3(256), 0, q, (const lbz_dblock *)c->blocks, nb, (const u8 *)c->W, (const u32 *)c->pinfo, d_out, (u64)out_cap, c->cap);
@@ -1242,7 +1254,9 @@ extern "C" int lbzamd_decompress_device(lbzamd_dctx *c, const void *d_in_v, size
       HIPCHK(hipGetLastError());
       float t = 0;
       HIPCHK(hipEventElapsedTime(&t, c->ev[5], c->ev[6])); ms[4] += t;
+      emitted = emit_total;
     }
+    if (stop) { *out_len = (size_t)emitted; return -3; }
     if (hb.empty()) break;
   }
   c->stats.nblocks = nblocks;
@@ -1255,12 +1269,12 @@ extern "C" int lbzamd_decompress_device(lbzamd_dctx *c, const void *d_in_v, size
       const size_t nbytes = std::min<size_t>(8, len - by);
       HIPCHK(hipMemcpy(tail.data(), d_in + by, nbytes, hipMemcpyDeviceToHost));
       std::vector<uint8_t> h(tail.begin(), tail.begin() + nbytes);
-      if (tr.bit + 80u > ((uint64_t)len + 3u) / 4u * 32u) { g_err = "lbzamd_decompress: the end-of-stream marker's CRC is cut off"; g_err_code = RE_EOF; return -3; }   /* parse.c:276 */
+      if (tr.bit + 80u > ((uint64_t)len + 3u) / 4u * 32u) { g_err = "lbzamd_decompress: the end-of-stream marker's CRC is cut off"; g_err_code = RE_EOF; *out_len = (size_t)emitted; return -3; }   /* parse.c:276 */
       const uint32_t want = rd_be32_bits(h, (tr.bit + 48) & 7u);
-      if (want != tr.cc) { g_err = "lbzamd_decompress: stream CRC mismatch"; g_err_code = RE_STRMCRC; return -3; }
+      if (want != tr.cc) { g_err = "lbzamd_decompress: stream CRC mismatch"; g_err_code = RE_STRMCRC; *out_len = (size_t)emitted; return -3; }
     }
   }
-  if (pend_code) { g_err = pend_msg; g_err_code = pend_code; return -3; }
+  if (pend_code) { g_err = pend_msg; g_err_code = pend_code; *out_len = (size_t)emitted; return -3; }
   c->stats.n_out = total;
   c->stats.ms_scan = ms[0]; c->stats.ms_huff = ms[1]; c->stats.ms_sort = ms[2]; c->stats.ms_walk = ms[3]; c->stats.ms_emit = ms[4];
   c->stats.ms_blocks = ms[5];
@@ -1286,9 +1300,10 @@ extern "C" int lbzamd_decompress_host(lbzamd_dctx *c, const uint8_t *in, size_t 
   }
   HIPCHK(hipMemcpy(c->d_in, in, len, hipMemcpyHostToDevice));
   const int rc = lbzamd_decompress_device(c, c->d_in, len, out_cap ? c->d_out : nullptr, out_cap, out_len);
-  if (rc) return rc;
-  if (*out_len) HIPCHK(hipMemcpy(out, c->d_out, *out_len, hipMemcpyDeviceToHost));
-  return 0;
+  if (rc && rc != -3) return rc;
+  if (*out_len && *out_len <= out_cap) HIPCHK(hipMemcpy(out, c->d_out, *out_len, hipMemcpyDeviceToHost));   /* (-3: the bytes in front of the error) */
+  else if (rc) *out_len = 0;
+  return rc;
 }
 
 /* One pass for callers that do not know the decoded size: the device output buffer grows between the block passes, the
@@ -1314,15 +1329,17 @@ extern "C" int lbzamd_decompress_alloc(lbzamd_dctx *c, const uint8_t *in, size_t
   size_t n = 0;
   const int rc = lbzamd_decompress_device(c, c->d_in, len, c->d_out, c->d_out_cap, &n);
   c->grow_out = false;
-  if (rc) return rc;
+  if (rc && (rc != -3 || n == 0)) return rc;
+  const std::string why = rc ? g_err : std::string();            /* (-3 with n > 0: the bytes in front of the error come back too) */
+  const int why_code = g_err_code;
   uint8_t *h = (uint8_t *)malloc(n ? n : 1);
-  if (!h) { g_err = "lbzamd_decompress_alloc: out of host memory"; return -1; }
+  if (!h) { if (rc) return rc; g_err = "lbzamd_decompress_alloc: out of host memory"; return -1; }
   if (n) {
     const hipError_t e = hipMemcpy(h, c->d_out, n, hipMemcpyDeviceToHost);
-    if (e != hipSuccess) { free(h); return fail_msg("hipMemcpy", e); }
+    if (e != hipSuccess) { free(h); if (rc) { g_err = why; g_err_code = why_code; return rc; } return fail_msg("hipMemcpy", e); }
   }
   *out = h; *out_len = n;
-  return 0;
+  return rc;
 }
 extern "C" void lbzamd_free(void *p) { free(p); }
 

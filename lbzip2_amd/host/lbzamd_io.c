@@ -576,7 +576,13 @@ int lbzamd_io_decompress(int fd_in, int fd_out, int not_bzip2_copy, int report, 
     if (lbzamd_dcreate(&d, -1, maxb > 2400u ? 2400u : maxb)) { rc = LBZAMD_IO_DEVICE; snprintf(msg, msg_cap, "%s", lbzamd_last_error()); goto done; }
     const int drc = lbzamd_decompress_alloc(d, z, zlen, &out, &n);
     t2 = now_s();
-    if (drc == -3) { rc = LBZAMD_IO_DATA; *err_code = lbzamd_last_error_code(); snprintf(msg, msg_cap, "%s", lbzamd_last_error()); goto done; }
+    if (drc == -3) {
+      rc = LBZAMD_IO_DATA; *err_code = lbzamd_last_error_code(); snprintf(msg, msg_cap, "%s", lbzamd_last_error());
+      /* the bytes in front of the damage -- the whole blocks before the one that was refused -- go out as the reference's do
+         (it has written what it decoded by then); a caller that writes a FILE removes it, as lbzip2 does */
+      if (fd_out >= 0 && out && n) (void)write_fully(fd_out, out, n, 0, 0);
+      goto done;
+    }
     if (drc) { rc = LBZAMD_IO_DEVICE; snprintf(msg, msg_cap, "%s", lbzamd_last_error()); goto done; }
   }
   if (fd_out >= 0 && write_fully(fd_out, out, n, 0, 0)) { rc = LBZAMD_IO_WRITE; *sys_errno = errno; snprintf(msg, msg_cap, "write()"); goto done; }

@@ -320,3 +320,18 @@ def test_damaged_streams_get_the_reference_s_diagnostic(emu_cli, tmp_path):
             assert len(out) == c["out_len"] and hashlib.md5(out).hexdigest() == c["out_md5"], c["name"]
         else:                     # ("also": a defect in a block's tables or codes -- the reference's threads race between the block's own error and the parser's)
             assert msg in [m.replace("lbzip2_stock: ", "") for m in [c["ref_message"]] + c.get("also", [])], (c["name"], msg, c["ref_message"])
+
+
+def test_the_bytes_in_front_of_the_damage_reach_the_pipe(emu_cli, tmp_path):
+    """`-dc` of a stream whose third block is damaged: status 1, and what was written to the pipe before the diagnostic is the
+    decoded data up to a block boundary -- the reference writes what it has decoded by then (whole buffers, sometimes a part of
+    the damaged block's own), this command the whole blocks in front of the one it refuses.  To a FILE nothing is left behind."""
+    data = bytes(gen("text", 350000, 5))
+    z = bytearray(subprocess.run([STOCK, "-1"], input=data, capture_output=True).stdout)
+    z[int(len(z) * 0.7)] ^= 0x20
+    rc_ref, out_ref, _ = _run(STOCK, ["-dc"], str(tmp_path), stdin=bytes(z))
+    rc, out, err = _run(emu_cli, ["-dc"], str(tmp_path), stdin=bytes(z))
+    assert rc == rc_ref == 1 and b"compressed data error" in err
+    assert data.startswith(out_ref) and data.startswith(out) and 190000 < len(out) < 210000, (len(out_ref), len(out))
+    rc, _, _, tree = _both(tmp_path, emu_cli, {"a.bz2": F(bytes(z))}, ["-d", "a.bz2"], racy_words=True)
+    assert rc == 1 and set(tree) == {"a.bz2"}

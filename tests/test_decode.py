@@ -127,6 +127,37 @@ def test_damaged_streams_are_refused_with_the_reference_s_error(emu):
             assert emu.lib.lbzamd_last_error_code() in want, (c["name"], emu.lib.lbzamd_last_error_code(), want)
 
 
+def _bytes_in_front_of_the_damage(lib):
+    """A stream of four blocks, a bit flipped inside each block's payload in turn (and in the first block's header, and the
+    stream cut inside the last block): refused, and the bytes handed back with the error are the whole blocks in front of
+    the one that was refused -- a prefix of the data, cut at a block boundary."""
+    data = bytes(gen("text", 350000, 5))
+    z = bz2.compress(data, 1)
+    for where, nblocks in ((0.1, 0), (0.4, 1), (0.7, 2), (0.95, 3)):
+        b = bytearray(z)
+        b[int(len(b) * where)] ^= 0x20
+        with pytest.raises(LbzError) as e:
+            lib.decompress(bytes(b))
+        got = e.value.decoded_in_front
+        assert data.startswith(got) and (len(got) == 0) == (nblocks == 0), (where, len(got))
+        if nblocks:
+            assert abs(len(got) - nblocks * 100000) < 200, (where, len(got))          # whole blocks (a block's decoded size: 100 000 less what its runs save)
+    with pytest.raises(LbzError) as e:
+        lib.decompress(z[:len(z) * 9 // 10])
+    assert data.startswith(e.value.decoded_in_front) and abs(len(e.value.decoded_in_front) - 300000) < 200
+    with pytest.raises(LbzError) as e:                        # a good stream, then one whose STREAM CRC is wrong: its blocks are good, all of it comes back
+        lib.decompress(z + bz2.compress(b"tail", 9)[:-4] + b"\0\0\0\0")
+    assert e.value.decoded_in_front == data + b"tail"
+    bad = bytearray(bz2.compress(b"tail" * 100, 9)); bad[12] ^= 1          # ... and one whose BLOCK CRC is wrong: the first stream's bytes
+    with pytest.raises(LbzError) as e:
+        lib.decompress(z + bytes(bad))
+    assert e.value.decoded_in_front == data
+
+
+def test_bytes_in_front_of_the_damage(emu):
+    _bytes_in_front_of_the_damage(emu)
+
+
 def test_hand_made_blocks_with_random_tables(emu):
     """tests/craft_bz2.py: random_block_streams -- valid streams that no encoder writes (any alphabet, up to six tables of random
     shape with codes of up to 20 bits, a random table per group, runs and counts of every kind): decoded to the bytes they were
@@ -296,6 +327,12 @@ def test_reference_compress_suite_streams_decode_on_the_gpu():
     with lbzip2_amd.library().decoder(64) as d:
         for name, z in suite_streams(1):
             assert d.decompress(z) == bz2.decompress(z), name
+
+
+@pytest.mark.gpu
+def test_bytes_in_front_of_the_damage_on_the_gpu():
+    import lbzip2_amd
+    _bytes_in_front_of_the_damage(lbzip2_amd.library())
 
 
 @pytest.mark.gpu
