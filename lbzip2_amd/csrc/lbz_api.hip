@@ -1200,15 +1200,16 @@ extern "C" int lbzamd_decompress_device(lbzamd_dctx *c, const void *d_in_v, size
            block CRCs, the end of the file), while a block's own status is reported only when the muxer reaches the block
            (:726-735).  So (a) a block that breaks off inside its tables or codes leaves the parser at the bit where
            retrieve() stopped, and what it finds there is not a block magic: ERR_HEADER; (b) an error noticed behind the
-           block's last code (CRC, size against the stream's level) is remembered, the walk goes on, and it is reported only
-           if the parser finds nothing of its own further down (the reference's decompressor suite: crc2). */
-        if (behind_the_block && kernel_ok) {
+           block's last code (CRC, size against the stream's level, origin pointer, empty block) is remembered -- the first such block
+           of the chain --, the walk goes on, and it is reported only if the parser finds nothing of its own further down (the
+           reference's decompressor suite: crc2). */
+        if (behind_the_block) {                                  /* (origin pointer behind the block, empty block: retrieve() has taken the whole block by then) */
           if (!pend_code) { pend_code = dec_error((int)b.err, b.nblock); pend_msg = buf; pend_total = total; }
         } else {
           g_err = buf;
           /* (c) a block whose codes ran past the last byte of the file (what it read there were zeros): retrieve() asked
              for more input and there was none -- ERR_EOF (decode.c:393-399) */
-          g_err_code = behind_the_block ? dec_error((int)b.err, b.nblock) : (b.bit_used > ((uint64_t)len + 3u) / 4u * 32u ? RE_EOF : RE_HEADER);
+          g_err_code = b.bit_used > ((uint64_t)len + 3u) / 4u * 32u ? RE_EOF : RE_HEADER;
           stop = true;
           break;
         }
