@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """bench.py -- the reference's headline metric on MI355X: bzip2 -9 compress throughput.
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W           (N > 1 without WORLD_SIZE: starts its own N ranks, below)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 One "step" = one pass of the hot path (RLE1+CRC -> BWT -> MTF/ZRLE -> prefix codes -> bit
@@ -19,6 +19,11 @@ points of a GNU-manual corpus, bzip2 ratio 4.3 vs enwik9's 3.9).  `--kind text` 
 --scaling strong           ONE 10^9-byte input, slab ranges dealt over the ranks, bodies gathered
                            to rank 0 into ONE stream that is byte-identical to the single-GPU
                            (and the reference's) stream (lbzip2_amd/shard.py, RCCL send/recv).
+
+N > 1: the line's `value` is the weak-scaling figure (per-GPU work fixed) and the same run adds `strong`: rank 0's 10^9-byte
+input dealt over the N ranks as slab ranges and gathered into ONE stream on rank 0, md5 against the reference fixture
+(`strong.value`: ranges resident per GPU; `strong.value_from_rank0`: scatter from rank 0 over xGMI included), `value_host`
+(every rank host buffer -> host buffer at once) and `value_node_file` (the command with --devices=N, file -> file on tmpfs).
 
 After the timed region the stream is copied to the host, hashed and compared with the fixture
 generated from the compiled reference (tests/golden/bench_fixtures.json): "verified": true/false,
@@ -311,7 +316,7 @@ def decode_leg(lib, torch, kind, n, seed, level, local):
             "slowest_block_ms": {"codes": round(ds.ms_huff, 2), "sort": round(ds.ms_sort, 2), "walk": round(ds.ms_walk, 2)}}
 
 
-def file_leg(data, level, fixture):
+def file_leg(data, level, fixture, devices=1):
     """the command (lbzip2_amd/host/lbzamd: lbzip2's options over the batch path, lbzamd_io.c's readers,
     pipelines and writers) file -> file on tmpfs, contexts and page-locked buffers included -- what a user of `lbzip2 FILE`
     waits for.  The stream is checked against the reference fixture; the program's own report line gives the rate behind the
@@ -320,7 +325,7 @@ def file_leg(data, level, fixture):
     import shutil
     import subprocess
     import tempfile
-    exe = os.path.join(ROOT, "lbzip2_amd", "host", "lbzamd")
+    exe = os.environ.get("LBZ_BENCH_LBZAMD") or os.path.join(ROOT, "lbzip2_amd", "host", "lbzamd")
     base = "/dev/shm" if os.path.isdir("/dev/shm") and shutil.disk_usage("/dev/shm").free > 3 * len(data) else tempfile.gettempdir()
     if not os.path.exists(exe):
         return {"skipped": "lbzip2_amd/host/lbzamd is not built"}
@@ -334,7 +339,8 @@ def file_leg(data, level, fixture):
             if os.path.exists(path + ".bz2"):
                 os.unlink(path + ".bz2")
             t0 = time.perf_counter()
-            p = subprocess.run([exe, "-k", "-%d" % level, "--report", path], capture_output=True, timeout=600)
+            p = subprocess.run([exe, "-k", "-%d" % level, "--report"] + (["--devices=%d" % devices] if devices > 1 else []) + [path],
+                               capture_output=True, timeout=600)
             dt = time.perf_counter() - t0
             if p.returncode != 0:
                 return {"error": p.stderr.decode(errors="replace")[-300:]}
@@ -349,8 +355,9 @@ def file_leg(data, level, fixture):
                 "verified": (h.hexdigest() == fixture["canon_md5"]) if fixture else None,
                 "first_context_s": float(m.group(2)) if m else None, "behind_first_context_MBps": int(m.group(3)) if m else None,
                 "report": line,
-                "what": "`lbzamd -k -9 --report FILE` on tmpfs, process start to exit (HIP initialisation, contexts, page-locked ring included); "
-                        "best of two"}
+                "devices": devices,
+                "what": "`lbzamd -k -9 --report%s FILE` on tmpfs, process start to exit (HIP initialisation, contexts, page-locked ring included); "
+                        "best of two" % (" --devices=%d" % devices if devices > 1 else "")}
     finally:
         shutil.rmtree(d, ignore_errors=True)
 
@@ -363,6 +370,90 @@ def find_fixture(kind, n, seed, level):
     except (OSError, ValueError):
         pass
     return None
+
+
+def relaunch(gpus):
+    """`python bench.py --gpus N` as the driver types it for N = 1, with N > 1 and no launcher around it: start the N ranks
+    ourselves (torch.distributed.run, one process per GPU, rendezvous on 127.0.0.1) with the same arguments.  The line rank 0
+    prints is this process's output."""
+    import socket
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")       # RCCL between processes needs dmabuf IPC on this pool
+    env.setdefault("MASTER_ADDR", "127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    sys.stdout.flush()
+    os.execvpe(cmd[0], cmd, env)
+
+
+def strong_leg(args, torch, dist, shard, ctx, src_full, nbytes, dst, rank, world, dev, sync, fixture):
+    """ONE input -> ONE stream over all ranks (north_star; process.c:515-548: N workers behind one splitter and one muxer).
+    Rank 0 holds the input in HBM; the slab ranges of shard_plan go to their ranks (send/recv between device buffers: RCCL over
+    xGMI), every rank compresses its range body-only, the bodies and the 12-byte CRC partials come back to rank 0 (StreamMux).
+    Timed twice, K steps between barriers, max over ranks: with the ranges already resident per GPU (`value`), and with the
+    scatter from rank 0 inside the step (`value_from_rank0`).  The stream is hashed against the reference fixture."""
+    plan = shard.shard_plan(nbytes, world, args.level)
+    off, ln = plan[rank]
+    part = src_full[off:off + ln] if rank == 0 else torch.empty(max(1, ln), dtype=torch.uint8, device=dev)
+    mux = shard.StreamMux(dist, args.level, lib_bound(nbytes), dev)
+
+    def scatter():
+        if rank == 0:
+            ops = [dist.P2POp(dist.isend, src_full[plan[r][0]:plan[r][0] + plan[r][1]], r) for r in range(1, world) if plan[r][1]]
+        else:
+            ops = [dist.P2POp(dist.irecv, part[:ln], 0)] if ln else []
+        if ops:
+            for w in dist.batch_isend_irecv(ops):
+                w.wait()
+
+    def step(with_scatter):
+        if with_scatter:
+            scatter()
+        m, nb, fold = ctx.compress_device_body(part.data_ptr(), ln, dst.data_ptr(), dst.numel())
+        return mux.gather(dst, m, nb, fold)
+
+    def barrier():
+        sync()
+        dist.barrier()
+        sync()
+
+    out = {}
+    scatter()                                       # the ranges are resident from here on
+    for name, ws in (("resident", False), ("from_rank0", True)):
+        for _ in range(max(1, args.warmup)):
+            total = step(ws)
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            total = step(ws)
+        barrier()
+        t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        out[name] = float(t.item()) / args.steps
+    res = None
+    if rank == 0:
+        z = mux.out[:total].cpu().numpy().tobytes()
+        ok = None
+        if fixture is not None and not args.no_verify:
+            ok = len(z) == fixture["out_len"] and hashlib.md5(z).hexdigest() == fixture["canon_md5"]
+        elif not args.no_verify and nbytes <= 300_000_000:
+            import bz2
+            ok = bz2.decompress(z) == bytes(src_full.cpu().numpy().tobytes())
+        res = {"value": round(nbytes / out["resident"] / 1e6, 1), "unit": "MB/s", "ms_per_step": round(out["resident"] * 1e3, 2),
+               "value_from_rank0": round(nbytes / out["from_rank0"] / 1e6, 1), "ms_per_step_from_rank0": round(out["from_rank0"] * 1e3, 2),
+               "steps": args.steps, "scaling": "strong", "out_bytes": total, "verified": ok,
+               "slabs_per_rank": [(l + args.level * 100000 - 1) // (args.level * 100000) for _, l in plan],
+               "what": "ONE %d-byte input -> ONE .bz2 stream on rank 0 over %d ranks: slab ranges by send/recv between device buffers, "
+                       "bodies + 12-byte CRC partials gathered by StreamMux (lbzip2_amd/shard.py); `value`: ranges resident per GPU when "
+                       "the step starts, `value_from_rank0`: the scatter from rank 0 inside the step" % (nbytes, world)}
+    del mux
+    return res
+
+
+lib_bound = None
 
 
 def main():
@@ -385,23 +476,52 @@ def main():
     ap.add_argument("--no-legs", action="store_true", help="skip the other BASELINE configurations (configs)")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        relaunch(args.gpus)                          # does not return
+
+    import datetime
+
     import torch
     import torch.distributed as dist
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
-    assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU path exists)"
-    if os.environ.get("LBZ_BENCH_ONE_DEVICE"):      # tests: several ranks on one device (exercises the collective code path)
-        local = 0
-    torch.cuda.set_device(local)
+    if world != args.gpus:
+        sys.exit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks")
+    # TEST HOOK (tests/test_bench_cpu.py, no GPU in the build container): LBZ_BENCH_EMU=1 runs this file's control flow -- the
+    # launcher, the ranks, the collectives (gloo), the JSON line -- against the emulated kernel build of tests/emu on host
+    # memory.  Never a measurement: the line says "emulated": true and the driver's runs do not set it.
+    emu = bool(os.environ.get("LBZ_BENCH_EMU"))
+    dev = "cpu" if emu else "cuda"
+    if not emu:
+        assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU path exists)"
+        if os.environ.get("LBZ_BENCH_ONE_DEVICE"):      # tests: several ranks on one device (exercises the collective code path)
+            local = 0
+        torch.cuda.set_device(local)
+
+    def sync():
+        if not emu:
+            torch.cuda.synchronize()
+
+    def free_cache():
+        if not emu:
+            torch.cuda.empty_cache()
+
     if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if emu:
+            dist.init_process_group("gloo", timeout=datetime.timedelta(minutes=30))
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local), timeout=datetime.timedelta(minutes=30))
 
     import lbzip2_amd
     from lbzip2_amd import shard
-    lib = lbzip2_amd.library()
+    if emu:
+        lib = lbzip2_amd.Library(os.path.join(ROOT, "tests", "emu", "_build", "liblbzamd_emu_1024.so"))
+    else:
+        lib = lbzip2_amd.library()
+    global lib_bound
+    lib_bound = lib.bound
 
     M = args.level * 100000
     strong = args.scaling == "strong"
@@ -423,10 +543,10 @@ def main():
     nslabs = max(1, (n + M - 1) // M)
     slabs = args.slabs or nslabs
 
-    src = torch.frombuffer(data, dtype=torch.uint8).cuda() if n else torch.empty(0, dtype=torch.uint8, device="cuda")
-    dst = torch.empty(lib.bound(n), dtype=torch.uint8, device="cuda")
+    src = torch.frombuffer(data, dtype=torch.uint8).to(dev) if n else torch.empty(0, dtype=torch.uint8, device=dev)
+    dst = torch.empty(lib.bound(n), dtype=torch.uint8, device=dev)
     ctx = lib.context(args.level, slabs, 0, local)
-    mux = shard.StreamMux(dist if world > 1 else None, args.level, lib.bound(len(full)), "cuda") if strong else None
+    mux = shard.StreamMux(dist if world > 1 else None, args.level, lib.bound(len(full)), dev) if strong else None
 
     def step():
         if strong:
@@ -435,10 +555,17 @@ def main():
         return ctx.compress_device(src.data_ptr(), n, dst.data_ptr(), dst.numel())
 
     def barrier():
-        torch.cuda.synchronize()
+        sync()
         if world > 1:
             dist.barrier()
-        torch.cuda.synchronize()
+        sync()
+
+    def max_over_ranks(seconds):
+        if world == 1:
+            return seconds
+        t = torch.tensor([seconds], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
 
     out_len = 0
     for _ in range(args.warmup):
@@ -459,10 +586,10 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-        o = torch.tensor([0 if strong and rank else out_len, n], dtype=torch.int64, device="cuda")
+        o = torch.tensor([0 if strong and rank else out_len, n], dtype=torch.int64, device=dev)
         dist.all_reduce(o)
         total_out, total_in = int(o[0].item()), int(o[1].item())
     else:
@@ -485,7 +612,7 @@ def main():
             verified_against = "round trip through Python's bz2 (no reference fixture for this workload)"
         verified = ok
     if world > 1 and not strong:
-        v = torch.tensor([1 if verified else 0, 1 if verified is None else 0], dtype=torch.int64, device="cuda")
+        v = torch.tensor([1 if verified else 0, 1 if verified is None else 0], dtype=torch.int64, device=dev)
         dist.all_reduce(v)
         verified = None if int(v[1].item()) == world else int(v[0].item()) + int(v[1].item()) == world
 
@@ -504,9 +631,12 @@ def main():
                               "k_bwt_fix": s1.ms_bwt_fix, "k_mtf": s1.ms_mtf, "k_encode": s1.ms_encode}}
         finally:
             del os.environ["LBZAMD_STREAMS"]
-    if rank == 0 and not args.no_host and world == 1:
-        hin = torch.frombuffer(data, dtype=torch.uint8).pin_memory()
-        hout = torch.empty(lib.bound(n), dtype=torch.uint8).pin_memory()
+    if not args.no_host and not strong:
+        # every rank at once, each its own host buffers: the node's host -> host rate is the sum
+        hin = torch.frombuffer(data, dtype=torch.uint8)
+        hout = torch.empty(lib.bound(n), dtype=torch.uint8)
+        if not emu:
+            hin, hout = hin.pin_memory(), hout.pin_memory()
         for _ in range(max(1, args.warmup)):
             m = ctx.compress_host_ptr(hin.data_ptr(), n, hout.data_ptr(), hout.numel())
         barrier()
@@ -514,26 +644,39 @@ def main():
         for _ in range(args.steps):                          # the protocol of `value`: K steps between barriers, wall clock
             m = ctx.compress_host_ptr(hin.data_ptr(), n, hout.data_ptr(), hout.numel())
         barrier()
-        dth = (time.perf_counter() - th) / args.steps
+        dth = max_over_ranks(time.perf_counter() - th) / args.steps
         ok = m == out_len and (fixture is None or args.no_verify
                                or hashlib.md5(hout[:m].numpy().tobytes()).hexdigest() == fixture["canon_md5"])
-        value_host = {"value": round(n / dth / 1e6, 1), "unit": "MB/s", "ms_per_step": round(dth * 1e3, 2), "steps": args.steps,
-                      "same_stream": bool(ok),
+        if world > 1:
+            v = torch.tensor([1 if ok else 0], dtype=torch.int64, device=dev)
+            dist.all_reduce(v)
+            ok = int(v.item()) == world
+        value_host = {"value": round(total_in / dth / 1e6, 1), "unit": "MB/s", "ms_per_step": round(dth * 1e3, 2), "steps": args.steps,
+                      "same_stream": bool(ok), "ranks": world,
                       "what": "SURVEY 8(d)'s end-to-end form of the metric: pinned host buffer in -> complete .bz2 stream in pinned host "
                               "memory; the input crosses PCIe round by round on one copy stream (issued up front), the stream leaves through the "
-                              "page-locked output buffer as k_gather writes it; timed like `value` (K steps, wall clock)"}
+                              "page-locked output buffer as k_gather writes it; timed like `value` (K steps, wall clock"
+                              + ("; all %d ranks at once, each its own buffers: the sum)" % world if world > 1 else ")")}
+        del hin, hout
+
+    strong_res = None
+    if world > 1 and not strong and not os.environ.get("LBZ_NO_STRONG"):
+        # the same run, the other scaling: rank 0's input over all ranks into ONE stream
+        sfix = find_fixture(args.kind, args.bytes, args.seed, args.level) if "synthetic" in source else None
+        strong_res = strong_leg(args, torch, dist, shard, ctx, src if rank == 0 else None, len(full), dst, rank, world,
+                                dev, sync, sfix)
 
     decode = None
     if rank == 0 and not args.no_decode and world == 1 and not strong:     # (strong: dst holds the body only)
         # the inverse path on the stream just written: every block decoded at once, compared with the input
-        back = torch.empty(n + 64, dtype=torch.uint8, device="cuda")
+        back = torch.empty(n + 64, dtype=torch.uint8, device=dev)
         with lib.decoder(max(8, min(4096, 2 * nslabs + 8))) as dec:
             best = None
             for _ in range(3):
-                torch.cuda.synchronize()
+                sync()
                 td = time.perf_counter()
                 k = dec.decompress_device(dst.data_ptr(), out_len, back.data_ptr(), back.numel())
-                torch.cuda.synchronize()
+                sync()
                 dt = time.perf_counter() - td
                 best = dt if best is None or dt < best else best
             ds = dec.stats()
@@ -545,7 +688,7 @@ def main():
                           "per block (prefix codes on one wave, inverse MTF by chunks on the others, counting sort, list ranking walk, "
                           "CRC), then inverse RLE1 into place; `others`: the same on high-entropy inputs (few blocks: 1024-thread workgroups)"}
         del back
-        torch.cuda.empty_cache()
+        free_cache()
         if not args.no_legs:
             decode["others"] = [decode_leg(lib, torch, "rand", 100_000_000, 2, 9, local), decode_leg(lib, torch, "mixed", 210_000_000, 2, 9, local)]
 
@@ -556,10 +699,10 @@ def main():
             cs.set_sequential(True)
             best = None
             for _ in range(2):
-                torch.cuda.synchronize()
+                sync()
                 tq = time.perf_counter()
                 mq = cs.compress_device(src.data_ptr(), n, dst.data_ptr(), dst.numel())
-                torch.cuda.synchronize()
+                sync()
                 dt = time.perf_counter() - tq
                 best = dt if best is None or dt < best else best
             sq = cs.stats()
@@ -576,17 +719,36 @@ def main():
                       "blocks": sq.nblocks, "verified": okq, "ms_block_chain": round(sq.ms_collect, 2),
                       "what": "lbzip2 -u blocking (blocks cut where they are full): the blocks' first pass is a chain on the device"}
 
+    nslots = ctx.nslots
+    nstreams = int(os.environ.get("LBZAMD_STREAMS", "3"))
+    per_round = min(nslots, nslabs)
+    segs, parts = ctx.round_shape(per_round, nstreams > 1 and nslabs > per_round)     # lbz_api.hip: launch_sort's choice, asked of the library
     value_file = None
     if rank == 0 and not args.no_host and world == 1 and not strong and not os.environ.get("LBZ_NO_FILE_LEG"):
         try:
             value_file = file_leg(data, args.level, fixture)
         except Exception as e:                                   # noqa: BLE001 -- a leg of its own: never the bench line's failure
             value_file = {"error": repr(e)[:200]}
+    value_node_file = None
+    if world > 1 and not args.no_host and not strong and not os.environ.get("LBZ_NO_FILE_LEG"):
+        # the command over all N devices, file -> file: the ranks give their device memory back first (the command's own
+        # contexts take up to half of what is free), rank 0 runs it, the others wait
+        ctx.close()
+        ctx = None
+        del src, dst
+        free_cache()
+        barrier()
+        if rank == 0:
+            try:
+                value_node_file = file_leg(data, args.level, fixture, devices=world)
+            except Exception as e:                               # noqa: BLE001
+                value_node_file = {"error": repr(e)[:200]}
+        barrier()
 
     legs = None
     if rank == 0 and not args.no_legs and world == 1 and not strong and args.kind == "wiki" and args.bytes == 1_000_000_000:
         del src, dst
-        torch.cuda.empty_cache()
+        free_cache()
         legs = [run_leg(lib, torch, *leg, local) for leg in LEGS]
         if not os.environ.get("LBZ_NO_REAL"):
             legs.append(real_leg(lib, torch, "C5 real files: tar of headers and sources", 1_000_000_000, args.level, local))
@@ -596,7 +758,6 @@ def main():
 
     if rank == 0:
         nchunks = (nslabs + slabs - 1) // slabs
-        nslots = ctx.nslots
         rounds = sum(-(-min(slabs, nslabs - i * slabs) // nslots) for i in range(nchunks))
         alg = {"k_collect": st.n_in + st.n_rle, "k_bwt_part": 5.0 * st.n_rle, "k_bwt_batch": 6.0 * st.n_rle, "k_bwt_fix": 6.0 * st.n_rle,
                "k_mtf": st.n_rle + 2.0 * st.n_mtf, "k_encode": 18.0 * st.n_mtf + st.n_out}     # bytes per step
@@ -647,10 +808,6 @@ def main():
         if traffic is not None:
             traffic = round(traffic * launches / max(1, dom_launches * args.steps))      # per launch of the table the fraction comes from
         pipe_alg = st.n_in + 13.0 * st.n_rle + 20.0 * st.n_mtf + st.n_out  # SURVEY 8(d), per step
-        ncus = torch.cuda.get_device_properties(local).multi_processor_count
-        per_round = min(nslots, nslabs)
-        nstreams = int(os.environ.get("LBZAMD_STREAMS", "3"))
-        segs, parts = ctx.round_shape(per_round, nstreams > 1 and nslabs > per_round)     # lbz_api.hip: launch_sort's choice, asked of the library
         res = {
             "metric": "compress MB/s (whole node) + ratio, enwik9 -9, at 1/2/4/8 MI355X",
             "value": round((len(full) if strong else total_in) * args.steps / elapsed / 1e6, 1),
@@ -689,10 +846,19 @@ def main():
             "kernel_ms_per_step": {k: round(v / args.steps, 2) for k, v in kms.items()},
             "sorter": {"blocks": st.nblocks, "periodic_blocks": st.nperiodic},
         }
+        if world > 1:
+            res["rccl_ranks"] = dist.get_world_size()
+            res["backend"] = dist.get_backend() + (" (RCCL: one process per GPU, torch.distributed)" if not emu else " (emulated kernels, host memory)")
+        if emu:
+            res["emulated"] = True
+        if strong_res:
+            res["strong"] = strong_res
         if value_host:
             res["value_host"] = value_host
         if value_file:
             res["value_file"] = value_file
+        if value_node_file:
+            res["value_node_file"] = value_node_file
         if decode:
             res["decode"] = decode
         if sequential:
@@ -702,7 +868,8 @@ def main():
         if not args.no_cpu:
             res["cpu_baseline"] = cpu_baseline(full, args.level)
         print(json.dumps(res), flush=True)
-    ctx.close()
+    if ctx is not None:
+        ctx.close()
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

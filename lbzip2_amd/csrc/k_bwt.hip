@@ -148,6 +148,7 @@ struct bwt_lds {
   u32 bc[16];
   u32 listn, seglo;                   /* k_bwt_batch: entries in the segment's list of tied rows so far; the segment's first row */
   u32 h0min, lmin;                    /* k_bwt_batch: least depth of a tie left for the rank rounds; of a run in the list */
+  u32 cmin, cpad;                     /* k_bwt_batch: least depth of a closed run (wave_finish_chunk) */
   u32 msd_shift, seghi;               /* 64 - the block's partition depth: rows with equal key >> msd_shift form a group; k_bwt_batch: the segment's end */
   u32 dbg[4];                         /* LDS_SORT_TICKS: whole-workgroup batch sorts (count, ticks), oversized groups (count, ticks) */
   u8 cmap[256];                       /* byte -> dense code */
@@ -903,6 +904,36 @@ __device__ void wave_finish_chunk(batch_lds *B, u32 cs, u32 ce, bool need_sort, 
     }
   }
   const u64 tw1 = wall_clock64();
+  /* CLOSED RUNS.  What the stage owes is the byte in front of every row, in row order, and the row of rotation 0 -- not the
+     order of the rows.  A run of tied rows that all have the SAME byte in front of them (and none of which is rotation 0)
+     writes that byte into each of its rows whatever their order: it is finished as it stands, at any depth, and so is every
+     run it could still split into.  On text two thirds of the rows tied on their first key are of that kind (a passage that
+     occurs twice is tied row for row with its copy, and only where the two begin do the bytes in front differ); in a tree of
+     sources nine tenths.  Such a run is not listed; its rows stay tied in the suffix array, where the rank rounds -- the one
+     consumer of that array -- find them should the block need them (deep_closed).  An OPEN run is marked in its first row's
+     `tied` byte (bit 1; every writer stores the same value). */
+  u32 nclosed = 0;
+  if (ntied) {
+    for (u32 j0 = cs; j0 < ce; j0 += 64u) {
+      const u32 j = j0 + lane;
+      if (j < ce && B->tied[j]) {
+        const u32 v = B->vA[j], hd = B->gh[j];
+#ifdef DBG_NOCLOSE_BATCH
+        B->tied[hd] = 3;
+#else
+        if ((v >> 24) != (B->vA[hd] >> 24) || (v & 0x00FFFFFFu) == 0u) B->tied[hd] = 3;
+#endif
+      }
+    }
+    wave_sync();
+    u32 nopen = 0;
+    for (u32 j0 = cs; j0 < ce; j0 += 64u) {
+      const u32 j = j0 + lane;
+      nopen += (u32)__popcll(__ballot(j < ce && B->tied[j] && (B->tied[B->gh[j]] & 2)));
+    }
+    nclosed = ntied - nopen;
+    ntied = nopen;
+  }
   const bwt_slot ls = seg_view(s, S->seglo);
   /* the chunk's tied runs take ONE stretch of the list: the rows of a run must lie side by side there */
   u32 lbase = ntied ? wave_reserve(&S->listn, ntied) : 0u;
@@ -912,11 +943,12 @@ __device__ void wave_finish_chunk(batch_lds *B, u32 cs, u32 ce, bool need_sort, 
     const bool ok = j < ce;
     const u32 v = ok ? B->vA[j] : 0u;
     const u32 idx = v & 0x00FFFFFFu;
-    const bool td = ok && ntied && B->tied[j];
-    const u32 head = td ? (u32)B->gh[j] : j;
+    const bool tdall = ok && (ntied || nclosed) && B->tied[j];           /* tied: in the suffix array */
+    const u32 head = tdall ? (u32)B->gh[j] : j;
+    const bool td = tdall && ntied && (B->tied[head] & 2);                /* ... and of an open run: listed */
     if (ok) {
       bwt[lo + j] = S->inv[v >> 24];
-      s.sa[lo + j] = SA_ENTRY(idx, v >> 24) | ((td && head != j) ? TIE_FLAG : 0u);
+      s.sa[lo + j] = SA_ENTRY(idx, v >> 24) | ((tdall && head != j) ? TIE_FLAG : 0u);
       if (idx == 0u) meta->bwt_idx = lo + j;
     }
     const u64 mask = __ballot(td);
@@ -930,6 +962,7 @@ __device__ void wave_finish_chunk(batch_lds *B, u32 cs, u32 ce, bool need_sort, 
     lbase += (u32)__popcll(mask);
   }
   if (ntied && lane == 0u) { atomicMin(&S->lmin, depth); if (nlong) atomicAdd(&S->bc[9], nlong); }
+  if (nclosed && lane == 0u) atomicMin(&S->cmin, depth);
   if (lane == 0u) {
     const u64 tw2 = wall_clock64();
     atomicAdd(&S->bc[13], (u32)(tw2 - tw0));
@@ -1106,8 +1139,20 @@ __device__ u32 batch_process(const u8 *T, u32 n, u8 *bwt, lbz_block_meta *meta, 
   return cnt;
 }
 
-/* rows [lo,hi) share one 64-bit key and are more than a batch: left to the rank rounds */
-__device__ void emit_tied_rows(u8 *bwt, bwt_slot s, bwt_lds *S, u32 lo, u32 hi, lbz_block_meta *meta, u32 depth)
+/* is the run of equal keys in rows [lo,hi) CLOSED (wave_finish_chunk): the same byte in front of every row, rotation 0 not among them? */
+__device__ bool rows_closed(bwt_slot s, bwt_lds *S, u32 lo, u32 hi)
+{
+  const u32 c0 = s.v0[lo] >> 24;
+  u32 bad = 0;
+  for (u32 j = lo + threadIdx.x; j < hi; j += LBZ_WG) {
+    const u32 v = s.v0[j];
+    if ((v >> 24) != c0 || (v & 0x00FFFFFFu) == 0u) bad = 1u;
+  }
+  return wg_max(bad, &S->sc) == 0u;
+}
+
+/* rows [lo,hi) share one 64-bit key and are more than a batch: left to the rank rounds -- or, a closed run, as they are */
+__device__ void emit_tied_rows(u8 *bwt, bwt_slot s, bwt_lds *S, u32 lo, u32 hi, lbz_block_meta *meta, u32 depth, bool closed = false)
 {
   for (u32 j = lo + threadIdx.x; j < hi; j += LBZ_WG) {
     const u32 v = s.v0[j];
@@ -1115,7 +1160,10 @@ __device__ void emit_tied_rows(u8 *bwt, bwt_slot s, bwt_lds *S, u32 lo, u32 hi, 
     s.sa[j] = SA_ENTRY(v & 0x00FFFFFFu, v >> 24) | (j > lo ? TIE_FLAG : 0u);
     if ((v & 0x00FFFFFFu) == 0u) meta->bwt_idx = j;
   }
-  if (threadIdx.x == 0) { S->bc[8] = 1u; atomicMin(&S->h0min, depth); }
+  if (threadIdx.x == 0) {
+    if (closed) atomicMin(&S->cmin, depth);
+    else { S->bc[8] = 1u; atomicMin(&S->h0min, depth); }
+  }
 #ifdef DEEP_DEBUG
   if (threadIdx.x == 0) printf("emit_tied_rows [%u,%u) depth %u\n", lo, hi, depth);
 #endif
@@ -1209,6 +1257,10 @@ __device__ void big_group(const u8 *T, u32 n, u8 *bwt, lbz_block_meta *meta, bwt
       const u32 cut = find_cut(s.k0, pos, e, 0u, S);
       if (!cut) {
         const u32 end = find_run_end(s.k0, pos, e, hi, 0u, S);
+#ifndef DBG_NOCLOSE_EMIT
+        if (rows_closed(s, S, pos, end)) emit_tied_rows(bwt, s, S, pos, end, meta, c.sy, true);
+        else
+#endif
         if (end - pos <= LONG_RUN_MAX) list_tied_rows(bwt, s, S, pos, end, meta, c.sy);
         else emit_tied_rows(bwt, s, S, pos, end, meta, c.sy);
         pos = end;
@@ -1399,6 +1451,7 @@ struct part_lds {
   u32 bc[16];
   u32 listn, seglo;
   u32 h0min, lmin;
+  u32 cmin, cpad;
   u32 msd_shift, seghi;
   u32 dbg[4];
   u8 cmap[256];
@@ -1443,9 +1496,8 @@ k_bwt_hist(const u8 *Tbase, lbz_block_meta *meta, lbz_layout L, u32 first, u32 c
   lbz_block_meta *M = &meta[blk];
   const u32 n = M->n;
   if (j == 0u && tid == 0) {                  /* the segment workgroups add to these */
-    M->periodic = 0; M->rounds = 0; M->sort_elems = 0; M->deep_rows = 0; M->nseg = 0; M->deep_h0 = 0xFFFFFFFFu; M->deep_skip = 0; M->deep_long = 0;
+    M->periodic = 0; M->rounds = 0; M->sort_elems = 0; M->deep_rows = 0; M->nseg = 0; M->deep_h0 = 0xFFFFFFFFu; M->deep_closed = 0xFFFFFFFFu; M->deep_skip = 0; M->deep_long = 0;
     for (u32 i = 0; i <= LBZ_DEEP_ROUNDS; i++) { M->deep_tot[i] = 0; M->deep_hmin[i] = 0xFFFFFFFFu; }
-    for (u32 i = 0; i < LBZ_BWT_MAXSEGS; i++) M->seg_long[i] = 0;
     M->msd_bits = MSD_BITS;
     for (u32 i = 0; i < 8u; i++) M->ticks[i] = 0;
     for (u32 i = 0; i < 16u; i++) M->fticks[i] = 0;
@@ -1563,6 +1615,7 @@ struct part1_lds {
   u32 bc[16];
   u32 listn, seglo;
   u32 h0min, lmin;
+  u32 cmin, cpad;
   u32 msd_shift, seghi;
   u32 dbg[4];
   u8 cmap[256];
@@ -1582,9 +1635,8 @@ k_bwt_part(const u8 *Tbase, lbz_block_meta *meta, lbz_layout L, u32 first, u32 c
   lbz_block_meta *M = &meta[blk];
   const u32 n = M->n;
   if (tid == 0) {                             /* the sorter's part of the block record: the segment workgroups add to it */
-    M->periodic = 0; M->rounds = 0; M->sort_elems = 0; M->deep_rows = 0; M->nseg = 0; M->deep_h0 = 0xFFFFFFFFu; M->deep_skip = 0; M->deep_long = 0;
+    M->periodic = 0; M->rounds = 0; M->sort_elems = 0; M->deep_rows = 0; M->nseg = 0; M->deep_h0 = 0xFFFFFFFFu; M->deep_closed = 0xFFFFFFFFu; M->deep_skip = 0; M->deep_long = 0;
     for (u32 i = 0; i <= LBZ_DEEP_ROUNDS; i++) { M->deep_tot[i] = 0; M->deep_hmin[i] = 0xFFFFFFFFu; }
-    for (u32 i = 0; i < LBZ_BWT_MAXSEGS; i++) M->seg_long[i] = 0;
     M->msd_bits = MSD_BITS;
     for (u32 i = 0; i < 8u; i++) M->ticks[i] = 0;
     for (u32 i = 0; i < 16u; i++) M->fticks[i] = 0;
@@ -1644,6 +1696,7 @@ struct segs_lds {                       /* bwt_lds up to its union: all the boun
   u32 bc[16];
   u32 listn, seglo;
   u32 h0min, lmin;
+  u32 cmin, cpad;
   u32 msd_shift, seghi;
   u32 dbg[4];
   u8 cmap[256];
@@ -1729,7 +1782,7 @@ k_bwt_batch(const u8 *Tbase, u8 *Bbase, lbz_block_meta *meta, lbz_layout L, u32 
   u32 lo = 0, hi = n;
   if (nseg > 1u) { lo = M->seg_lo[seg]; hi = M->seg_lo[seg + 1u]; }
   if (tid == 0) {
-    S.listn = 0; S.seglo = lo; S.seghi = hi; S.h0min = 0xFFFFFFFFu; S.lmin = 0xFFFFFFFFu;
+    S.listn = 0; S.seglo = lo; S.seghi = hi; S.h0min = 0xFFFFFFFFu; S.lmin = 0xFFFFFFFFu; S.cmin = 0xFFFFFFFFu;
     for (u32 i = 0; i < 4; i++) S.dbg[i] = 0;
   }
   __syncthreads();
@@ -1767,6 +1820,7 @@ k_bwt_batch(const u8 *Tbase, u8 *Bbase, lbz_block_meta *meta, lbz_layout L, u32 
     M->seg_m[seg] = S.listn;                   /* short runs: the text rounds' list */
     if (S.listn) { atomicAdd(&M->deep_tot[0], S.listn); atomicMin(&M->deep_hmin[0], S.lmin); }
     if (S.bc[9]) atomicAdd(&M->deep_long, S.bc[9]);
+    if (S.cmin != 0xFFFFFFFFu) atomicMin(&M->deep_closed, S.cmin);
     atomicAdd(&M->deep_rows, S.listn);
     atomicAdd(&M->sort_elems, hi - lo);
     /* diagnostics, summed over the block's segments (tests/tools/quickperf.py) */
@@ -1821,7 +1875,7 @@ struct deep_wave {
 };
 struct deep_lds {
   wg_scratch sc;
-  u32 ticket, outn, h0min, bad;
+  u32 ticket, outn, h0min, bad, cmin;
   u8 inv[256];
   deep_wave w[LBZ_NW];
 };
@@ -1913,6 +1967,28 @@ __device__ __forceinline__ u32 deep_longest_run(u32 hl, u32 lane)
   return wave_max(hl == lane ? he - lane : 0u);
 }
 
+/* CLOSED RUNS in a strip (see wave_finish_chunk): a run whose rows all have the same byte in front of them, rotation 0 not among
+ * them, is finished whatever order its rows are in.  Called when the strip's runs have just split: the rows of such a run stop
+ * being `tied` (they take no further steps and are not listed again) and are closed (their output keeps them tied in the
+ * suffix array, for the rank rounds should the block come to need them: a row that is not tied but not alone in its run).  Runs
+ * only split, and every part of a closed run is closed, so the answer is taken afresh from the rows as they stand. */
+__device__ __forceinline__ void deep_close(u32 val, u32 hl, u32 lane, bool in, bool &tied)
+{
+  const u32 code = SA_CODE(val);
+  const u32 hcode = (u32)__shfl((int)code, (int)hl);                  /* the byte in front of the run's first row */
+  const u64 bad = __ballot(in && (code != hcode || SA_IDX(val) == 0u));
+  const u64 hm = __ballot(hl == lane);                                 /* first lanes of the runs as they stand */
+  const u64 above = lane == 63u ? 0ull : hm >> (lane + 1u);
+  const u32 he = above ? lane + 1u + (u32)__builtin_ctzll(above) : 64u;
+  const u64 runmask = (he == 64u ? ~0ull : (1ull << he) - 1ull) & ~((1ull << hl) - 1ull);
+#ifdef DBG_NOCLOSE_STRIP
+  const bool open = true;
+#else
+  const bool open = (bad & runmask) != 0ull;
+#endif
+  tied = tied && open;
+}
+
 /* text of rotation idx from symbol d on: 16 bytes, memory order (first symbol in the low byte of .a) */
 __device__ __forceinline__ u64x2 deep_load16(const u8 *T, u32 n, u32 idx, u32 d)
 {
@@ -1957,131 +2033,6 @@ __device__ __forceinline__ void deep_publish(deep_ranks R, u32 idx, u32 rank, u3
 
 struct deep_lists { const u32 *sin, *gin, *din; u32 *sout, *gout, *dout; };
 
-/* A piece of 64 .. DEEP_MID rows of a long run, ordered in ONE pass (round 5; k_bwt_long only).  The counting split below takes a piece apart one
- * symbol at a time -- common prefix, count, scan, placement: four latency-bound phases of 3-5 us each whatever the piece's
- * size -- and an average piece of a text block is 190 rows (profiles/r05_deep_ticks.txt: 2 600 pieces and 490 000 piece-rows
- * per block, 43 % of a text launch's wave time).  Here the piece's rows (four per lane) fetch their next 16 bytes once; the
- * symbols ALL of them share are skipped (lc, as below), the next up to seven become a 56-bit key with the row's place in the
- * piece in the low byte -- unique, so a row's new place is the number of smaller keys, counted against every key of the
- * piece at a broadcast LDS address (two keys a read, sixteen compare-and-add pairs for a lane's four rows).  The keys sit
- * where the split's counters do, the rows where its offsets do.  Rows alone with their key are final; the others -- tied on
- * up to seven more symbols, in sub-runs of any length -- go to the next list.  Returns false if the piece has to go the
- * other way (fewer than 16 symbols left in front of the block's end). */
-#ifndef DEEP_MID
-#define DEEP_MID 256u
-#endif
-__device__ __forceinline__ bool deep_mid_run(deep_wave *W, u32 lane, const u32 *src, u32 len, u32 d, u32 r0, u32 rank0, bool moved,
-                                             deep_lists Ls, const u8 *T, u32 n, u32 *sa, u8 *bwt, const u8 *inv, lbz_block_meta *M,
-                                             u32 *outn, u32 &hmin, bool late, deep_ranks R)
-{
-  const u32 nq = (len + 63u) >> 6;                         /* strips the piece fills (wave-uniform): 2 .. 4 */
-  u32 v4[4];
-  u64x2 x4[4];
-#pragma unroll
-  for (u32 q = 0; q < 4u; q++) { const u32 k = 64u * q + lane; v4[q] = src[k < len ? k : 0u]; }
-  /* symbols every row shares with the piece's first row: 16 at a time while all of them are shared (at most 64: a
-     template that a hundred rows share for 60 symbols costs four 16-byte steps, as in the counting split) */
-  u32 lc = 16u;
-  for (u32 it = 0; it < 4u; it++) {
-    if (d + 16u > n) return false;
-#pragma unroll
-    for (u32 q = 0; q < 4u; q++) x4[q] = deep_load16(T, n, SA_IDX(v4[q]), d);
-    const u64 ra = (u64)(u32)__builtin_amdgcn_readfirstlane((int)(u32)x4[0].x) | (u64)(u32)__builtin_amdgcn_readfirstlane((int)(u32)(x4[0].x >> 32)) << 32;
-    const u64 rb = (u64)(u32)__builtin_amdgcn_readfirstlane((int)(u32)x4[0].y) | (u64)(u32)__builtin_amdgcn_readfirstlane((int)(u32)(x4[0].y >> 32)) << 32;
-    lc = 16u;
-#pragma unroll
-    for (u32 q = 0; q < 4u; q++) {
-      const u64 xa = x4[q].x ^ ra, xb = x4[q].y ^ rb;
-      const u32 l = xa ? (u32)__builtin_ctzll(xa) >> 3 : (xb ? 8u + ((u32)__builtin_ctzll(xb) >> 3) : 16u);
-      if (64u * q + lane < len) lc = l < lc ? l : lc;
-    }
-    lc = wave_min(lc);
-    if (lc < 16u || it == 3u) break;
-    d += 16u;
-  }
-  const u32 nsym = 16u - lc < 7u ? 16u - lc : 7u;          /* symbols the key holds; 0: the piece shares all 16 */
-  u64 *K = reinterpret_cast<u64 *>(W->cnt);                /* cnt[256] + fill[256]: 256 keys */
-  u32 *V = reinterpret_cast<u32 *>(W->base);               /* base[256] + obase[256]: 256 rows */
-  u64 key[4];
-#pragma unroll
-  for (u32 q = 0; q < 4u; q++) {
-    const u32 k = 64u * q + lane;
-    const u64 hi = __builtin_bswap64(x4[q].x), lw = __builtin_bswap64(x4[q].y);      /* big-endian: integer order = string order */
-    /* the 128 bits shifted left by lc symbols, top 56 of them */
-    const u32 sh = 8u * lc;
-    const u64 top = sh == 0u ? hi : (sh < 64u ? (hi << sh) | (lw >> (64u - sh)) : (sh == 64u ? lw : lw << (sh - 64u)));
-    const u64 mask = nsym >= 7u ? ~0xFFull : (nsym == 0u ? 0ull : ~((1ull << (64u - 8u * nsym)) - 1ull));   /* (nsym = 0: 64 shared symbols and counting -- the piece goes on as it is) */
-    key[q] = k < len ? ((top & mask) & ~0xFFull) | (u64)k : ~0ull;
-    K[k] = key[q];
-  }
-  wave_sync();
-  u32 pos[4] = { 0u, 0u, 0u, 0u };
-  {
-    const u64x2 *kp = reinterpret_cast<const u64x2 *>(K);
-    const u32 pairs = (len + 1u) >> 1;
-    for (u32 j0 = 0; j0 < pairs; j0 += 4u) {               /* eight keys a trip: four broadcast reads in flight (registers: a wave more per SIMD is worth more than the reads) */
-      u64x2 c2[4];
-#pragma unroll
-      for (u32 t = 0; t < 4u; t++) c2[t] = kp[j0 + t < 128u ? j0 + t : 127u];
-#pragma unroll
-      for (u32 t = 0; t < 4u; t++) {
-        if (j0 + t < pairs) {
-#pragma unroll
-          for (u32 q = 0; q < 4u; q++) if (q < nq) pos[q] = add_if_less2(pos[q], c2[t].x, c2[t].y, key[q]);
-        }
-      }
-    }
-  }
-  wave_sync();                                             /* every lane has read the keys: their column is written in order now */
-#pragma unroll
-  for (u32 q = 0; q < 4u; q++) if (64u * q + lane < len) { K[pos[q]] = key[q] >> 8; V[pos[q]] = v4[q]; }
-  wave_sync();
-  /* the sorted piece: sub-runs of equal keys */
-  const u32 dnew = d + lc + nsym;
-  u32 hq[4], val[4];
-  bool td[4];
-  u32 carry = 0u, ntied = 0u;
-#pragma unroll
-  for (u32 q = 0; q < 4u; q++) {
-    const u32 k = 64u * q + lane;
-    const bool ok = k < len;
-    const u64 sk = ok ? K[k] : 0ull;
-    const bool head = ok && (k == 0u || K[k - 1u] != sk);
-    const bool nexthead = !ok || k + 1u >= len || K[k + 1u] != sk;
-    u32 h = wave_incl_max(head ? k : 0u);
-    if (h < carry) h = carry;
-    carry = (u32)__builtin_amdgcn_readlane((int)h, 63);
-    hq[q] = h;
-    td[q] = ok && !(head && nexthead);
-    val[q] = ok ? V[k] : 0u;
-    ntied += (u32)__popcll(__ballot(td[q]));
-  }
-  u32 ob = ntied ? wave_reserve(outn, ntied) : 0u;
-#pragma unroll
-  for (u32 q = 0; q < 4u; q++) {
-    const u32 k = 64u * q + lane;
-    const u64 tm = __ballot(td[q]);
-    if (k < len) {
-      const u32 row = r0 + k, rank = r0 + hq[q];
-      if (!td[q] || late) {
-        sa[row] = val[q] | ((td[q] && hq[q] != k) ? TIE_FLAG : 0u);
-        if (!td[q]) bwt[row] = inv[SA_CODE(val[q])];
-        if (SA_IDX(val[q]) == 0u) M->bwt_idx = row;
-      }
-      if (td[q]) {
-        const u32 o = ob + (u32)__popcll(tm & lanes_below());
-        Ls.sout[o] = val[q]; Ls.gout[o] = rank; Ls.dout[o] = dnew;
-        if (R.build) deep_publish(R, SA_IDX(val[q]), rank, dnew);
-      }
-      if (R.live && (moved || hq[q] != 0u)) R.isa[SA_IDX(val[q])] = ISA_ENTRY_D(rank, rank0, R.tag, dnew);   /* final for this launch: its rank changed */
-    }
-    ob += (u32)__popcll(tm);
-  }
-  if (ntied) hmin = dnew < hmin ? dnew : hmin;
-  wave_sync();
-  return true;
-}
-
 /* A run of g >= 64 tied rows (list entries [p, p + g)): too long for a strip.  Its wave takes it apart symbol by symbol:
  * it finds how many further symbols ALL rows of the piece share (compared with the piece's first row, 16 bytes a step, up
  * to 64), then splits the piece on the first symbol they do not all share -- a counting sort on one byte whose only state
@@ -2098,9 +2049,8 @@ __device__ __forceinline__ bool deep_mid_run(deep_wave *W, u32 lane, const u32 *
  * over the piece's keys in LDS -- halves the long runs' wave time (46.9 -> 26.3 ms per block) and costs 24 vector registers:
  * at five waves a SIMD the tie stages gain 2-4 % on text and lose 2 % on sources, at four they lose 8 %.  So k_bwt_deep
  * runs this without it (MID = false); k_bwt_long, the long runs in a launch of their own, with it.)                          */
-template <bool MID>
 __device__ void deep_big_run(deep_wave *W, u32 lane, u32 p, u32 g, deep_lists Ls, u32 *ping, u32 *pong, const u8 *T, u32 n,
-                             u32 *sa, u8 *bwt, const u8 *inv, lbz_block_meta *M, u32 *outn, u32 &hmin, bool late, deep_ranks R)
+                             u32 *sa, u8 *bwt, const u8 *inv, lbz_block_meta *M, u32 *outn, u32 &hmin, u32 *cminp, bool late, deep_ranks R)
 {
   const u32 rank0 = Ls.gin[p];
   const u32 d0 = Ls.din[p];
@@ -2119,7 +2069,6 @@ __device__ void deep_big_run(deep_wave *W, u32 lane, u32 p, u32 g, deep_lists Ls
     const u32 *src = (buf ? pong : ping) + p + off;
     u32 *dst = (buf ? ping : pong) + p + off;
     const u32 r0 = rank0 + off;                         /* the piece's rows are consecutive from here */
-    if (MID && len <= DEEP_MID && deep_mid_run(W, lane, src, len, d, r0, rank0, off != 0u, Ls, T, n, sa, bwt, inv, M, outn, hmin, late, R)) continue;
     const u32 idx0 = SA_IDX(src[0]);
     bool split = false;
 #ifdef DEEP_TICKS
@@ -2162,7 +2111,7 @@ __device__ void deep_big_run(deep_wave *W, u32 lane, u32 p, u32 g, deep_lists Ls
           if (SA_IDX(val) == 0u) M->bwt_idx = r0 + k;
         }
         if (R.build) deep_publish(R, SA_IDX(val), r0, d);
-        else if (R.live && off) R.isa[SA_IDX(val)] = ISA_ENTRY_D(r0, rank0, R.tag, d);
+        else if (R.live && (off || d != d0)) R.isa[SA_IDX(val)] = ISA_ENTRY_D(r0, rank0, R.tag, d);
       }
       hmin = d < hmin ? d : hmin;
       wave_sync();
@@ -2181,30 +2130,49 @@ __device__ void deep_big_run(deep_wave *W, u32 lane, u32 p, u32 g, deep_lists Ls
 #pragma unroll
         for (u32 q = 0; q < 4u; q++) { u32 at = SA_IDX(v4[q]) + d; if (at >= n) at -= n; b4[q] = T[at]; }
       }
+      /* closed sub-runs (deep_close): a value's rows all have the same byte in front of them iff the sum of those bytes' codes is
+         rows x the largest code; rotation 0 counts as a code of its own.  The sum rides above the row count (13 bits: a run in a
+         list has at most LONG_RUN_MAX = 4096 rows), exact up to 2048 rows -- a longer sub-run is taken for open */
 #pragma unroll
-      for (u32 q = 0; q < 4u; q++) if (k0 + 64u * q + lane < len) atomicAdd(&W->cnt[b4[q]], 1u);
+      for (u32 q = 0; q < 4u; q++)
+        if (k0 + 64u * q + lane < len) {
+          const u32 code = SA_CODE(v4[q]);
+          atomicAdd(&W->cnt[b4[q]], 1u | (code << 13));
+          atomicMax(&W->fill[b4[q]], SA_IDX(v4[q]) == 0u ? 256u : code);
+        }
     }
     wave_sync();
 #ifdef DEEP_TICKS
     const u64 tb2 = wall_clock64();
 #endif
     u32 shorttot;
+    bool anyclosed = false;
     {
       u32 c[4], t[4];
-      bool pushed[4];
+      bool pushed[4], clo[4];
       u32 sum = 0, tsum = 0;
 #pragma unroll
       for (u32 q = 0; q < 4u; q++) {
-        c[q] = W->cnt[4u * lane + q];
+        const u32 cw = W->cnt[4u * lane + q], mx = W->fill[4u * lane + q];
+        c[q] = cw & 0x1FFFu;
+#ifdef DBG_NOCLOSE_BIG
+        clo[q] = false;
+#else
+        clo[q] = c[q] > 1u && c[q] <= 2048u && mx < 256u && (cw >> 13) == c[q] * mx;
+#endif
+        anyclosed |= clo[q];
         pushed[q] = false;
-        if (c[q] > BIG_RUN) {                           /* a piece again, if the stack has room: else it goes to the next list as a long run */
+        if (c[q] > BIG_RUN && !clo[q]) {                /* a piece again, if the stack has room: else it goes to the next list as a long run */
           const u32 at = atomicAdd(&W->sp, 1u);
           pushed[q] = at < DEEP_STACK;
           if (pushed[q]) { W->st_len[at] = c[q]; W->st_dep[at] = d + 1u; W->st_buf[at] = (buf ^ 1u) | ((level + 1u) << 1); W->st_off[at] = 4u * lane + q; /* the value: its offset follows */ }
         }
-        t[q] = (c[q] > 1u && !pushed[q]) ? c[q] : 0u;
+        t[q] = (c[q] > 1u && !pushed[q] && !clo[q]) ? c[q] : 0u;
         sum += c[q]; tsum += t[q];
       }
+      wave_sync();                                     /* every lane has read its counters: they become plain counts (bit 31: closed), the slots start at zero */
+#pragma unroll
+      for (u32 q = 0; q < 4u; q++) { W->cnt[4u * lane + q] = c[q] | (clo[q] ? 0x80000000u : 0u); W->fill[4u * lane + q] = 0u; }
       const u32 tin = wave_incl_add(tsum);
       u32 ex = wave_incl_add(sum) - sum, tex = tin - tsum;
       shorttot = (u32)__builtin_amdgcn_readlane((int)tin, 63);
@@ -2242,17 +2210,18 @@ __device__ void deep_big_run(deep_wave *W, u32 lane, u32 p, u32 g, deep_lists Ls
         if (k0 + 64u * q + lane >= len) continue;
         const u32 val = v4[q], by = b4[q];
         const u32 slot = atomicAdd(&W->fill[by], 1u);
-        const u32 c = W->cnt[by], b0 = (u32)W->base[by];
+        const u32 cw = W->cnt[by], c = cw & 0x7FFFFFFFu, b0 = (u32)W->base[by];
+        const bool fin = c == 1u || (cw >> 31);          /* alone with its value, or of a closed sub-run: final */
         const u32 row = r0 + b0 + slot;
-        if (c == 1u || late) {                           /* see the strips' output */
+        if (fin || late) {                               /* see the strips' output */
           sa[row] = val | ((c > 1u && slot) ? TIE_FLAG : 0u);
-          if (c == 1u) bwt[row] = inv[SA_CODE(val)];
+          if (fin) bwt[row] = inv[SA_CODE(val)];
           if (SA_IDX(val) == 0u) M->bwt_idx = row;
         }
         if (W->obase[by] == 0xFFFFu) {
           dst[b0 + slot] = val;
         } else {
-          if (c > 1u) {
+          if (c > 1u && !(cw >> 31)) {
             const u32 o = ob + (u32)W->obase[by] + slot;
             Ls.sout[o] = val; Ls.gout[o] = r0 + b0; Ls.dout[o] = d + 1u;
             if (R.build) deep_publish(R, SA_IDX(val), r0 + b0, d + 1u);
@@ -2262,6 +2231,7 @@ __device__ void deep_big_run(deep_wave *W, u32 lane, u32 p, u32 g, deep_lists Ls
       }
     }
     if (shorttot) hmin = d + 1u < hmin ? d + 1u : hmin;
+    if (__ballot(anyclosed) && lane == 0u) atomicMin(cminp, d + 1u);
     __threadfence_block();                              /* dst is read back by this wave from the next piece on */
     wave_sync();
 #ifdef DEEP_TICKS
@@ -2326,7 +2296,6 @@ __device__ __forceinline__ void deep_body(deep_lds &S, const u8 *Tbase, u8 *Bbas
   }
   const u32 m = M->seg_m[seg];
   if (m == 0u) return;
-  const bool longdone = (handover >> 31) != 0u;
   const u64 tk0 = wall_clock64();
   const u32 tid = threadIdx.x, lane = lane_id();
   const u32 lo = M->seg_lo[seg];
@@ -2345,7 +2314,7 @@ __device__ __forceinline__ void deep_body(deep_lds &S, const u8 *Tbase, u8 *Bbas
     const u32 ex = wg_excl_add(f, &tot, &S.sc);
     if (tot > 128u) { if (tid < 256u) S.inv[tid] = (u8)tid; }       /* bwt_setup's rule */
     else if (f) S.inv[ex] = (u8)tid;
-    if (tid == 0) { S.ticket = 0; S.outn = longdone ? M->seg_long[seg] : 0u; S.h0min = 0xFFFFFFFFu; S.bad = 0; }   /* k_bwt_long's runs are in the next list already */
+    if (tid == 0) { S.ticket = 0; S.outn = 0u; S.h0min = 0xFFFFFFFFu; S.bad = 0; S.cmin = 0xFFFFFFFFu; }
     __syncthreads();
   }
   deep_wave *W = &S.w[wave_id()];
@@ -2368,7 +2337,7 @@ __device__ __forceinline__ void deep_body(deep_lds &S, const u8 *Tbase, u8 *Bbas
   const bool late = round + 1u == DEEP_ROUNDS || round + 1u == DEEP_HANDOVER;   /* what is tied after this launch may be for the rank rounds: they read the suffix array */
   const u32 chunk = m < 16u * DEEP_CHUNK ? 64u : DEEP_CHUNK;    /* a short list (the late launches: long repeats, a strip's steps are a chain of
                                                                    round trips) is dealt out a strip at a time */
-  u32 hmin = 0xFFFFFFFFu;
+  u32 hmin = 0xFFFFFFFFu;                               /* least depth of a run that stays tied (in the next list) */
   for (;;) {
     const u32 a = wave_claim(&S.ticket) * chunk;
     if (a >= m) break;
@@ -2390,6 +2359,7 @@ __device__ __forceinline__ void deep_body(deep_lds &S, const u8 *Tbase, u8 *Bbas
       u32 val = have ? sin[k] : 0u;
       const u32 g = have ? gin[k] : 0xFFFFFFFFu - lane;
       u32 d = have ? din[k] : 0u;
+      const u32 dstart = d;
       const u32 gbelow = lane_from_below(g);
       const bool head0 = lane == 0u || g != gbelow;
       u32 hl = wave_incl_max(head0 ? lane : 0u);
@@ -2405,7 +2375,7 @@ __device__ __forceinline__ void deep_body(deep_lds &S, const u8 *Tbase, u8 *Bbas
           if (df) { len += (u32)__ffsll((long long)df) - 1u; break; }
           len += 64u;
         }
-        if (!longdone) deep_big_run<false>(W, lane, p, len, Ls, const_cast<u32 *>(sin), s.v0 + lo, T, n, s.sa, bwt, S.inv, M, &S.outn, hmin, late, R);
+        deep_big_run(W, lane, p, len, Ls, const_cast<u32 *>(sin), s.v0 + lo, T, n, s.sa, bwt, S.inv, M, &S.outn, hmin, &S.cmin, late, R);
         p += len;
         DT_MARK(t9); DT_ADD(tkb, t0, t9);
         continue;
@@ -2419,7 +2389,7 @@ __device__ __forceinline__ void deep_body(deep_lds &S, const u8 *Tbase, u8 *Bbas
       if (in && R.live) R.isa[SA_IDX(val)] = ISA_ENTRY_D(g, g, 0u, d);
       const u32 row = g + (lane - hl);                  /* places are fixed: the run's rows are consecutive from its rank on */
       if (!in) hl = lane;
-      bool tied = in, longmode = false;
+      bool tied = in, longmode = false;                  /* (the runs of a list are open: whoever listed them saw to that) */
       u64 k2 = 0;
       DT_MARK(t1); DT_ADD(tks, t0, t1);
       for (u32 step = 0; step < kmax; step++) {
@@ -2445,7 +2415,11 @@ __device__ __forceinline__ void deep_body(deep_lds &S, const u8 *Tbase, u8 *Bbas
             const u64 e = R.isa[at];
             const bool fresh = ISA_TAG(e) == R.tag;
             s1 = (u64)isa_before(e, R.tag);
-            k2 = (u64)(fresh ? R.hcur : (ISA_DEPTH(e) > R.hcur ? ISA_DEPTH(e) : R.hcur));      /* travels with the row */
+            /* the depth of the run the target was in when this launch began: a fresh entry's note belongs to the run it has just become
+               part of, but the row was in this launch's list (depth >= hcur); any other note was written before the launch began and
+               is a lower bound as it stands -- NOT to be raised to hcur: the target may have left the lists in a closed run, tied for
+               good at the depth it had then */
+            k2 = (u64)(fresh ? R.hcur : ISA_DEPTH(e));      /* travels with the row */
           }
           bool tsort = useT;                            /* the text runs take a slice of their next 16 bytes -- unless all agree on them */
           if (__ballot(useT)) {
@@ -2491,6 +2465,7 @@ __device__ __forceinline__ void deep_body(deep_lds &S, const u8 *Tbase, u8 *Bbas
           deep_stage(W, lane, cut, s1, val, k2, hl, tied);
           if (__ballot(tied && tsort))                  /* useR, tsort belong to the place: runs only split */
             deep_stage(W, lane, cut, tsort ? k2 : 0ull, val, k2, hl, tied);
+          deep_close(val, hl, lane, in, tied);
           /* rows that stay tied after a rank step looked up rotations of ONE run: either's note of its depth is a lower
              bound of that run's */
           W->val[lane] = (u32)k2;
@@ -2541,9 +2516,15 @@ __device__ __forceinline__ void deep_body(deep_lds &S, const u8 *Tbase, u8 *Bbas
         const u64 hi = __builtin_bswap64(xa), lw = __builtin_bswap64(xb);        /* big-endian: integer order = string order */
         k2 = can ? ((hi & 0xFFFull) << 40) | (lw >> 24) : 0ull;
         deep_stage(W, lane, cut, can ? hi >> 12 : 0ull, val, k2, hl, tied);
-        if (__ballot(tied && can))                      /* can is a property of the place: runs only split */
+        deep_close(val, hl, lane, in, tied);
+        const bool second = __ballot(tied && can) != 0ull;      /* can is a property of the place: runs only split */
+        if (second) {
           deep_stage(W, lane, cut, k2, val, k2, hl, tied);
-        if (can) d += DEEP_STEP;
+          deep_close(val, hl, lane, in, tied);
+        }
+        /* (no second slice: whatever is still side by side is a closed run, ordered on 52 bits -- six whole symbols; the depth a
+           closed run is left at is where the rank rounds would start, and what the rank steps of the later launches add) */
+        if (can) d += second ? DEEP_STEP : 6u;
       }
 #ifdef DEEP_DEBUG
       if (in && (row == 3902u || row == 3903u)) printf("round %u row %u lane %u cut %u idx %u d %u tied %d hl %u g %u p %u a %u e %u m %u\n", round, row, lane, cut, SA_IDX(val), d, (int)tied, hl, g, p, a, e, m);
@@ -2552,12 +2533,22 @@ __device__ __forceinline__ void deep_body(deep_lds &S, const u8 *Tbase, u8 *Bbas
       /* a row that became unique is final: its BWT byte and its suffix-array entry.  A row that is still tied is written
          again by whoever orders it; only the last launch leaves the suffix array current for the rank rounds */
       if (in && (!tied || late)) {
-        s.sa[row] = val | ((tied && hl != lane) ? TIE_FLAG : 0u);
+        s.sa[row] = val | (hl != lane ? TIE_FLAG : 0u);           /* (a row that is neither tied nor closed is its run's first lane) */
         if (!tied) bwt[row] = S.inv[SA_CODE(val)];
         if (SA_IDX(val) == 0u) M->bwt_idx = row;
       }
+      {                                                 /* closed rows: not tied, not alone in their run; the least depth of such a run */
+        const u64 hmf = __ballot(hl == lane);
+        const bool clo = in && !tied && (hl != lane || (lane < 63u && !((hmf >> (lane + 1u)) & 1ull)));
+        if (__ballot(clo)) {
+          const u32 cm = wave_min(clo ? d : 0xFFFFFFFFu);
+          if (lane == 0u) atomicMin(&S.cmin, cm);
+        }
+      }
       const u32 newrank = row - (lane - hl);
-      if (in && R.live && newrank != g) R.isa[SA_IDX(val)] = ISA_ENTRY_D(newrank, g, R.tag, d);
+      /* (a row that stays tied and has gained depth without a change of rank -- a long repeat -- notes the depth too: the next
+         launch's readers may come before its strip's refresh) */
+      if (in && R.live && (newrank != g || (tied && d != dstart))) R.isa[SA_IDX(val)] = ISA_ENTRY_D(newrank, g, R.tag, d);
       const u64 tm = __ballot(tied);
       if (tm) {
         const u32 base = wave_reserve(&S.outn, (u32)__popcll(tm));
@@ -2586,7 +2577,7 @@ __device__ __forceinline__ void deep_body(deep_lds &S, const u8 *Tbase, u8 *Bbas
   __syncthreads();
   if (tid == 0) {
     M->seg_m[seg] = S.outn;
-    if (longdone) M->seg_long[seg] = 0u;              /* (for the k_bwt_long launch in front of the next k_bwt_deep) */
+    if (S.cmin != 0xFFFFFFFFu) atomicMin(&M->deep_closed, S.cmin);
     if (S.bad) M->err = 7u;
     if (S.outn) { atomicAdd(&M->deep_tot[round + 1u], S.outn); atomicMin(&M->deep_hmin[round + 1u], S.h0min); }
     if (round + 1u == DEEP_ROUNDS && S.outn) { atomicMax(&M->periodic, LBZ_TIES_LATE); atomicMin(&M->deep_h0, S.h0min); }
@@ -2598,7 +2589,7 @@ __device__ __forceinline__ void deep_body(deep_lds &S, const u8 *Tbase, u8 *Bbas
   }
 }
 
-__global__ void __launch_bounds__(LBZ_WG, 4)
+__global__ void __launch_bounds__(LBZ_WG, 6)          /* six waves a SIMD: at most 80 vector registers (five cost the text rounds 3-4 %) */
 k_bwt_deep(const u8 *Tbase, u8 *Bbase, lbz_block_meta *meta, lbz_layout L, u32 first, u32 count, u32 nblk, u32 segs,
            u8 *ws, u64 slot_bytes, u8 *ws_spill, u64 spill_bytes, const u32 *slabs, u32 round, u32 handover)
 {
@@ -2606,7 +2597,7 @@ k_bwt_deep(const u8 *Tbase, u8 *Bbase, lbz_block_meta *meta, lbz_layout L, u32 f
   deep_body<false>(S, Tbase, Bbase, meta, L, first, count, nblk, segs, ws, slot_bytes, ws_spill, spill_bytes, slabs, round, handover);
 }
 
-__global__ void __launch_bounds__(LBZ_WG, 4)
+__global__ void __launch_bounds__(LBZ_WG, 6)          /* six waves a SIMD: at most 80 vector registers (five cost the text rounds 3-4 %) */
 k_bwt_deepr(const u8 *Tbase, u8 *Bbase, lbz_block_meta *meta, lbz_layout L, u32 first, u32 count, u32 nblk, u32 segs,
             u8 *ws, u64 slot_bytes, u8 *ws_spill, u64 spill_bytes, const u32 *slabs, u32 round, u32 handover)
 {
@@ -2614,123 +2605,6 @@ k_bwt_deepr(const u8 *Tbase, u8 *Bbase, lbz_block_meta *meta, lbz_layout L, u32 
   deep_body<true>(S, Tbase, Bbase, meta, L, first, count, nblk, segs, ws, slot_bytes, ws_spill, spill_bytes, slabs, round, handover);
 }
 
-/* The long runs (64 rows and more) of text launch `round`, in a launch of their own IN FRONT of it (round 5; launch_sort: the
- * launches up to DEEP_BUILD, where nine tenths of the long runs' rows are).  Same lists, same hand-over rule as k_bwt_deep; what
- * lies between two run heads 64 or more entries apart goes through deep_big_run -- WITH the one-pass ordering of pieces of up
- * to DEEP_MID rows (deep_mid_run), which costs 24 vector registers that the strips' kernel cannot spare (a wave less per SIMD
- * there cost more than the pieces gained: DESIGN 3.2, 4) and this kernel can.
- * A long run is one wave's job, a chain of round trips (" of the ", four thousand rows: thirty pieces one after the other), and
- * next to the strips of its workgroup's other waves that did not matter.  Alone it does: with k_bwt_deep's workgroups of four
- * waves three of them held their places idle while the fourth worked (measured: a quarter of the wave slots busy, the launch
- * longer than what it took out of k_bwt_deep).  So a workgroup here is ONE wave: LONG_SUB of them per segment, each walks its
- * share of the segment's list (256 entries a trip) and is gone when its own runs are done.
- * The runs they leave tied are the first entries of the next list; they count them in seg_long[seg] (zero when the launch
- * begins: k_bwt_part / the k_bwt_deep launch before), where k_bwt_deep (bit 31 of `handover` set) starts appending and whose
- * long runs it passes over.
- * Measured on the MI355X (profiles/r05_long_*.txt): this launch 26 ms a 1 GB pass, k_bwt_deep 20 ms shorter, the pass as fast
- * with as without on text, a tar and sources -- a piece is latency, and here it has no strips to hide behind.  Off by default
- * (LBZ_LONG_ROUNDS; LBZAMD_LONG_ROUNDS=2 turns it on; tests/test_emu_kernels.py and tests/test_gpu_parity.py run it). */
-struct long_lds { u8 inv[256]; deep_wave w; };
-__global__ void __launch_bounds__(64, 4)
-k_bwt_long(const u8 *Tbase, u8 *Bbase, lbz_block_meta *meta, lbz_layout L, u32 first, u32 count, u32 nblk, u32 segs,
-           u8 *ws, u64 slot_bytes, u8 *ws_spill, u64 spill_bytes, const u32 *slabs, u32 round, u32 handover)
-{
-  __shared__ long_lds S;
-  u32 bi, vseg;
-  if (!seg_item(nblk, segs * LBZ_LONG_SUB, &bi, &vseg)) return;
-  const u32 seg = vseg / LBZ_LONG_SUB, sub = vseg % LBZ_LONG_SUB;
-  const u32 blk = lbz_round_block(first, count, bi, slabs);
-  lbz_block_meta *M = &meta[blk];
-  const u32 n = M->n;
-  if (n < 2u || seg >= M->nseg) return;
-  const u32 lane = lane_id();
-  const u32 tot = M->deep_tot[round];
-  if (tot == 0u || deep_handed_over(M, n, round, tot, handover)) return;
-  const u32 m = M->seg_m[seg];
-  if (m <= 64u) return;                                 /* (a run of 64 at the end of the list is a strip: k_bwt_deep's rule) */
-  const u32 a = (u32)((u64)m * sub / LBZ_LONG_SUB), e = (u32)((u64)m * (sub + 1u) / LBZ_LONG_SUB);   /* the runs that START in [a, e) are this wave's */
-  if (a >= e) return;
-  const bwt_slot s = round_slot(ws, slot_bytes, ws_spill, spill_bytes, count, L, bi);
-  const u32 lo = M->seg_lo[seg];
-  const u32 cap = bi < count ? L.cap_a : L.cap_b;
-  const size_t off = lbz_elem_off(L, blk);
-  const u8 *T = Tbase + off;
-  u8 *bwt = Bbase + off;
-  u32 *colA[3] = { s.sufx + lo, s.grp + lo, s.pos + lo };
-  u32 *colB[3] = { s.v1 + lo, reinterpret_cast<u32 *>(s.k1) + lo, reinterpret_cast<u32 *>(s.k1) + cap + lo };
-  const u32 *sin = (round & 1u) ? colB[0] : colA[0], *gin = (round & 1u) ? colB[1] : colA[1], *din = (round & 1u) ? colB[2] : colA[2];
-  u32 *sout = (round & 1u) ? colA[0] : colB[0], *gout = (round & 1u) ? colA[1] : colB[1], *dout = (round & 1u) ? colA[2] : colB[2];
-  u32 cur = 0;                                          /* the last run head seen: entry 0 is one */
-  if (a) {
-    cur = e;
-    for (u32 w0 = a; w0 < e; w0 += 64u) {
-      const u32 k = w0 + lane;
-      const u32 g1 = k < m ? gin[k] : 0u, g0 = k - 1u < m ? gin[k - 1u] : 0u;
-      const u64 hd = __ballot(k < e && g1 != g0);
-      if (hd) { cur = w0 + (u32)__ffsll((long long)hd) - 1u; break; }
-    }
-  }
-  bool ready = false;                                   /* the symbol table (for the BWT bytes of rows that come out alone) is made when the first long run turns up */
-  deep_wave *W = &S.w;
-  const deep_lists Ls = { sin, gin, din, sout, gout, dout };
-  deep_ranks R;
-  R.isa = s.isa; R.map = reinterpret_cast<u32 *>(s.k0);
-  R.tag = round + 1u; R.hcur = M->deep_hmin[round];
-  R.build = round == DEEP_BUILD; R.live = false;        /* (launch_sort: no launch behind DEEP_BUILD has this kernel in front of it) */
-  const bool late = round + 1u == DEEP_ROUNDS || round + 1u == DEEP_HANDOVER;
-  u32 hmin = 0xFFFFFFFFu;
-  u32 w0 = cur + 1u;
-  while (cur < e) {
-    /* heads among the next 256 entries, 64 a ballot.  Two heads inside one ballot are less than 64 apart: only the distance
-       from the last head seen to a ballot's first one can be a long run */
-    u64 hd4[4];
-    {
-      u32 g1[4], g0[4];
-#pragma unroll
-      for (u32 q = 0; q < 4u; q++) {
-        const u32 k = w0 + 64u * q + lane;
-        g1[q] = k < m ? gin[k] : 0u; g0[q] = k < m ? gin[k - 1u] : 0u;
-      }
-#pragma unroll
-      for (u32 q = 0; q < 4u; q++) hd4[q] = __ballot(w0 + 64u * q + lane < m && g1[q] != g0[q]);
-    }
-    bool done = false;
-#pragma unroll 1
-    for (u32 q = 0; q < 4u; q++) {
-      const u64 hd = q == 0u ? hd4[0] : (q == 1u ? hd4[1] : (q == 2u ? hd4[2] : hd4[3]));
-      const u32 b0 = w0 + 64u * q;
-      const bool endw = b0 + 64u >= m;                                     /* the list ends here: so does the run */
-      if (!hd && !endw) continue;
-      const u32 firsth = hd ? b0 + (u32)__builtin_ctzll(hd) : m, lasth = hd ? b0 + 63u - (u32)__builtin_clzll(hd) : m;
-      if (firsth - cur >= 64u && m - cur > 64u) {
-        if (!ready) {
-          u32 f[4], nuse = 0, ex = 0;
-#pragma unroll
-          for (u32 t = 0; t < 4u; t++) { f[t] = M->inuse[64u * t + lane] ? 1u : 0u; nuse += (u32)__popcll(__ballot(f[t] != 0u)); }
-#pragma unroll
-          for (u32 t = 0; t < 4u; t++) {
-            const u64 bm = __ballot(f[t] != 0u);
-            if (nuse > 128u) S.inv[64u * t + lane] = (u8)(64u * t + lane);           /* bwt_setup's rule */
-            else if (f[t]) S.inv[ex + (u32)__popcll(bm & lanes_below())] = (u8)(64u * t + lane);
-            ex += (u32)__popcll(bm);
-          }
-          wave_sync();
-          ready = true;
-        }
-        deep_big_run<true>(W, lane, cur, firsth - cur, Ls, const_cast<u32 *>(sin), s.v0 + lo, T, n, s.sa, bwt, S.inv, M, &M->seg_long[seg], hmin, late, R);
-      }
-      cur = lasth;                                                         /* (a run that starts in the list's last 64 entries is not a long one) */
-      if (cur >= e || endw) { done = true; break; }
-    }
-    if (done) break;
-    w0 += 256u;
-  }
-  hmin = wave_min(hmin);
-  if (lane == 0u && hmin != 0xFFFFFFFFu) {
-    atomicMin(&M->deep_hmin[round + 1u], hmin);
-    if (round + 1u == DEEP_ROUNDS) atomicMin(&M->deep_h0, hmin);
-  }
-}
 
 /* ---- kernels 3: the rank rounds (fall-back): prefix doubling, ONE LAUNCH PER ROUND ----
  * k_bwt_fix0   every segment of a block that has ties left builds its list of tied rows (suffix, rank, row) in row order
@@ -2797,7 +2671,8 @@ k_bwt_fixr(const u8 *Tbase, u8 *Bbase, lbz_block_meta *meta, lbz_layout L, u32 f
   const bwt_slot s = seg_view(round_slot(ws, slot_bytes, ws_spill, spill_bytes, count, L, bi), lo);
   const size_t off = lbz_elem_off(L, blk);
   bwt_setup(M, &S);
-  const u64 h = (u64)M->deep_h0 << round;       /* every tie left is at least deep_h0 symbols deep, every rank at least as deep as that */
+  const u32 h0 = M->deep_h0 < M->deep_closed ? M->deep_h0 : M->deep_closed;      /* (closed runs are tied rows of the suffix array like the others) */
+  const u64 h = (u64)h0 << round;               /* every tie left is at least h0 symbols deep, every rank at least as deep as that */
   if (h >= n) return;                           /* tied at depth >= n: tied for good (k_bwt_fixend) */
   const u32 m2 = doubling_round(Tbase + off, n, Bbase + off, s, &S, (u32)h, m, round + 1u);
   if (threadIdx.x == 0) {

@@ -61,9 +61,6 @@ struct lbzamd_ctx {
   std::vector<hipEvent_t> cev;                /* round i's slabs are in device memory */
   hipEvent_t head_ev = nullptr;
   u8 *ws_head = nullptr;                      /* BWT workspaces of the head round */
-  /* the rank rounds of the blocks handed over early run on a stream of their own beside the round's later text launches */
-  struct aux_lane { hipStream_t q, aux; hipEvent_t handed, done; };
-  std::vector<aux_lane> aux;
   std::vector<int> bkind;                     /* which kernel each pair times (index into kms) */
   float kms[6] = { 0, 0, 0, 0, 0, 0 };       /* partition, batch, fix, mtf, encode, collect: accumulated per call */
   /* device */
@@ -104,7 +101,6 @@ static int ctx_free(lbzamd_ctx *c)
   for (auto &e : c->jev) if (e) (void)hipEventDestroy(e);
   for (auto &e : c->fev) if (e) (void)hipEventDestroy(e);
   for (auto &e : c->cev) if (e) (void)hipEventDestroy(e);
-  for (auto &a : c->aux) { if (a.handed) (void)hipEventDestroy(a.handed); if (a.done) (void)hipEventDestroy(a.done); if (a.aux) (void)hipStreamDestroy(a.aux); }
   if (c->head_ev) (void)hipEventDestroy(c->head_ev);
   if (c->copy_q) (void)hipStreamDestroy(c->copy_q);
   if (c->head_q) (void)hipStreamDestroy(c->head_q);
@@ -343,79 +339,30 @@ static void launch_sort(lbzamd_ctx *c, hipStream_t q, u32 first, u32 count, u32 
     static const unsigned deep_pad = getenv("LBZAMD_DEEP_PAD") ? (unsigned)atoi(getenv("LBZAMD_DEEP_PAD")) : 0u;   /* (tuning) idle LDS: fewer workgroups per CU */
     /* when a block goes to the rank rounds, in thousandths of its rows tied: as the text rounds begin (0 = no such rule) and
        after their first launch (k_bwt_deep) */
-    const char *e0 = getenv("LBZAMD_HANDOVER0"), *e1 = getenv("LBZAMD_HANDOVER1"), *es = getenv("LBZAMD_SPLIT_CHAIN");   /* (tuning; read per round) */
+    const char *e0 = getenv("LBZAMD_HANDOVER0"), *e1 = getenv("LBZAMD_HANDOVER1");   /* (tuning; read per round) */
     const u32 ho0 = e0 ? (u32)atoi(e0) : LBZ_HANDOVER0;
     const u32 ho1 = e1 ? (u32)atoi(e1) : LBZ_HANDOVER1;
-    const bool split = es && atoi(es) != 0;              /* off by default: see below */
     const u32 handover = (ho0 & 0xFFFFu) | (ho1 << 16);
     const dim3 g(lbz_seg_grid(nblk, segs));
     const u32 R = lbz_fix_rounds(c->L.M);
-    const char *el = getenv("LBZAMD_LONG_ROUNDS");         /* (tuning) text launches whose long runs get a launch of their own */
-    u32 long_rounds = el ? (u32)atoi(el) : LBZ_LONG_ROUNDS;
-    if (long_rounds > LBZ_DEEP_BUILD + 1u) long_rounds = LBZ_DEEP_BUILD + 1u;
-    auto text_rounds = [&](u32 from, u32 to) {
-      for (u32 r = from; r < to; r++)
-        if (r <= LBZ_DEEP_BUILD) {
-          if (r < long_rounds)
-            hipLaunchKernelGGL(k_bwt_long, dim3(lbz_seg_grid(nblk, segs * LBZ_LONG_SUB)), dim3(64), 0, q, (const u8 *)c->T, c->B, c->meta, c->L,
-                               first, count, nblk, segs, ws, (u64)c->slot_bytes, wsp, (u64)c->spill_bytes, lst, r, handover);
-          hipLaunchKernelGGL(k_bwt_deep, g, dim3(LBZ_BWT_WG), deep_pad, q, (const u8 *)c->T, c->B, c->meta, c->L,
-                             first, count, nblk, segs, ws, (u64)c->slot_bytes, wsp, (u64)c->spill_bytes, lst, r,
-                             handover | (r < long_rounds ? 0x80000000u : 0u));
-        } else                                             /* the launches that may step by ranks */
-          hipLaunchKernelGGL(k_bwt_deepr, g, dim3(LBZ_BWT_WG), deep_pad, q, (const u8 *)c->T, c->B, c->meta, c->L,
-                             first, count, nblk, segs, ws, (u64)c->slot_bytes, wsp, (u64)c->spill_bytes, lst, r, handover);
-    };
-    auto rank_rounds = [&](hipStream_t on, u32 which) {
-      hipLaunchKernelGGL(k_bwt_fix0, g, dim3(LBZ_BWT_WG), 0, on, (const u8 *)c->T, c->B, c->meta, c->L,
-                         first, count, nblk, segs, ws, (u64)c->slot_bytes, wsp, (u64)c->spill_bytes, lst, which);
-      for (u32 r = 0; r < R; r++)
-        hipLaunchKernelGGL(k_bwt_fixr, g, dim3(LBZ_BWT_WG), 0, on, (const u8 *)c->T, c->B, c->meta, c->L,
-                           first, count, nblk, segs, ws, (u64)c->slot_bytes, wsp, (u64)c->spill_bytes, lst, r, which);
-      hipLaunchKernelGGL(k_bwt_fixend, dim3(nblk), dim3(LBZ_BWT_WG), 0, on, c->B, c->meta, c->L,
-                         first, count, ws, (u64)c->slot_bytes, wsp, (u64)c->spill_bytes, lst, which);
-    };
-    /* The blocks handed over by k_bwt_batch or by the first launches of k_bwt_deep (LBZ_TIES_EARLY: a third of the blocks of a
-       source tree) need 7-12 doublings, each a launch that a fraction of the round's workgroups take part in; the round's other
-       blocks need the remaining text launches, which thin out the same way.  The two chains touch different blocks, so they CAN
-       run side by side (LBZAMD_SPLIT_CHAIN=1): the early blocks' rank rounds on the lane's second stream, the text launches on
-       its first, and what the last text launch leaves tied (LBZ_TIES_LATE: long repeats, exactly periodic blocks) gets a chain
-       behind both.  Measured (round 5, profiles/r05_trace_pysrc_split_chain.txt, r05_sweep_split_chain.txt): a round alone on
-       the device loses a quarter of its tie stages' time that way (47.7 -> 34 ms), three overlapping rounds gain nothing (the
-       other rounds' work filled those gaps already), and the second chain's 19 launches -- empty as a rule, but 45 000
-       workgroups each on a round of level-1 blocks -- cost the short rounds 6-8 %; with six streams per context on four
-       hardware queues the bench line's real-file legs lost 9 %.  So the default is ONE chain behind the last text launch, for
-       every block with ties left (which = 0). */
-    lbzamd_ctx::aux_lane *al = nullptr;
-    if (split) {
-      for (auto &a : c->aux) if (a.q == q) al = &a;
-      if (!al) {
-        lbzamd_ctx::aux_lane a{ q, nullptr, nullptr, nullptr };
-        if (hipStreamCreateWithFlags(&a.aux, hipStreamNonBlocking) == hipSuccess
-            && hipEventCreateWithFlags(&a.handed, hipEventDisableTiming) == hipSuccess
-            && hipEventCreateWithFlags(&a.done, hipEventDisableTiming) == hipSuccess) {
-          c->aux.push_back(a);
-          al = &c->aux.back();
-        } else {
-          (void)hipGetLastError();
-          if (a.handed) (void)hipEventDestroy(a.handed);
-          if (a.aux) (void)hipStreamDestroy(a.aux);
-        }
-      }
-    }
-    const u32 cut = LBZ_DEEP_HANDOVER + 1u < LBZ_DEEP_ROUNDS ? LBZ_DEEP_HANDOVER + 1u : LBZ_DEEP_ROUNDS;
-    text_rounds(0u, cut);
-    if (al && hipEventRecord(al->handed, q) == hipSuccess && hipStreamWaitEvent(al->aux, al->handed, 0) == hipSuccess) {
-      rank_rounds(al->aux, LBZ_TIES_EARLY);
-      (void)hipEventRecord(al->done, al->aux);
-      text_rounds(cut, LBZ_DEEP_ROUNDS);
-      (void)hipStreamWaitEvent(q, al->done, 0);
-      rank_rounds(q, LBZ_TIES_LATE);
-    } else {
-      if (split) (void)hipGetLastError();
-      text_rounds(cut, LBZ_DEEP_ROUNDS);
-      rank_rounds(q, 0u);
-    }
+    for (u32 r = 0; r < LBZ_DEEP_ROUNDS; r++)
+      if (r <= LBZ_DEEP_BUILD)
+        hipLaunchKernelGGL(k_bwt_deep, g, dim3(LBZ_BWT_WG), deep_pad, q, (const u8 *)c->T, c->B, c->meta, c->L,
+                           first, count, nblk, segs, ws, (u64)c->slot_bytes, wsp, (u64)c->spill_bytes, lst, r, handover);
+      else                                               /* the launches that may step by ranks */
+        hipLaunchKernelGGL(k_bwt_deepr, g, dim3(LBZ_BWT_WG), deep_pad, q, (const u8 *)c->T, c->B, c->meta, c->L,
+                           first, count, nblk, segs, ws, (u64)c->slot_bytes, wsp, (u64)c->spill_bytes, lst, r, handover);
+    /* ONE chain of rank rounds behind the last text launch, for every block with ties left (which = 0).  Round 5 also ran the
+       blocks handed over early on a stream of their own beside the later text launches (LBZAMD_SPLIT_CHAIN): a round alone on
+       the device lost a quarter of its tie stages' time that way, three overlapping rounds gained nothing and short rounds
+       lost 6-8 % to the second chain's launches (profiles/r05_sweep_split_chain.txt) -- taken out in round 6. */
+    hipLaunchKernelGGL(k_bwt_fix0, g, dim3(LBZ_BWT_WG), 0, q, (const u8 *)c->T, c->B, c->meta, c->L,
+                       first, count, nblk, segs, ws, (u64)c->slot_bytes, wsp, (u64)c->spill_bytes, lst, 0u);
+    for (u32 r = 0; r < R; r++)
+      hipLaunchKernelGGL(k_bwt_fixr, g, dim3(LBZ_BWT_WG), 0, q, (const u8 *)c->T, c->B, c->meta, c->L,
+                         first, count, nblk, segs, ws, (u64)c->slot_bytes, wsp, (u64)c->spill_bytes, lst, r, 0u);
+    hipLaunchKernelGGL(k_bwt_fixend, dim3(nblk), dim3(LBZ_BWT_WG), 0, q, c->B, c->meta, c->L,
+                       first, count, ws, (u64)c->slot_bytes, wsp, (u64)c->spill_bytes, lst, 0u);
   }
 }
 

@@ -82,12 +82,14 @@ typedef struct lbz_block_meta {
   uint32_t deep_h0;     /* depth every tie that is left for the rank rounds (k_bwt_fix*) is known to reach: they double from here.
                            0xFFFFFFFF while nothing is left (k_bwt_batch and the last k_bwt_deep launch lower it) */
   uint32_t deep_long;   /* tied rows of the block in runs of more than 63 (k_bwt_batch counts them): a block that is mostly such runs skips the text rounds */
+  uint32_t deep_closed; /* least depth at which a run of tied rows was left as it is because its order cannot show in the output: every row
+                           has the same byte in front of it and none is rotation 0 (k_bwt.hip, "closed runs").  The suffix array keeps
+                           such rows tied, so the rank rounds -- should the block still need them -- double from min(deep_h0, deep_closed) */
   uint32_t deep_skip;   /* k_bwt_batch left long runs tied (BIG_ROUNDS refinements did not split them): the block goes to the rank rounds as it is */
   uint32_t deep_tot[LBZ_DEEP_ROUNDS + 1];   /* tied rows of the block that enter text round r (its segments' lists together); [LBZ_DEEP_ROUNDS]: left over */
   uint32_t deep_hmin[LBZ_DEEP_ROUNDS + 1];  /* ... and the least depth any of them is known to share */
   uint32_t seg_lo[LBZ_BWT_MAXSEGS + 1];
   uint32_t seg_m[LBZ_BWT_MAXSEGS];         /* length of the segment's list of tied rows (k_bwt_batch -> k_bwt_deep rounds; k_bwt_fix* build their own) */
-  uint32_t seg_long[LBZ_BWT_MAXSEGS];      /* ... of which k_bwt_long wrote this many (the runs the launch's long runs left tied): k_bwt_deep appends behind them */
   uint32_t ticks[8];   /* wall_clock64 ticks of k_bwt_part / k_bwt_batch phases (diagnostic) */
   uint32_t fticks[16];  /* wall_clock64 ticks of k_bwt_fix phases (diagnostic) */
   uint8_t  inuse[256]; /* used-byte map (encode.c:63) */

@@ -79,20 +79,11 @@ __global__ void k_bwt_deep(const u8 *Tbase, u8 *Bbase, lbz_block_meta *meta, lbz
                            u32 count, u32 nblk, u32 segs, u8 *ws, u64 slot_bytes, u8 *ws_spill, u64 spill_bytes, const u32 *slabs, u32 round, u32 handover);
 __global__ void k_bwt_deepr(const u8 *Tbase, u8 *Bbase, lbz_block_meta *meta, lbz_layout L, u32 first,
                            u32 count, u32 nblk, u32 segs, u8 *ws, u64 slot_bytes, u8 *ws_spill, u64 spill_bytes, const u32 *slabs, u32 round, u32 handover);
-/* the long runs (64 rows and more) of text launch `round`, in front of it (launches < LBZ_LONG_ROUNDS): k_bwt_deep is then launched with bit 31
-   of `handover` set and passes over them */
-__global__ void k_bwt_long(const u8 *Tbase, u8 *Bbase, lbz_block_meta *meta, lbz_layout L, u32 first,
-                           u32 count, u32 nblk, u32 segs, u8 *ws, u64 slot_bytes, u8 *ws_spill, u64 spill_bytes, const u32 *slabs, u32 round, u32 handover);
-#ifndef LBZ_LONG_SUB
-#define LBZ_LONG_SUB 8u          /* one-wave workgroups per segment in k_bwt_long: grid = lbz_seg_grid(nblk, segs * LBZ_LONG_SUB), 64 threads */
-#endif
-#ifndef LBZ_LONG_ROUNDS
-#define LBZ_LONG_ROUNDS 0u       /* text launches with a k_bwt_long launch in front (at most LBZ_DEEP_BUILD + 1: it does not step by ranks).  0: measured on the
-                                    MI355X the same throughput with and without (profiles/r05_long_*.txt); LBZAMD_LONG_ROUNDS=2 turns it on */
-#endif
 /* lbz_block_meta.periodic while the sorter runs: ties left for the rank rounds -- flagged before the third text launch (their
    chain of launches starts there, beside the later text launches), or by the last one (a second chain behind both) */
+#ifndef LBZ_DEEP_BUILD
 #define LBZ_DEEP_BUILD 1u        /* the text launch whose leftovers get rank entries: the launches behind it (k_bwt_deepr) may step by ranks */
+#endif
 #define LBZ_DEEP_HANDOVER 1u     /* the text launch that hands over a block with too many rows still tied */
 #define LBZ_HANDOVER0 850u       /* thousandths of a block's rows tied as the text rounds begin: above, the block skips them (0: no such rule).  Text-like
                                     blocks of real sources: 60-81 %, the blocks the first text launch used to hand over: 80-99 % (profiles/r05_rows_*.txt) */

@@ -73,3 +73,32 @@ def test_real_file_leg_input():
         except (tarfile.ReadError, EOFError):
             pass
     assert len(names) >= a[1] - 1 and len(set(names)) == len(names) and names == sorted(names)
+
+
+def test_bare_bench_starts_its_own_ranks(tmp_path):
+    """`python bench.py --gpus 2` typed bare, the way the driver types `--gpus 1` (no torchrun around it): bench.py starts its own
+    two ranks, and the ONE line rank 0 prints carries the weak figure, the strong leg (one input -> one stream over both ranks,
+    verified against the reference fixture), the host -> host leg of both ranks, the command over two devices, the roofline and
+    the backend.  LBZ_BENCH_EMU (a test hook, see bench.py) puts the emulated kernel build and gloo where the GPU box has the
+    HIP library and RCCL; everything else -- launcher, ranks, collectives, the line -- is the code the driver runs."""
+    import json
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    subprocess.check_call(["make", "-s", "-C", os.path.join(root, "tests", "emu"), "WG=1024"])
+    env = dict(os.environ, LBZ_BENCH_EMU="1", LBZ_EMU_THREADS="2", LBZ_EMU_DEVICES="2",
+               LBZ_BENCH_LBZAMD=os.path.join(root, "tests", "emu", "_build", "lbzamd_emu"))
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT"):
+        env.pop(k, None)
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1", "--bytes", "350000",
+                          "--level", "1", "--seed", "2", "--no-cpu"], env=env, capture_output=True, text=True, timeout=1500, cwd=str(tmp_path))
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-3000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    r = json.loads(lines[0])
+    assert r["n_gpus"] == 2 and r["rccl_ranks"] == 2 and r["backend"].startswith("gloo") and r["emulated"] is True
+    assert r["scaling"] == "weak" and r["value"] > 0 and r["verified"] is True
+    assert r["strong"]["verified"] is True and r["strong"]["value"] > 0 and r["strong"]["value_from_rank0"] > 0
+    assert r["strong"]["slabs_per_rank"] == [2, 2]
+    assert r["value_host"]["ranks"] == 2 and r["value_host"]["same_stream"] is True
+    assert r["value_node_file"]["verified"] is True and r["value_node_file"]["devices"] == 2
+    assert r["roofline"]["bound"] == "hbm" and "frac" in r["roofline"] and "isolated" in r["roofline"]      # (the emulator's events time nothing)

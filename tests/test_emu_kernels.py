@@ -286,12 +286,11 @@ def test_long_runs_of_every_size(emu):
     _stages(emu, data[50000:50000 + 180000], 2)
 
 
-def test_long_runs_in_a_launch_of_their_own(emu, monkeypatch):
-    """LBZAMD_LONG_ROUNDS=1 / 2: the long runs of the first text launches go through k_bwt_long -- one-wave workgroups, eight per
-    segment, pieces of up to 256 rows ordered in one pass (deep_mid_run), the runs they leave tied in front of the next list --
-    and k_bwt_deep passes over them (lbz_api.hip: launch_sort; off by default).  Same stream as without, on inputs with long runs
-    of every size, two of them next to each other in a list (the stack hazard the emulator's call-site check found), rounds
-    of many blocks and of few."""
+def test_long_runs_of_every_size(emu, monkeypatch):
+    """Runs of 64 tied rows and more (deep_big_run: counting splits, pieces on a stack, closed sub-runs) of every size, two of
+    them next to each other in a list, in rounds of many blocks and of few -- and the same inputs with every block handed to
+    the rank rounds at once / after the first text launch (LBZAMD_HANDOVER0 / 1 = 1 thousandth), so that the fall-back meets
+    the closed runs the batches and the first launch left tied in the suffix array."""
     import random
     rng = random.Random(12)
     base = bytes(gen("wiki", 20000, 78))
@@ -305,8 +304,10 @@ def test_long_runs_in_a_launch_of_their_own(emu, monkeypatch):
     cases = ((bytes(out)[:99000], 1, 1, 1), (bytes(out), 2, 2, 2), (many, 1, 21, 21), (many, 1, 21, 4))
     for data, level, max_slabs, nslots in cases:
         want = L.orc_compress(data, level)
-        for rounds in ("1", "2"):
-            monkeypatch.setenv("LBZAMD_LONG_ROUNDS", rounds)
+        for knob in (None, "LBZAMD_HANDOVER0", "LBZAMD_HANDOVER1"):
+            if knob:
+                monkeypatch.setenv(knob, "1")
             with emu.context(level, max_slabs, nslots) as ctx:
-                assert ctx.compress(data) == want, (len(data), level, nslots, rounds)
-    monkeypatch.delenv("LBZAMD_LONG_ROUNDS")
+                assert ctx.compress(data) == want, (len(data), level, nslots, knob)
+            if knob:
+                monkeypatch.delenv(knob)

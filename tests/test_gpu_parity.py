@@ -494,11 +494,12 @@ def test_round_schedule(lib, monkeypatch, streams, nslots, max_slabs):
             assert ctx.compress(data) == want
 
 
-@pytest.mark.parametrize("knob,value", [("LBZAMD_LONG_ROUNDS", "2"), ("LBZAMD_LONG_ROUNDS", "1"), ("LBZAMD_SPLIT_CHAIN", "1")])
-def test_opt_in_launch_shapes(lib, monkeypatch, knob, value):
-    """The sorter's launch shapes that are off by default (lbz_api.hip: launch_sort) -- the long runs of the first text launches
-    in a launch of their own (k_bwt_long), the rank rounds of the blocks handed over early on a stream of their own -- write
-    the reference's stream too: text (long runs in every block), sources and a tar of this image's files, rounds of 5 slabs."""
+@pytest.mark.parametrize("knob,value", [("LBZAMD_HANDOVER0", "1"), ("LBZAMD_HANDOVER1", "1"), ("LBZAMD_HANDOVER0", "0")])
+def test_hand_over_rules_forced(lib, monkeypatch, knob, value):
+    """The sorter's fall-back with the hand-over rules forced (lbz_api.hip: launch_sort): every block to the rank rounds before
+    its first text launch / after it -- they then meet the CLOSED runs (k_bwt.hip) that the batches and the first launch left
+    tied in the suffix array -- and no block handed over on what the batches leave tied.  The reference's stream each time:
+    text (long runs in every block), sources and a tar of this image's files, rounds of 5 slabs."""
     import bench
     made = bench.real_tar(4_000_000)
     data = bytes(gen("wiki", 9_000_000, 31)) + bytes(gen("lines", 2_000_000, 32)) + (bytes(made[0]) if made else b"")

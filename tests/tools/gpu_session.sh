@@ -1,0 +1,27 @@
+#!/bin/bash
+# GPU box, one call: the steps named on the command line, each under its own timeout, logs under gpurun_out/<tag>_*.
+#   usage: tests/tools/gpu_session.sh <tag> step [step ...]
+#   steps: suite (pytest -m gpu + smoke) | bench (the driver's bench line) | sweep:<slabs>:<kinds>:<settings> (sweep_r5.py)
+#          rows:<slabs>:<kind> (diag_rows.py) | small (small_rounds.py) | prof (run_profiles.sh) | pmc:<slabs>:<kind> (run_pmc.sh)
+#          wu (work-unit interface at 16/64/256 threads) | file (file -> file, hostpath_perf) | py:<script and args>
+cd /root/repo
+TAG=$1; shift
+export PYTHONPATH=/root/repo:/root/repo/tests:/root/repo/tests/tools
+mkdir -p gpurun_out
+for step in "$@"; do
+  IFS=: read -r what a b c <<< "$step"
+  echo "=== $step"
+  case $what in
+    suite) timeout 900 python -m pytest tests -x -q -m gpu --durations=6 > gpurun_out/${TAG}_gpu_suite.log 2>&1; tail -12 gpurun_out/${TAG}_gpu_suite.log
+           timeout 200 python __graft_entry__.py smoke 2>&1 | tail -1 ;;
+    bench) timeout 900 python bench.py $a $b $c > gpurun_out/${TAG}_bench.json 2> gpurun_out/${TAG}_bench.err; tail -c 6000 gpurun_out/${TAG}_bench.json; tail -3 gpurun_out/${TAG}_bench.err ;;
+    sweep) timeout 900 python tests/tools/sweep_r5.py $a $b "$c" 2>&1 | grep -E "MB/s|Error|error" | tee -a gpurun_out/${TAG}_sweep.txt ;;
+    rows)  SHOW=${c:-24} timeout 600 python tests/tools/diag_rows.py $a $b 2>&1 | grep -v amdgpu.ids | tee gpurun_out/${TAG}_rows_$b.txt | tail -40 ;;
+    small) timeout 600 python tests/tools/small_rounds.py 2>&1 | tee gpurun_out/${TAG}_small_rounds.txt | tail -30 ;;
+    prof)  timeout 1500 bash tests/tools/run_profiles.sh $TAG 2>&1 | tail -60 ;;
+    pmc)   timeout 1500 bash tests/tools/run_pmc.sh ${TAG}_pmc $a $b 2>&1 | tail -40 ;;
+    wu)    for n in 16 64 256; do timeout 300 python tests/tools/hostpath_perf.py $n 2>&1 | tail -2; done | tee gpurun_out/${TAG}_workunits.txt ;;
+    file)  timeout 900 bash tests/tools/gpu_filemode.sh 2>&1 | tee gpurun_out/${TAG}_filemode.txt | tail -30 ;;
+    py)    timeout 900 python $a $b $c 2>&1 | tail -40 ;;
+  esac
+done
