@@ -120,6 +120,7 @@ __device__ __forceinline__ u32 isa_before(u64 e, u32 tag)      /* the rank as of
 }
 static_assert(BATCH_CAP == LBZ_WG * 4u, "a batch is one 4-rows-per-thread tile");
 
+#define BIG_FRAMES 14u                  /* big_group: BIG_LEVELS + 1 frames, rounded up */
 struct sort_lds {                       /* HBM radix passes (partition, oversized groups, doubling) */
   u32 hist[8][256];
   u32 wcnt[LBZ_NW][256];
@@ -149,6 +150,7 @@ struct bwt_lds {
   u32 listn, seglo;                   /* k_bwt_batch: entries in the segment's list of tied rows so far; the segment's first row */
   u32 h0min, lmin;                    /* k_bwt_batch: least depth of a tie left for the rank rounds; of a run in the list */
   u32 cmin, cpad;                     /* k_bwt_batch: least depth of a closed run (wave_finish_chunk) */
+  u32 fr_end[BIG_FRAMES], fr_dep[BIG_FRAMES];   /* k_bwt_batch, big_group: where each level of re-keyed rows ends, how deep its keys reach */
   u32 msd_shift, seghi;               /* 64 - the block's partition depth: rows with equal key >> msd_shift form a group; k_bwt_batch: the segment's end */
   u32 dbg[4];                         /* LDS_SORT_TICKS: whole-workgroup batch sorts (count, ticks), oversized groups (count, ticks) */
   u8 cmap[256];                       /* byte -> dense code */
@@ -1238,8 +1240,17 @@ __device__ void list_tied_rows(u8 *bwt, bwt_slot s, bwt_lds *S, u32 lo, u32 hi, 
 
 /* An oversized group [lo,hi) (> BATCH_CAP rows with equal top MSD_BITS): HBM radix sort on the remaining key bits, then
  * batches cut at key boundaries.  A run of more than a batch of EQUAL keys (" of the ": thousands of rows of a text
- * block) goes to the text rounds' list as it is; beyond LONG_RUN_MAX rows (long runs of one or two byte values,
- * "abababab") to the rank rounds.                                                                                   */
+ * block) goes to the text rounds' list as it is, one long run for one wave to take apart -- up to LONG_RUN_MAX rows.  A longer
+ * one (eight blanks: a third of the rows of a block of indented sources; the zero padding of a tar) is the whole workgroup's
+ * job (round 6): its rows get NEW keys -- the next sy symbols of the text -- are sorted on them in HBM and walked again, one
+ * level deeper, at most BIG_LEVELS times; the levels are frames on a small stack in LDS (where a frame ends, how deep its keys
+ * reach): keys of different frames are of different depths, so nothing is compared across a frame's end.  What is still one
+ * run of more than LONG_RUN_MAX rows then ("abababab": periodic stretches) is left to the rank rounds, and the block with it.
+ * Until round 6 every such run sent its block there -- with the closed runs that is a tenfold detour (every block of a real
+ * tar of sources: profiles/r06_a_rows_realtar.txt).                                                                        */
+#ifndef BIG_LEVELS
+#define BIG_LEVELS 12u
+#endif
 __device__ void big_group(const u8 *T, u32 n, u8 *bwt, lbz_block_meta *meta, bwt_slot s,
                           bwt_lds *S, keycfg c, u32 lo, u32 hi)
 {
@@ -1248,27 +1259,47 @@ __device__ void big_group(const u8 *T, u32 n, u8 *bwt, lbz_block_meta *meta, bwt
   const u32 which = wg_radix_sort(s.k0 + lo, s.v0 + lo, s.k1 + lo, s.v1 + lo, m, S->msd_shift, S);
   if (which) {
     for (u32 i = tid; i < m; i += LBZ_WG) { s.k0[lo + i] = s.k1[lo + i]; s.v0[lo + i] = s.v1[lo + i]; }
-    __syncthreads();
   }
-  u32 pos = lo;
+  if (tid == 0) { S->fr_end[0] = hi; S->fr_dep[0] = c.sy; }
+  __syncthreads();
+  u32 pos = lo, nf = 1u;                                /* frames in use (every thread keeps the same count) */
   while (pos < hi) {
-    u32 e = pos + BATCH_CAP < hi ? pos + BATCH_CAP : hi;
-    if (e < hi) {
+    while (pos >= S->fr_end[nf - 1u]) nf--;             /* (frame 0 ends at hi) */
+    const u32 lim = S->fr_end[nf - 1u], dep = S->fr_dep[nf - 1u];
+    u32 e = pos + BATCH_CAP < lim ? pos + BATCH_CAP : lim;
+    if (e < lim) {
       const u32 cut = find_cut(s.k0, pos, e, 0u, S);
       if (!cut) {
-        const u32 end = find_run_end(s.k0, pos, e, hi, 0u, S);
+        const u32 end = find_run_end(s.k0, pos, e, lim, 0u, S);
 #ifndef DBG_NOCLOSE_EMIT
-        if (rows_closed(s, S, pos, end)) emit_tied_rows(bwt, s, S, pos, end, meta, c.sy, true);
+        if (rows_closed(s, S, pos, end)) emit_tied_rows(bwt, s, S, pos, end, meta, dep, true);
         else
 #endif
-        if (end - pos <= LONG_RUN_MAX) list_tied_rows(bwt, s, S, pos, end, meta, c.sy);
-        else emit_tied_rows(bwt, s, S, pos, end, meta, c.sy);
+        if (end - pos <= LONG_RUN_MAX) list_tied_rows(bwt, s, S, pos, end, meta, dep);
+        else if (nf <= BIG_LEVELS && dep + c.sy < n) {
+          const u32 g = end - pos;
+          for (u32 j = pos + tid; j < end; j += LBZ_WG) {
+            u32 start = (s.v0[j] & 0x00FFFFFFu) + dep;
+            if (start >= n) start -= n;
+            s.k0[j] = key_from_text(T, n, start, S->cmap, c);
+          }
+          __syncthreads();
+          const u32 w2 = wg_radix_sort(s.k0 + pos, s.v0 + pos, s.k1 + pos, s.v1 + pos, g, 64u, S);
+          if (w2) {
+            for (u32 i = tid; i < g; i += LBZ_WG) { s.k0[pos + i] = s.k1[pos + i]; s.v0[pos + i] = s.v1[pos + i]; }
+          }
+          if (tid == 0) { S->fr_end[nf] = end; S->fr_dep[nf] = dep + c.sy; }
+          __syncthreads();
+          nf++;
+          continue;                                     /* the same rows again, by their new keys */
+        }
+        else emit_tied_rows(bwt, s, S, pos, end, meta, dep);
         pos = end;
         continue;
       }
       e = cut;
     }
-    batch_process(T, n, bwt, meta, s, S, c, pos, e - pos, true, false);
+    batch_process(T, n, bwt, meta, s, S, c, pos, e - pos, true, false, false, dep);
     pos = e;
   }
 }
@@ -1452,6 +1483,7 @@ struct part_lds {
   u32 listn, seglo;
   u32 h0min, lmin;
   u32 cmin, cpad;
+  u32 fr_end[BIG_FRAMES], fr_dep[BIG_FRAMES];
   u32 msd_shift, seghi;
   u32 dbg[4];
   u8 cmap[256];
@@ -1616,6 +1648,7 @@ struct part1_lds {
   u32 listn, seglo;
   u32 h0min, lmin;
   u32 cmin, cpad;
+  u32 fr_end[BIG_FRAMES], fr_dep[BIG_FRAMES];
   u32 msd_shift, seghi;
   u32 dbg[4];
   u8 cmap[256];
@@ -1697,6 +1730,7 @@ struct segs_lds {                       /* bwt_lds up to its union: all the boun
   u32 listn, seglo;
   u32 h0min, lmin;
   u32 cmin, cpad;
+  u32 fr_end[BIG_FRAMES], fr_dep[BIG_FRAMES];
   u32 msd_shift, seghi;
   u32 dbg[4];
   u8 cmap[256];
@@ -2007,6 +2041,34 @@ __device__ __forceinline__ u64x2 deep_load16(const u8 *T, u32 n, u32 idx, u32 d)
   }
   u64x2 x; x.x = xa; x.y = xb;
   return x;
+}
+
+/* A strip of few rows in a long repeat (the late launches: pairs of passages that occur twice, thousands of symbols deep -- and
+ * since the closed runs (deep_close) the rows such a pair would look up have no rank entries: their order cannot show, so nobody
+ * ranked them).  The idle lanes look ahead: lane = (chunk, row), every row's next 64 / cp chunks of 16 bytes are compared with
+ * the same chunk of its run's first row, and all rows advance by the chunks every run agrees on -- a pair takes 512 bytes a trip
+ * instead of 64.  Returns the symbols to advance by (for the lanes that take text steps; 0 for the others). */
+__device__ __forceinline__ u32 deep_wide_skip(const u8 *T, u32 n, u32 val, u32 hl, bool useT, u32 d, u32 cut, u32 lane)
+{
+  const u32 cp = cut <= 2u ? 2u : (cut <= 4u ? 4u : (cut <= 8u ? 8u : (cut <= 16u ? 16u : 32u)));
+  const u32 r = lane & (cp - 1u), cix = lane / cp;
+  const u32 rv = (u32)__shfl((int)val, (int)r), rh = (u32)__shfl((int)hl, (int)r);
+  const bool ru = __shfl((int)(useT ? 1 : 0), (int)r) != 0;
+  u32 rd = (u32)__shfl((int)d, (int)r), total = 0;
+  for (u32 it = 0; it < 8192u; it++) {
+    const bool valid = ru && rd + 16u * (cix + 1u) <= n;
+    u64x2 x; x.x = 0; x.y = 0;
+    if (valid) x = deep_load16(T, n, SA_IDX(rv), rd + 16u * cix);
+    const u32 from = rh + cix * cp;                          /* the same chunk of the run's first row */
+    const u64 ha = (u64)(u32)__shfl((int)(u32)x.x, (int)from) | (u64)(u32)__shfl((int)(u32)(x.x >> 32), (int)from) << 32;
+    const u64 hb = (u64)(u32)__shfl((int)(u32)x.y, (int)from) | (u64)(u32)__shfl((int)(u32)(x.y >> 32), (int)from) << 32;
+    const u64 dm = __ballot(ru && (!valid || x.x != ha || x.y != hb));
+    const u32 adv = dm ? (u32)__builtin_ctzll(dm) / cp : 64u / cp;      /* chunks every run agrees on (lanes are chunk-major) */
+    rd += 16u * adv;
+    total += 16u * adv;
+    if (dm) break;
+  }
+  return useT ? total : 0u;
 }
 
 /* Ranks for the rows the text has not ordered by launch DEEP_BUILD (on text a quarter of a block: repeats of 35 symbols and
@@ -2425,6 +2487,11 @@ __device__ __forceinline__ void deep_body(deep_lds &S, const u8 *Tbase, u8 *Bbas
           if (__ballot(useT)) {
             const bool mate = useT && hl != lane;
             u64 xa = 0, xb = 0;
+            if (longmode && cut <= 32u && !__ballot(useR)) {
+              d += deep_wide_skip(T, n, val, hl, useT, d, cut, lane);
+              at = SA_IDX(val) + d;                       /* (d <= n: the skip stops where a row has come round) */
+              if (at >= n) at -= n;
+            }
             if (longmode && !__ballot(useT && (at + 64u > n || d + 64u > n))) {
               u64 ya[4], yb[4];
 #pragma unroll
@@ -2597,7 +2664,8 @@ k_bwt_deep(const u8 *Tbase, u8 *Bbase, lbz_block_meta *meta, lbz_layout L, u32 f
   deep_body<false>(S, Tbase, Bbase, meta, L, first, count, nblk, segs, ws, slot_bytes, ws_spill, spill_bytes, slabs, round, handover);
 }
 
-__global__ void __launch_bounds__(LBZ_WG, 6)          /* six waves a SIMD: at most 80 vector registers (five cost the text rounds 3-4 %) */
+__global__ void __launch_bounds__(LBZ_WG, 5)          /* (the launches behind the second: short lists, a wave less per SIMD costs them nothing measurable and leaves
+                                                          room for the rank steps and the wide skip without spills) */
 k_bwt_deepr(const u8 *Tbase, u8 *Bbase, lbz_block_meta *meta, lbz_layout L, u32 first, u32 count, u32 nblk, u32 segs,
             u8 *ws, u64 slot_bytes, u8 *ws_spill, u64 spill_bytes, const u32 *slabs, u32 round, u32 handover)
 {

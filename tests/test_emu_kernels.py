@@ -311,3 +311,34 @@ def test_long_runs_of_every_size(emu, monkeypatch):
                 assert ctx.compress(data) == want, (len(data), level, nslots, knob)
             if knob:
                 monkeypatch.delenv(knob)
+
+
+def test_long_duplicates_and_huge_runs_of_one_key(emu, monkeypatch):
+    """Round 6: (1) passages of thousands of bytes that occur twice and thrice with different bytes in front of them -- their
+    first rows are the only OPEN ones (the rows inside the copies are closed runs without rank entries), and the late text
+    launches walk them 512 bytes a trip (deep_wide_skip); (2) more than LONG_RUN_MAX rows with ONE 64-bit key -- records of
+    equal fields -- which the batch kernel re-keys on the text behind the key, level by level (big_group's frames).  Also with
+    every block handed to the rank rounds after the first launch: the fall-back must give the same stream."""
+    import random
+    rng = random.Random(5)
+    src = bytes(gen("wiki", 60000, 11))
+    out = bytearray()
+    for ln in (3000, 9000, 20000, 40000):
+        at = rng.randrange(0, len(src) - ln)
+        out += b"<" + src[at:at + ln] + b">" + bytes(gen("text", 500, ln)) + b"[" + src[at:at + ln] + b"]"
+        out += b"{" + src[at:at + ln // 2] + b"}"
+    dups = bytes(out)
+    out = bytearray()
+    for i in range(7000):                       # "field=AbCdEfGh;" x 7000: one key 7000 times over, then the same again one, two ... fields deeper
+        out += b"AbCdEfGhIjKlMnOp" * rng.choice([1, 1, 2, 3, 5]) + bytes(gen("text", rng.choice([3, 7, 12]), i)) + rng.choice([b"\n", b";\n", b",\n"])
+    keys = bytes(out)
+    for data, level in ((dups, 2), (keys, 2), (keys[:99000] + dups[:99000], 9)):
+        want = L.orc_compress(data, level)
+        M = level * 100000
+        for knob in (None, "LBZAMD_HANDOVER1"):
+            if knob:
+                monkeypatch.setenv(knob, "1")
+            with emu.context(level, (len(data) + M - 1) // M, 4) as ctx:
+                assert ctx.compress(data) == want, (len(data), level, knob)
+            if knob:
+                monkeypatch.delenv(knob)
