@@ -2116,7 +2116,13 @@ __device__ void deep_big_run(deep_wave *W, u32 lane, u32 p, u32 g, deep_lists Ls
 {
   const u32 rank0 = Ls.gin[p];
   const u32 d0 = Ls.din[p];
-  wave_sync();                                          /* (every lane has read the empty stack of the run before: k_bwt_long calls this twice with no collective between) */
+  /* how far a piece is followed in one launch: 64 shared symbols and DEEP_LEVELS splits in the first launches (a long run must not keep
+     its wave while the strips of a hundred thousand rows wait); in the last two, whose lists are short, as far as it takes -- seven
+     hundred files of one block that begin with the same licence text are ONE run for six hundred symbols, a table sheds a few
+     rows with every symbol for a hundred (profiles/r06_b_rows_realtar.txt: such blocks ended in the rank rounds) */
+  const u32 maxit = R.tag + 2u <= DEEP_ROUNDS ? (R.tag <= 2u ? 4u : 16u) : 2048u;
+  const u32 maxlev = R.tag + 2u <= DEEP_ROUNDS ? DEEP_LEVELS : 40u;
+  wave_sync();                                          /* (every lane has read the empty stack of the run before) */
   if (lane == 0u) { W->st_off[0] = 0u; W->st_len[0] = g; W->st_dep[0] = d0; W->st_buf[0] = 0u; W->sp = 1u; }
   if (R.live)                                                     /* as for the strips: rank and depth at the start of the launch */
     for (u32 k = lane; k < g; k += 64u) R.isa[SA_IDX(ping[p + k])] = ISA_ENTRY_D(rank0, rank0, 0u, d0);
@@ -2136,7 +2142,7 @@ __device__ void deep_big_run(deep_wave *W, u32 lane, u32 p, u32 g, deep_lists Ls
 #ifdef DEEP_TICKS
     const u64 tb0 = wall_clock64();
 #endif
-    for (u32 it = 0; it < 4u && d + 16u <= n; it++) {
+    for (u32 it = 0; it < maxit && d + 16u <= n; it++) {
       const u64x2 ref = deep_load16(T, n, idx0, d);
       u32 lc = 16u;
       for (u32 k0 = 0; k0 < len; k0 += 256u) {           /* four strips a trip: their loads are in flight together */
@@ -2160,7 +2166,7 @@ __device__ void deep_big_run(deep_wave *W, u32 lane, u32 p, u32 g, deep_lists Ls
         break;
       }
     }
-    if (!split || d >= n || level >= DEEP_LEVELS) {
+    if (!split || d >= n || level >= maxlev) {
       /* nothing to split on yet (64 more symbols shared, or tied all the way round), or enough for one launch (a run that
          sheds a few rows with every symbol -- counters, tables -- would keep its wave for as many passes as it is deep):
          the piece goes on as it is, deeper */
