@@ -121,8 +121,7 @@ __device__ __forceinline__ u32 isa_before(u64 e, u32 tag)      /* the rank as of
 static_assert(BATCH_CAP == LBZ_WG * 4u, "a batch is one 4-rows-per-thread tile");
 
 #define BIG_FRAMES 14u                  /* big_group: BIG_LEVELS + 1 frames, rounded up */
-struct sort_lds {                       /* HBM radix passes (partition, oversized groups, doubling) */
-  u32 hist[8][256];
+struct sort_core {                      /* HBM radix passes (partition, oversized groups, doubling): what a tile's scatter needs */
   u32 wcnt[LBZ_NW][256];
   u32 dbase[256];                       /* running global offset of every digit */
   u32 toff[256];                        /* digit offsets inside the current tile */
@@ -131,6 +130,10 @@ struct sort_lds {                       /* HBM radix passes (partition, oversize
   u64 stage_k[SORT_TILE];               /* the tile, regrouped by digit, before it is written */
   u32 stage_v[SORT_TILE];
   u32 tile[(SORT_TILE + PART_HALO + 16u) / 4u];
+};
+struct sort_lds : sort_core {           /* ... and the digit histograms of the sorters that count before they scatter (k_bwt_scat does without: a
+                                           fourth workgroup per CU) */
+  u32 hist[8][256];
 };
 struct batch_lds {                      /* one batch resident in LDS */
   u64 kA[BATCH_CAP], kB[BATCH_CAP];
@@ -172,7 +175,9 @@ struct keycfg {
   u32 b;        /* bits per symbol */
   u32 sy;       /* symbols per key */
   u32 pad;      /* 64 - b*sy: keys are left aligned */
+  u32 q0;       /* whole symbols in a key's top half: what the partition's 8-byte rows carry */
 };
+#define BATCH_DEPTH(c) ((c).q0 + 4u)    /* symbols a key of k_bwt_batch covers: the top half's, and four bytes of text behind them (row_key) */
 
 __device__ __forceinline__ bwt_slot slot_carve(u8 *ws, u32 cap)
 {
@@ -206,17 +211,18 @@ __device__ __forceinline__ bwt_slot seg_view(bwt_slot s, u32 lo)
   return s;
 }
 
-struct sort_lds;
-template <bool NEXT = false>
-__device__ __forceinline__ void radix_tile_scatter_hbm(sort_lds *X, const unsigned long long (&key)[4], const unsigned int (&val)[4],
+struct sort_core;
+template <bool NEXT = false, bool HALF = false>
+__device__ __forceinline__ void radix_tile_scatter_hbm(sort_core *X, const unsigned long long (&key)[4], const unsigned int (&val)[4],
                                                        unsigned int okmask, unsigned int shift,
-                                                       unsigned long long *kout, unsigned int *vout,
+                                                       void *kout, unsigned int *vout,
                                                        unsigned int (*nh)[256] = nullptr, unsigned int nshift = 0u);
 
 /* ======================================================================= HBM radix sorter
  * Stable LSD radix sort of m (key,value) pairs on key bits [0, nbits).  Input in (k0,v0);
  * returns 0 if the sorted result is in (k0,v0), 1 if in (k1,v1).                        */
-__device__ u32 wg_radix_sort(u64 *k0, u32 *v0, u64 *k1, u32 *v1, u32 m, u32 nbits, bwt_lds *S)
+/* (always inlined, like every device function of this library: see the note at lds_radix_sort) */
+__device__ __forceinline__ u32 wg_radix_sort(u64 *k0, u32 *v0, u64 *k1, u32 *v1, u32 m, u32 nbits, bwt_lds *S)
 {
   sort_lds *G = &S->u.X;
   const u32 tid = threadIdx.x, lane = lane_id(), w = wave_id();
@@ -260,7 +266,7 @@ __device__ u32 wg_radix_sort(u64 *k0, u32 *v0, u64 *k1, u32 *v1, u32 m, u32 nbit
         val[k] = i < m ? vin[i] : 0u;
         if (i < m) okmask |= 1u << k;
       }
-      radix_tile_scatter_hbm(G, key, val, okmask, shift, kout, vout);
+      radix_tile_scatter_hbm<false, false>(G, key, val, okmask, shift, kout, vout);
     }
     __syncthreads();
     cur ^= 1u;
@@ -392,6 +398,23 @@ __device__ __forceinline__ u64 key_from_text(const u8 *T, u32 n, u32 start, cons
   return key << c.pad;
 }
 
+/* The key k_bwt_batch orders a row by: the top half the partition carried (q0 whole symbols, and perhaps some bits of the
+ * next), and behind it the four BYTES of text from symbol q0 on.  Bytes, not codes: the dense codes keep the bytes' order, so
+ * inside a group -- rows whose top halves agree -- bytes order the rows exactly as the codes would, and a 4-byte load replaces a
+ * table look-up per symbol.  Two rows with the same key share q0 + 4 symbols (BATCH_DEPTH). */
+__device__ __forceinline__ u64 row_key(const u8 *T, u32 n, u32 hi32, u32 idx, keycfg c)
+{
+  u32 at = idx + c.q0;
+  if (at >= n) at -= n;
+  u32 raw;
+  if (at + 4u <= n) raw = __builtin_bswap32(reinterpret_cast<const lbz_text4 *>(T + at)->a);
+  else {
+    raw = 0;
+    for (u32 q = 0; q < 4u; q++) { raw = (raw << 8) | T[at]; at = at + 1u == n ? 0u : at + 1u; }
+  }
+  return ((u64)hi32 << 32) | raw;
+}
+
 /* One stable counting-sort step of a 4096-row tile on digit (key >> shift) & 255: rows are
  * held wave-striped (row = wbase + k*64 + lane), ranks inside a wave come from ballots, the
  * per-wave counters and the running digit offsets (dbase) live in LDS.  Its barriers order
@@ -444,10 +467,13 @@ __device__ __forceinline__ void radix_tile_scatter(u32 (*wcnt)[256], u32 *dbase,
  * in LDS and written out by consecutive threads, so that each wave store covers a few runs of
  * consecutive addresses instead of 64 scattered rows.  NEXT is a template argument on purpose: as a run-time test inside
  * the write-out loop it cost the array passes 35 % (3.4 ms against 2.45 per pass of 371 blocks, r04 traces).      */
-template <bool NEXT>
-__device__ __forceinline__ void radix_tile_scatter_hbm(sort_lds *X, const u64 (&key)[SORT_IPT],
+/* HALF (round 6): the partition's rows are 8 bytes -- the key's TOP HALF and the value.  Its passes read digits of the top 32
+ * bits only; the low half of a key is first looked at by k_bwt_batch, which rebuilds it from the block's text (in its XCD's L2
+ * by then) instead of carrying it four times through HBM: 56 bytes of payload per rotation instead of 84. */
+template <bool NEXT, bool HALF>
+__device__ __forceinline__ void radix_tile_scatter_hbm(sort_core *X, const u64 (&key)[SORT_IPT],
                                                        const u32 (&val)[SORT_IPT], u32 okmask, u32 shift,
-                                                       u64 *kout, u32 *vout, u32 (*nh)[256], u32 nshift)
+                                                       void *kout_, u32 *vout, u32 (*nh)[256], u32 nshift)
 {
   const u32 tid = threadIdx.x, lane = lane_id(), w = wave_id();
   u32 rnk[SORT_IPT];
@@ -493,7 +519,8 @@ __device__ __forceinline__ void radix_tile_scatter_hbm(sort_lds *X, const u64 (&
     if ((okmask >> k) & 1u) {
       const u32 d = (u32)(key[k] >> shift) & 255u;
       const u32 lpos = X->toff[d] + X->wcnt[w][d] + rnk[k];
-      X->stage_k[lpos] = key[k];
+      if (HALF) reinterpret_cast<u32 *>(X->stage_k)[lpos] = (u32)(key[k] >> 32);
+      else X->stage_k[lpos] = key[k];
       X->stage_v[lpos] = val[k];
     }
   }
@@ -503,11 +530,19 @@ __device__ __forceinline__ void radix_tile_scatter_hbm(sort_lds *X, const u64 (&
   for (u32 k = 0; k < SORT_IPT; k++) {
     const u32 i = tid + k * LBZ_WG;
     if (i < rows) {
-      const u64 kk = X->stage_k[i];
-      const u32 dst = X->gdelta[(u32)(kk >> shift) & 255u] + i;
-      stg_u64(kout + dst, kk);
-      stg_u32(vout + dst, X->stage_v[i]);
-      if (NEXT) atomicAdd(&nh[dst >> nshift][(u32)(kk >> (shift + 8u)) & 255u], 1u);      /* the NEXT pass's digit, by the range of its input the row lands in */
+      if (HALF) {
+        const u32 kk = reinterpret_cast<const u32 *>(X->stage_k)[i];
+        const u32 dst = X->gdelta[(kk >> (shift - 32u)) & 255u] + i;
+        stg_u32(reinterpret_cast<u32 *>(kout_) + dst, kk);
+        stg_u32(vout + dst, X->stage_v[i]);
+        if (NEXT) atomicAdd(&nh[dst >> nshift][(kk >> (shift - 24u)) & 255u], 1u);
+      } else {
+        const u64 kk = X->stage_k[i];
+        const u32 dst = X->gdelta[(u32)(kk >> shift) & 255u] + i;
+        stg_u64(reinterpret_cast<u64 *>(kout_) + dst, kk);
+        stg_u32(vout + dst, X->stage_v[i]);
+        if (NEXT) atomicAdd(&nh[dst >> nshift][(u32)(kk >> (shift + 8u)) & 255u], 1u);      /* the NEXT pass's digit, by the range of its input the row lands in */
+      }
     }
   }
   wg_lds_barrier();
@@ -521,7 +556,7 @@ __device__ __forceinline__ void radix_tile_scatter_hbm(sort_lds *X, const u64 (&
  *                  the way if `count_above` (hist[j]: the digit at bit 32 + 8 j).  Values carry the CODE of the
  *                  preceding byte; the emitters map it back.                                 */
 template <bool SCATTER, bool NEXT = false>
-__device__ __forceinline__ void msd_text_pass(const u8 *T, u32 n, keycfg c, u64 *kout, u32 *vout, bwt_lds *S, u32 shift, u32 r0, u32 r1,
+__device__ __forceinline__ void msd_text_pass(const u8 *T, u32 n, keycfg c, u32 *kout, u32 *vout, bwt_lds *S, u32 shift, u32 r0, u32 r1,
                               u32 (*nh)[256] = nullptr, u32 nshift = 0u)      /* rotations [r0, r1), r0 a multiple of the tile */
 {
   sort_lds *P = &S->u.X;
@@ -586,7 +621,7 @@ __device__ __forceinline__ void msd_text_pass(const u8 *T, u32 n, keycfg c, u64 
       }
     }
     if (SCATTER) {
-      radix_tile_scatter_hbm<NEXT>(P, key, val, okmask, shift, kout, vout, nh, nshift);
+      radix_tile_scatter_hbm<NEXT, true>(P, key, val, okmask, shift, kout, vout, nh, nshift);
     } else {
       /* the first pass's digit of every rotation of the range, for either depth of partition: hist[0] the key byte at bit 32
          (32-bit partition), hist[2] the one at bit 48 (16-bit) */
@@ -606,19 +641,19 @@ __device__ __forceinline__ void msd_text_pass(const u8 *T, u32 n, keycfg c, u64 
  * row again; okmask drops them) and say "global" (lbz_asm.h), so no wait for an LDS read waits for them.  The compiler's own
  * form of this loop -- a guarded flat load per row, each followed by its wait -- ran a pass of 371 blocks in 3.3 ms. */
 template <bool NEXT>
-__device__ __forceinline__ void msd_array_pass(const u64 *kin, const u32 *vin, u32 shift, u64 *kout, u32 *vout, bwt_lds *S, u32 r0, u32 r1,
+__device__ __forceinline__ void msd_array_pass(const u32 *kin, const u32 *vin, u32 shift, u32 *kout, u32 *vout, bwt_lds *S, u32 r0, u32 r1,
                                                u32 (*nh)[256], u32 nshift)      /* rows [r0, r1) */
 {
   if (r0 >= r1) return;                                      /* (workgroup-uniform) */
   sort_lds *P = &S->u.X;
   const u32 lane = lane_id(), w = wave_id();
   const u32 last = r1 - 1u;
-  u64 nkey[SORT_IPT];
+  u32 nkey[SORT_IPT];
   u32 nval[SORT_IPT];
 #pragma unroll
   for (u32 k = 0; k < SORT_IPT; k++) {
     const u32 i0 = r0 + w * 64u * SORT_IPT + k * 64u + lane, i = i0 < last ? i0 : last;
-    nkey[k] = ldg_u64(kin + i);
+    nkey[k] = ldg_u32(kin + i);
     nval[k] = ldg_u32(vin + i);
   }
   for (u32 t0 = r0; t0 < r1; t0 += SORT_TILE) {
@@ -627,17 +662,17 @@ __device__ __forceinline__ void msd_array_pass(const u64 *kin, const u32 *vin, u
     const u32 wbase = t0 + w * 64u * SORT_IPT;
 #pragma unroll
     for (u32 k = 0; k < SORT_IPT; k++) {
-      key[k] = nkey[k];
+      key[k] = (u64)nkey[k] << 32;
       val[k] = nval[k];
       if (wbase + k * 64u + lane < r1) okmask |= 1u << k;
     }
 #pragma unroll
     for (u32 k = 0; k < SORT_IPT; k++) {
       const u32 i0 = wbase + SORT_TILE + k * 64u + lane, i = i0 < last ? i0 : last;
-      nkey[k] = ldg_u64(kin + i);
+      nkey[k] = ldg_u32(kin + i);
       nval[k] = ldg_u32(vin + i);
     }
-    radix_tile_scatter_hbm<NEXT>(P, key, val, okmask, shift, kout, vout, nh, nshift);
+    radix_tile_scatter_hbm<NEXT, true>(P, key, val, okmask, shift, kout, vout, nh, nshift);
   }
 }
 
@@ -653,7 +688,14 @@ __device__ __forceinline__ void load_digit_offsets(const u32 *hist, u32 *dbase, 
 
 /* ======================================================================= LDS batch */
 /* Radix sort of cnt <= BATCH_CAP pairs held in (kA,vA); returns 0/1 = result in A/B. */
-__device__ u32 lds_radix_sort(batch_lds *B, u32 cnt, bwt_lds *S)
+/* NO DEVICE FUNCTION CALLS.  Left to itself the compiler kept this function and wg_radix_sort out of line in k_bwt_batch (two
+ * s_swappc call sites each, 67 scalar registers of the kernel spilled to lanes of v127 around them).  In round 6 a build of that
+ * shape sorted wiki blocks wrongly on the device -- rows unwritten behind the first oversized group, differently from run to run,
+ * with one workgroup per block as with 32 -- while the emulator, every sanitizer run and three builds that differed by one
+ * never-taken bounds check were right; with the two functions inlined every one of those builds is right (tests/tools/dbg_bwt.py,
+ * profiles/r06_g_*).  The kernels of this library therefore contain no calls: `make calls` (csrc/Makefile) fails the build if
+ * a code object has an s_swappc. */
+__device__ __forceinline__ u32 lds_radix_sort(batch_lds *B, u32 cnt, bwt_lds *S)
 {
   const u32 tid = threadIdx.x, lane = lane_id(), w = wave_id();
   /* which key bytes differ between any two keys of the batch? */
@@ -1044,7 +1086,8 @@ __device__ u32 chunk_plan(batch_lds *B, u32 cnt)
  * batch).  Finding the cut on the rows already in LDS saves the separate search in HBM.      */
 __device__ u32 batch_process(const u8 *T, u32 n, u8 *bwt, lbz_block_meta *meta, bwt_slot s,
                              bwt_lds *S, keycfg c, u32 lo, u32 cnt, bool presorted, bool preloaded,
-                             bool trim = false, u32 depth = 0u)        /* depth: symbols the rows' keys reach (0: the first key, c.sy) */
+                             bool trim = false, u32 depth = 0u,        /* depth: symbols the rows' keys reach (0: the first key, c.sy) */
+                             const u64 *kfull = nullptr)               /* the rows' whole keys, where big_group has made them; else they are read off the text */
 {
   batch_lds *B = &S->u.B;
   const u32 tid = threadIdx.x;
@@ -1054,14 +1097,22 @@ __device__ u32 batch_process(const u8 *T, u32 n, u8 *bwt, lbz_block_meta *meta, 
      the kernel (2.4 of 27.8 ms per block) */
   u64 behind = 0;
   const bool more = trim && lo + cnt < S->seghi;     /* partition depth <= 32 bits; the segment ends at a group boundary (beyond it a neighbour may be rewriting keys) */
-  if (tid == 0 && more) behind = ldg_u64(s.k0 + lo + cnt);
+  if (tid == 0 && more) behind = (u64)ldg_u32(reinterpret_cast<const u32 *>(s.k0) + lo + cnt) << 32;      /* (the partition's keys are top halves) */
   if (!preloaded) {
     u64 kk[BATCH_CAP / LBZ_WG];
     u32 vv[BATCH_CAP / LBZ_WG];
 #pragma unroll
     for (u32 k = 0; k < BATCH_CAP / LBZ_WG; k++) {
       const u32 i0 = tid + k * LBZ_WG, i = i0 < cnt ? i0 : cnt - 1u;       /* cnt >= 1 */
-      kk[k] = ldg_u64(s.k0 + lo + i); vv[k] = ldg_u32(s.v0 + lo + i);
+      vv[k] = ldg_u32(s.v0 + lo + i);
+      if (kfull) kk[k] = ldg_u64(kfull + lo + i);
+      else kk[k] = (u64)ldg_u32(reinterpret_cast<const u32 *>(s.k0) + lo + i);
+    }
+    /* The partition moved the keys' top halves only (8-byte rows, round 6); the low half is four bytes of the text behind the
+       top half's symbols (row_key): a 4-byte gather from the text of the four blocks an XCD works on at a time, in its L2. */
+    if (!kfull) {
+#pragma unroll
+      for (u32 k = 0; k < BATCH_CAP / LBZ_WG; k++) kk[k] = row_key(T, n, (u32)kk[k], vv[k] & 0x00FFFFFFu, c);
     }
 #pragma unroll
     for (u32 k = 0; k < BATCH_CAP / LBZ_WG; k++) {
@@ -1256,11 +1307,16 @@ __device__ void big_group(const u8 *T, u32 n, u8 *bwt, lbz_block_meta *meta, bwt
 {
   const u32 tid = threadIdx.x;
   const u32 m = hi - lo;
-  const u32 which = wg_radix_sort(s.k0 + lo, s.v0 + lo, s.k1 + lo, s.v1 + lo, m, S->msd_shift, S);
+  /* whole keys for the group's rows (the partition's are top halves): in the second key column, sorted with the rank table's
+     column as the other buffer -- both idle until the text rounds */
+  u64 *const K = s.k1, *const K2 = s.isa;
+  for (u32 j = lo + tid; j < hi; j += LBZ_WG) K[j] = row_key(T, n, reinterpret_cast<const u32 *>(s.k0)[j], s.v0[j] & 0x00FFFFFFu, c);
+  __syncthreads();
+  const u32 which = wg_radix_sort(K + lo, s.v0 + lo, K2 + lo, s.v1 + lo, m, S->msd_shift, S);
   if (which) {
-    for (u32 i = tid; i < m; i += LBZ_WG) { s.k0[lo + i] = s.k1[lo + i]; s.v0[lo + i] = s.v1[lo + i]; }
+    for (u32 i = tid; i < m; i += LBZ_WG) { K[lo + i] = K2[lo + i]; s.v0[lo + i] = s.v1[lo + i]; }
   }
-  if (tid == 0) { S->fr_end[0] = hi; S->fr_dep[0] = c.sy; }
+  if (tid == 0) { S->fr_end[0] = hi; S->fr_dep[0] = BATCH_DEPTH(c); }
   __syncthreads();
   u32 pos = lo, nf = 1u;                                /* frames in use (every thread keeps the same count) */
   while (pos < hi) {
@@ -1268,9 +1324,9 @@ __device__ void big_group(const u8 *T, u32 n, u8 *bwt, lbz_block_meta *meta, bwt
     const u32 lim = S->fr_end[nf - 1u], dep = S->fr_dep[nf - 1u];
     u32 e = pos + BATCH_CAP < lim ? pos + BATCH_CAP : lim;
     if (e < lim) {
-      const u32 cut = find_cut(s.k0, pos, e, 0u, S);
+      const u32 cut = find_cut(K, pos, e, 0u, S);
       if (!cut) {
-        const u32 end = find_run_end(s.k0, pos, e, lim, 0u, S);
+        const u32 end = find_run_end(K, pos, e, lim, 0u, S);
 #ifndef DBG_NOCLOSE_EMIT
         if (rows_closed(s, S, pos, end)) emit_tied_rows(bwt, s, S, pos, end, meta, dep, true);
         else
@@ -1281,12 +1337,12 @@ __device__ void big_group(const u8 *T, u32 n, u8 *bwt, lbz_block_meta *meta, bwt
           for (u32 j = pos + tid; j < end; j += LBZ_WG) {
             u32 start = (s.v0[j] & 0x00FFFFFFu) + dep;
             if (start >= n) start -= n;
-            s.k0[j] = key_from_text(T, n, start, S->cmap, c);
+            K[j] = key_from_text(T, n, start, S->cmap, c);
           }
           __syncthreads();
-          const u32 w2 = wg_radix_sort(s.k0 + pos, s.v0 + pos, s.k1 + pos, s.v1 + pos, g, 64u, S);
+          const u32 w2 = wg_radix_sort(K + pos, s.v0 + pos, K2 + pos, s.v1 + pos, g, 64u, S);
           if (w2) {
-            for (u32 i = tid; i < g; i += LBZ_WG) { s.k0[pos + i] = s.k1[pos + i]; s.v0[pos + i] = s.v1[pos + i]; }
+            for (u32 i = tid; i < g; i += LBZ_WG) { K[pos + i] = K2[pos + i]; s.v0[pos + i] = s.v1[pos + i]; }
           }
           if (tid == 0) { S->fr_end[nf] = end; S->fr_dep[nf] = dep + c.sy; }
           __syncthreads();
@@ -1299,7 +1355,7 @@ __device__ void big_group(const u8 *T, u32 n, u8 *bwt, lbz_block_meta *meta, bwt
       }
       e = cut;
     }
-    batch_process(T, n, bwt, meta, s, S, c, pos, e - pos, true, false, false, dep);
+    batch_process(T, n, bwt, meta, s, S, c, pos, e - pos, true, false, false, dep, K);
     pos = e;
   }
 }
@@ -1442,6 +1498,7 @@ __device__ keycfg bwt_setup(const lbz_block_meta *meta, bwt_lds *S)
   c.sy = 64u / c.b;
   if (c.sy > MAX_SYMS) c.sy = MAX_SYMS;
   c.pad = 64u - c.b * c.sy;
+  c.q0 = 32u / c.b;
   if (tid == 0) {
     for (u32 i = 1; i < 16; i++) S->bc[i] = 0;
     S->msd_shift = 64u - (meta->msd_bits ? meta->msd_bits : MSD_BITS);
@@ -1463,7 +1520,7 @@ __device__ u32 seg_cut(const u64 *k0, u32 x, u32 n, bwt_lds *S)
 {
   if (x == 0u) return 0u;
   if (x >= n) return n;
-  return find_run_end(k0, x - 1u, x, n, S->msd_shift, S);
+  return find_run_end(reinterpret_cast<const u32 *>(k0), x - 1u, x, n, S->msd_shift - 32u, S);      /* the partition's keys: top halves */
 }
 
 /* ---- kernels 1: the partition, several workgroups per block ----------------------------------------------------------
@@ -1493,6 +1550,22 @@ struct part_lds {
 };
 static_assert(offsetof(part_lds, X) == offsetof(bwt_lds, u), "same layout up to the union");
 static_assert(sizeof(part_lds) <= 54 * 1024, "three per CU");
+struct scat_lds {                       /* k_bwt_scat: the same without the digit histograms of `X` (it reads its offsets from the block's tables) */
+  wg_scratch sc;
+  u32 bc[16];
+  u32 listn, seglo;
+  u32 h0min, lmin;
+  u32 cmin, cpad;
+  u32 fr_end[BIG_FRAMES], fr_dep[BIG_FRAMES];
+  u32 msd_shift, seghi;
+  u32 dbg[4];
+  u8 cmap[256];
+  u8 inv[256];
+  sort_core X;
+  u32 nh[PART_MAX][256];
+};
+static_assert(offsetof(scat_lds, X) == offsetof(bwt_lds, u), "same layout up to the union");
+static_assert(sizeof(scat_lds) <= 40 * 1024, "four per CU");
 
 /* ranges of 2^shift rows (whole tiles), at most `parts` of them */
 __device__ __forceinline__ u32 part_shift(u32 n, u32 parts)
@@ -1556,11 +1629,11 @@ k_bwt_hist(const u8 *Tbase, lbz_block_meta *meta, lbz_layout L, u32 first, u32 c
 }
 
 /* pass `pass` of the block's 2 or 4: range j of the pass's input */
-__global__ void __launch_bounds__(LBZ_WG, 3)
+__global__ void __launch_bounds__(LBZ_WG, 4)
 k_bwt_scat(const u8 *Tbase, lbz_block_meta *meta, lbz_layout L, u32 first, u32 count, u32 nblk, u32 parts,
            u8 *ws, u64 slot_bytes, u8 *ws_spill, u64 spill_bytes, const u32 *slabs, u32 pass)
 {
-  __shared__ part_lds S_;
+  __shared__ scat_lds S_;
   bwt_lds &S = *reinterpret_cast<bwt_lds *>(&S_);
   const u32 tid = threadIdx.x;
   u32 bi, j;
@@ -1616,7 +1689,7 @@ k_bwt_scat(const u8 *Tbase, lbz_block_meta *meta, lbz_layout L, u32 first, u32 c
     __syncthreads();
   }
   /* buffers alternate so that the last pass lands in (k0,v0) */
-  u64 *kb[2] = { s.k0, s.k1 };
+  u32 *kb[2] = { reinterpret_cast<u32 *>(s.k0), reinterpret_cast<u32 *>(s.k1) };      /* rows of 8 bytes: the key's top half and the value */
   u32 *vb[2] = { s.v0, s.v1 };
   const u32 dst = (passes - 1u - pass) & 1u;                  /* pass p writes buffer (passes - 1 - p) & 1 */
   const u32 shift = 32u + 8u * dj;
@@ -1693,7 +1766,7 @@ k_bwt_part(const u8 *Tbase, lbz_block_meta *meta, lbz_layout L, u32 first, u32 c
   const u32 bits = (bytes && MSD_BITS > MSD_BITS_FLAT && top <= n / 128u) ? MSD_BITS_FLAT : MSD_BITS;
   if (tid == 0) M->msd_bits = bits;
   const u32 passes = bits / 8u;
-  u64 *kb[2] = { s.k0, s.k1 };
+  u32 *kb[2] = { reinterpret_cast<u32 *>(s.k0), reinterpret_cast<u32 *>(s.k1) };
   u32 *vb[2] = { s.v0, s.v1 };
   load_digit_offsets(passes == 4u ? P->hist[0] : P->hist[2], P->dbase, &S);
   u32 cur = (passes - 1u) & 1u;                                /* buffers alternate so that the last pass lands in (k0,v0) */
@@ -1755,7 +1828,7 @@ k_bwt_segs(lbz_block_meta *meta, lbz_layout L, u32 first, u32 count, u32 segs,
   if (tid == 0) {
     u32 bad = 0;
     for (u32 i = 1; i < n && bad < 5u; i++)
-      if ((s.k0[i] >> S.msd_shift) < (s.k0[i - 1u] >> S.msd_shift)) { printf("part: blk %u row %u out of order: %llx after %llx (bits %u)\n", blk, i, s.k0[i], s.k0[i - 1u], M->msd_bits); bad++; }
+      if ((reinterpret_cast<const u32 *>(s.k0)[i] >> (S.msd_shift - 32u)) < (reinterpret_cast<const u32 *>(s.k0)[i - 1u] >> (S.msd_shift - 32u))) { printf("part: blk %u row %u out of order (bits %u)\n", blk, i, M->msd_bits); bad++; }
     u64 sum = 0; for (u32 i = 0; i < n; i++) sum += s.v0[i] & 0xFFFFFFu;
     printf("part: blk %u n %u index sum %llu (want %llu)\n", blk, n, sum, (u64)n * (n - 1u) / 2u);
   }
@@ -1832,12 +1905,12 @@ k_bwt_batch(const u8 *Tbase, u8 *Bbase, lbz_block_meta *meta, lbz_layout L, u32 
     u32 pos = lo;
     while (pos < hi) {
       const u32 want = hi - pos < BATCH_CAP ? hi - pos : BATCH_CAP;
-      const u32 used = batch_process(T, n, bwt, M, s, &S, c, pos, want, false, false, true);
+      const u32 used = batch_process(T, n, bwt, M, s, &S, c, pos, want, false, false, true, BATCH_DEPTH(c));
       if (used == 0u) {                          /* one group fills the batch: sort it in HBM first */
 #ifdef LDS_SORT_TICKS
         const u64 tg0 = wall_clock64();
 #endif
-        const u32 end = find_run_end(s.k0, pos, pos + want, hi, S.msd_shift, &S)   /* inside the segment: a neighbour may be rewriting its keys */;
+        const u32 end = find_run_end(reinterpret_cast<const u32 *>(s.k0), pos, pos + want, hi, S.msd_shift - 32u, &S);   /* inside the segment (the partition's keys: top halves) */
         big_group(T, n, bwt, M, s, &S, c, pos, end);
 #ifdef LDS_SORT_TICKS
         if (tid == 0) { S.dbg[3] += (u32)(wall_clock64() - tg0); S.dbg[2] += end - pos; }

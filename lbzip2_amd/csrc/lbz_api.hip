@@ -273,7 +273,12 @@ static int timed_end(lbzamd_ctx *c, size_t *nbev, hipStream_t s)
 
 /* Workgroups per block of a round of `count` blocks: in the sorting kernels (segments), and in the partition (1 = k_bwt_part,
  * every pass in one launch; else the launch-per-pass kernels with that many workgroups per block).  LBZAMD_PARTS: (tuning). */
-static u32 round_segs(const lbzamd_ctx *c, u32 count) { return count <= c->ncus ? LBZ_BWT_MAXSEGS : LBZ_BWT_SEGS; }
+static u32 round_segs(const lbzamd_ctx *c, u32 count)
+{
+  static const int forced = getenv("LBZAMD_SEGS") ? atoi(getenv("LBZAMD_SEGS")) : 0;      /* (tuning) */
+  if (forced > 0 && forced <= (int)LBZ_BWT_MAXSEGS) return (u32)forced;
+  return count <= c->ncus ? LBZ_BWT_MAXSEGS : LBZ_BWT_SEGS;
+}
 static u32 round_parts(const lbzamd_ctx *c, u32 count, bool overlapped)
 {
   static const int forced = getenv("LBZAMD_PARTS") ? atoi(getenv("LBZAMD_PARTS")) : 0;

@@ -207,6 +207,7 @@ __device__ __forceinline__ unsigned wave_reserve(unsigned *counter, unsigned amo
 
 /* 16 bytes of the block text at any byte address (global_load_dwordx4: gfx950 takes unaligned addresses) */
 struct __attribute__((packed, aligned(1))) lbz_text16 { unsigned long long a, b; };
+struct __attribute__((packed, aligned(1))) lbz_text4 { unsigned a; };
 
 /* acc + (a0 < b) + (a1 < b), unsigned 64-bit: two v_cmp_lt_u64 + v_addc_co_u32 pairs in one block (the compiler's form
  * is compare, select, add, and it separates two blocks that both write VCC with a wait state) */

@@ -71,6 +71,7 @@ static inline unsigned wave_reserve(unsigned *counter, unsigned amount)
   return (unsigned)__builtin_amdgcn_readfirstlane((int)r);
 }
 struct __attribute__((packed, aligned(1))) lbz_text16 { unsigned long long a, b; };
+struct __attribute__((packed, aligned(1))) lbz_text4 { unsigned a; };
 static inline unsigned add_if_less2(unsigned acc, unsigned long long a0, unsigned long long a1, unsigned long long b) { return acc + (a0 < b ? 1u : 0u) + (a1 < b ? 1u : 0u); }
 static inline unsigned long long ldg_u64(const unsigned long long *p) { return *p; }
 static inline unsigned ldg_u32(const unsigned *p) { return *p; }

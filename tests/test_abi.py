@@ -58,3 +58,13 @@ def test_no_device_fails_loudly(lib):
     h = C.c_void_p()
     rc = lib.lib.lbzamd_create(C.byref(h), -1, 9, 1, 1)
     assert rc != 0 and lib.error()
+
+
+def test_kernels_contain_no_device_function_calls():
+    """Every gfx950 code object of the product library is free of s_swappc: the sorter's out-of-line functions once made a
+    build that sorted wrongly on the device only (k_bwt.hip, note at lds_radix_sort; csrc/check_no_calls.sh)."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([os.path.join(root, "lbzip2_amd", "csrc", "check_no_calls.sh")], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "no calls" in r.stdout

@@ -3,6 +3,7 @@
 #   usage: tests/tools/gpu_session.sh <tag> step [step ...]
 #   steps: suite (pytest -m gpu + smoke) | bench (the driver's bench line) | sweep:<slabs>:<kinds>:<settings> (sweep_r5.py)
 #          rows:<slabs>:<kind> (diag_rows.py) | small (small_rounds.py) | prof (run_profiles.sh) | pmc:<slabs>:<kind> (run_pmc.sh)
+#          ab:<variant>:<slabs>:<kinds> (default library against a variant, same box)
 #          wu (work-unit interface at 16/64/256 threads) | file (file -> file, hostpath_perf) | py:<script and args>
 cd /root/repo
 TAG=$1; shift
@@ -22,6 +23,11 @@ for step in "$@"; do
     pmc)   timeout 1500 bash tests/tools/run_pmc.sh ${TAG}_pmc $a $b 2>&1 | tail -40 ;;
     wu)    for n in 16 64 256; do timeout 300 python tests/tools/hostpath_perf.py $n 2>&1 | tail -2; done | tee gpurun_out/${TAG}_workunits.txt ;;
     file)  timeout 900 bash tests/tools/gpu_filemode.sh 2>&1 | tee gpurun_out/${TAG}_filemode.txt | tail -30 ;;
+    ab)    # A/B on one box: sweep_r5.py with the default library, then with lbzip2_amd/csrc/variants/<a>.so    ab:<variant>:<slabs>:<kinds>
+           for lib in default $a; do
+             if [ "$lib" = default ]; then unset LBZ_LIB; else export LBZ_LIB=/root/repo/lbzip2_amd/csrc/variants/$lib.so; fi
+             timeout 900 python tests/tools/sweep_r5.py $b $c "LBZAMD_STREAMS=1;LBZAMD_STREAMS=3" 2>&1 | grep -E "MB/s|rror" | sed "s/^/$lib /" | tee -a gpurun_out/${TAG}_ab.txt
+           done; unset LBZ_LIB ;;
     py)    timeout 900 python $a $b $c 2>&1 | tail -40 ;;
   esac
 done
