@@ -125,3 +125,54 @@ k_meta_pick(const lbz_block_meta *meta, const u32 *slabs, u32 count, u32 *out)
   const lbz_block_meta *m = &meta[2u * slabs[i]];
   out[4u * i] = m->consumed; out[4u * i + 1u] = m->out_len; out[4u * i + 2u] = m->crc; out[4u * i + 3u] = m->err;
 }
+
+/* work-unit encode rounds: the packed blocks of the listed slabs go to the pool's page-locked staging area -- the device
+ * writes them there itself (whole words, 16 bytes a thread; PCIe writes are posted), their four result words beside them, so
+ * that a round ends with ONE wait of its leader instead of a copy of the sizes, a wait, a copy per block and another wait.
+ * grid = parts * count.                                                                                               */
+__global__ void __launch_bounds__(256)
+k_pool_out(const u8 *Obase, const lbz_block_meta *meta, lbz_layout L, const u32 *slabs, u8 *h_out, u32 *h_pick, u32 parts, u32 spare)
+{
+  const u32 i = blockIdx.x / parts, part = blockIdx.x % parts, slab = slabs[i];
+  if (slab == spare) return;                               /* (an entry of the other half of a split list) */
+  const lbz_block_meta *m = &meta[2u * slab];
+  if (part == 0u && threadIdx.x == 0u) {
+    h_pick[4u * i] = m->consumed; h_pick[4u * i + 1u] = m->out_len; h_pick[4u * i + 2u] = m->crc; h_pick[4u * i + 3u] = m->err;
+  }
+  if (m->err) return;
+  const u32 words16 = (m->out_len + 15u) / 16u;            /* (the block's reserve is a multiple of 256 bytes) */
+  const uint4 *src = reinterpret_cast<const uint4 *>(Obase + lbz_out_off(L, 2u * slab));
+  uint4 *dst = reinterpret_cast<uint4 *>(h_out + (size_t)slab * L.out_a);
+  for (u32 w = part * 256u + threadIdx.x; w < words16; w += parts * 256u) dst[w] = src[w];
+}
+
+/* work-unit collect rounds: the callers' slabs come from the page-locked staging area by the device's own reads (16 bytes a
+ * thread, every workgroup with four loads in flight per thread) -- one launch instead of a copy call per slab. grid = parts * count */
+__global__ void __launch_bounds__(256)
+k_pool_in(const u8 *h_in, u8 *d_in, u32 M, const u32 *slabs, const u32 *lens, u32 parts)
+{
+  const u32 i = blockIdx.x / parts, part = blockIdx.x % parts, slab = slabs[i];
+  const u32 words16 = (lens[i] + 15u) / 16u;
+  const uint4 *src = reinterpret_cast<const uint4 *>(h_in + (size_t)slab * M);
+  uint4 *dst = reinterpret_cast<uint4 *>(d_in + (size_t)slab * M);
+  const u32 stride = parts * 256u;
+  u32 w = part * 256u + threadIdx.x;
+  for (; w + 3u * stride < words16; w += 4u * stride) {
+    const uint4 a = src[w], b = src[w + stride], c = src[w + 2u * stride], d = src[w + 3u * stride];
+    dst[w] = a; dst[w + stride] = b; dst[w + 2u * stride] = c; dst[w + 3u * stride] = d;
+  }
+  for (; w < words16; w += stride) dst[w] = src[w];
+}
+
+/* work-unit encode rounds: the round's list in two of the same length -- the blocks the text rounds finished, and the ones
+ * the rank rounds still have to sort (flagged LBZ_TIES_*); where a list lacks a block it names the pool's spare slab. */
+__global__ void __launch_bounds__(256)
+k_pool_split(const lbz_block_meta *meta, const u32 *slabs, u32 count, u32 *fast, u32 *slow, u32 spare)
+{
+  const u32 i = blockIdx.x * 256u + threadIdx.x;
+  if (i >= count) return;
+  const u32 slab = slabs[i];
+  const bool left = meta[2u * slab].n >= 2u && meta[2u * slab].periodic >= LBZ_TIES_EARLY;
+  fast[i] = left ? spare : slab;
+  slow[i] = left ? slab : spare;
+}

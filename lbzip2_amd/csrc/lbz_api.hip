@@ -15,6 +15,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <chrono>
 #include <condition_variable>
 #include <mutex>
 #include <string>
@@ -314,7 +315,7 @@ static void launch_mtf(lbzamd_ctx *c, hipStream_t q, u32 first, u32 count, u32 n
 }
 
 static void launch_sort(lbzamd_ctx *c, hipStream_t q, u32 first, u32 count, u32 nblk, u8 *ws, u8 *wsp, const u32 *lst,
-                        int phase /* 0 = partition, 1 = batches, 2 = deep ties */, bool overlapped = false /* other rounds run beside this one */)
+                        int phase /* 0 = partition, 1 = batches, 2 = deep ties (3: the text rounds alone, 4: the rank rounds alone) */, bool overlapped = false /* other rounds run beside this one */)
 {
   /* workgroups per block in the sorting kernels: more of them when the round has fewer blocks than the device has CUs -- the
      caller then waits for a block's chain of launches, and every launch is as long as its longest segment */
@@ -350,7 +351,7 @@ static void launch_sort(lbzamd_ctx *c, hipStream_t q, u32 first, u32 count, u32 
     const u32 handover = (ho0 & 0xFFFFu) | (ho1 << 16);
     const dim3 g(lbz_seg_grid(nblk, segs));
     const u32 R = lbz_fix_rounds(c->L.M);
-    for (u32 r = 0; r < LBZ_DEEP_ROUNDS; r++)
+    for (u32 r = 0; r < LBZ_DEEP_ROUNDS && phase != 4; r++)
       if (r <= LBZ_DEEP_BUILD)
         hipLaunchKernelGGL(k_bwt_deep, g, dim3(LBZ_BWT_WG), deep_pad, q, (const u8 *)c->T, c->B, c->meta, c->L,
                            first, count, nblk, segs, ws, (u64)c->slot_bytes, wsp, (u64)c->spill_bytes, lst, r, handover);
@@ -361,6 +362,7 @@ static void launch_sort(lbzamd_ctx *c, hipStream_t q, u32 first, u32 count, u32 
        blocks handed over early on a stream of their own beside the later text launches (LBZAMD_SPLIT_CHAIN): a round alone on
        the device lost a quarter of its tie stages' time that way, three overlapping rounds gained nothing and short rounds
        lost 6-8 % to the second chain's launches (profiles/r05_sweep_split_chain.txt) -- taken out in round 6. */
+    if (phase == 3) return;
     hipLaunchKernelGGL(k_bwt_fix0, g, dim3(LBZ_BWT_WG), 0, q, (const u8 *)c->T, c->B, c->meta, c->L,
                        first, count, nblk, segs, ws, (u64)c->slot_bytes, wsp, (u64)c->spill_bytes, lst, 0u);
     for (u32 r = 0; r < R; r++)
@@ -1345,23 +1347,38 @@ struct wu_req {
   int stage;                  /* 0 = collect, 1 = encode */
   bool done;
   uint32_t consumed, out_len, crc, err;       /* the block record as of the round that served the request */
+  std::condition_variable cv; /* the request's own: its thread is woken when the request is done, or to lead a round -- and no
+                                 other thread with it.  (One condition variable for the pool, broadcast at the end of every
+                                 round, kept 47 of 64 caller threads runnable at any moment, in the kernel, on the futex: 14
+                                 CPUs of system time, and the box's CPU quota throttled the process for 68 ms of every 100:
+                                 profiles/r06_i_wu_*.txt) */
 };
 
-struct wu_lane {                      /* one kind of request (0 = collect, 1 = encode): its own queue, leader and stream */
+struct wu_lane {                      /* a stream that runs one round at a time, with the round's lists and (encode) its own set of BWT workspaces */
   hipStream_t q = nullptr;            /* non-blocking: no ties to the null stream */
-  u32 *d_list = nullptr, *d_len = nullptr, *d_pick = nullptr;
-  u32 *h_pick = nullptr;              /* pinned: {consumed, out_len, crc, err} per request of the round */
-  std::vector<wu_req *> pending;
-  bool leader = false;
+  u32 *d_list = nullptr, *d_len = nullptr;
+  u32 *h_pick = nullptr;              /* pinned: {consumed, out_len, crc, err} per request of the round; the device writes it */
+  u32 *h_list = nullptr;              /* pinned: the round's slabs, then their lengths (the source of the list copies) */
+  u8 *ws = nullptr;                   /* encode lanes: nslots slots of the pool context's workspace */
+  bool busy = false;
 };
+#define WU_COLLECT_LANES 2u
+#define WU_ENCODE_LANES 3u
 
 struct wu_pool {
   lbzamd_ctx *c = nullptr;    /* P resident slabs, staging for P slabs of input */
   uint32_t P = 0;
-  wu_lane lane[2];
+  /* Requests of one kind (0 = collect, 1 = encode) wait in one queue; whoever finds a free lane of that kind leads a round
+     on it.  Several rounds of a kind run side by side (round 6): with one encode round at a time the callers moved in
+     convoy -- the first block back from a round went through collect alone and then held the only encode lane for a
+     round of ONE block (7 ms of launch chain) while the other 63 waited: 2.85 GB/s at 64 threads (profiles/r05_workunits.txt). */
+  std::vector<wu_req *> pending[2];
+  std::vector<wu_lane> lanes[2];
+  uint32_t inflight[2] = { 0, 0 };        /* rounds running, per kind */
+  bool gathering[2] = { false, false };   /* a leader is waiting for stragglers: arrivals join its round */
   u8 *h_in = nullptr, *h_out = nullptr;   /* pinned staging, one slab each: callers fill / drain it in parallel, the leader's copies are pure DMA */
   std::mutex mu;
-  std::condition_variable cv;
+  std::condition_variable cv_slab, cv_arrive; /* a slab was freed (states beyond the pool's slabs wait here); a request arrived (a gathering leader listens) */
   std::vector<uint32_t> free_slabs;
   /* re-entered collect(): one at a time (the reference holds a token, compress.c:62,143), own stream and scratch */
   std::mutex seq_mu;
@@ -1414,17 +1431,28 @@ static wu_pool *pool_on(int device, unsigned bs100k)
                                                    (1024, the default until round 4: 35 GB and 2 GB on the first collect() whatever the number of
                                                    threads); callers beyond that wait for a slab */
   if (p->P < 1u) p->P = 1u;
-  /* one slot set: encode rounds run one at a time, up to 512 blocks (two per CU) each */
-  if (ctx_create(&p->c, device, bs100k, p->P, p->P < 512u ? p->P : 512u, 1u)) die("cannot create the work-unit pool");
+  /* a slot set per encode lane, each for half the pool's slabs (a bigger round goes through its lane in pieces) */
+  const uint32_t lane_slots = p->P <= 2u ? p->P : (p->P + 1u) / 2u;
+  if (ctx_create(&p->c, device, bs100k, p->P + 1u, lane_slots, p->P <= 2u ? 1u : WU_ENCODE_LANES)) die("cannot create the work-unit pool");      /* (+ 1: the spare slab, always empty: k_pool_split) */
   lbzamd_ctx *c = p->c;
   if (ensure_staging(c, (size_t)p->P * c->L.M, 0)) die("work-unit pool staging");
-  for (wu_lane &l : p->lane) {
-    HIPDIE(hipStreamCreateWithFlags(&l.q, hipStreamNonBlocking), "pool");
-    HIPDIE(hipMalloc((void **)&l.d_list, p->P * sizeof(u32)), "pool");
-    HIPDIE(hipMalloc((void **)&l.d_len, p->P * sizeof(u32)), "pool");
-    HIPDIE(hipMalloc((void **)&l.d_pick, p->P * 4u * sizeof(u32)), "pool");
-    HIPDIE(hipHostMalloc((void **)&l.h_pick, p->P * 4u * sizeof(u32), hipHostMallocPortable), "pool");
+  HIPDIE(hipMemset(c->meta + 2u * (size_t)p->P, 0, 2u * sizeof(lbz_block_meta)), "pool");
+  p->lanes[0].resize(WU_COLLECT_LANES);
+  p->lanes[1].resize(c->nstreams);                  /* a lane per slot set */
+  if (getenv("LBZAMD_POOL_LANES") && atoi(getenv("LBZAMD_POOL_LANES")) >= 1 && (size_t)atoi(getenv("LBZAMD_POOL_LANES")) < p->lanes[1].size()) {
+    p->lanes[1].resize((size_t)atoi(getenv("LBZAMD_POOL_LANES")));      /* (tuning) */
+    p->lanes[0].resize(1);
   }
+  for (int k = 0; k < 2; k++)
+    for (size_t i = 0; i < p->lanes[k].size(); i++) {
+      wu_lane &l = p->lanes[k][i];
+      HIPDIE(hipStreamCreateWithFlags(&l.q, hipStreamNonBlocking), "pool");
+      HIPDIE(hipMalloc((void **)&l.d_list, p->P * sizeof(u32)), "pool");
+      HIPDIE(hipMalloc((void **)&l.d_len, 2u * p->P * sizeof(u32)), "pool");
+      HIPDIE(hipHostMalloc((void **)&l.h_pick, p->P * 4u * sizeof(u32), hipHostMallocPortable), "pool");
+      HIPDIE(hipHostMalloc((void **)&l.h_list, p->P * 2u * sizeof(u32), hipHostMallocPortable), "pool");
+      if (k == 1) l.ws = c->ws + (size_t)(i % c->nstreams) * c->nslots * (c->slot_bytes + c->spill_bytes);
+    }
   HIPDIE(hipHostMalloc((void **)&p->h_in, (size_t)p->P * c->L.M, hipHostMallocPortable), "pool");
   HIPDIE(hipHostMalloc((void **)&p->h_out, (size_t)p->P * c->L.out_a, hipHostMallocPortable), "pool");
   for (uint32_t i = p->P; i-- > 0;) p->free_slabs.push_back(i);
@@ -1441,76 +1469,154 @@ static wu_pool *pool_on(int device, unsigned bs100k)
  * their own leaders: a collect round touches only slabs whose states are in collect(), an encode round only
  * slabs whose states are in encode(), so the two overlap -- while the device works through an encode round, the
  * callers whose transmit() returned are already collecting, and the next encode round is full when this one ends. */
-static void pool_round(wu_pool *p, int stage, const std::vector<wu_req *> &batch)
+static void pool_round(wu_pool *p, int stage, wu_lane &ln, std::vector<wu_req *> &batch)
 {
   lbzamd_ctx *c = p->c;
-  wu_lane &ln = p->lane[stage];
+  static const bool trace = getenv("LBZAMD_POOL_TRACE") != nullptr;
+  const double t0 = trace ? std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count() : 0.0;
   HIPDIE(hipSetDevice(c->device), "work-unit round");
-  std::vector<u32> list, len;
-  for (wu_req *r : batch) {
-    list.push_back(r->slab);
-    if (stage == 0) {
-      len.push_back(r->len);
-      HIPDIE(hipMemcpyAsync(c->d_in + (size_t)r->slab * c->L.M, p->h_in + (size_t)r->slab * c->L.M, r->len, hipMemcpyHostToDevice, ln.q), "collect");
-    }
-  }
-  const u32 cnt = (u32)list.size();
-  HIPDIE(hipMemcpyAsync(ln.d_list, list.data(), cnt * sizeof(u32), hipMemcpyHostToDevice, ln.q), "round");
+  const u32 cnt = (u32)batch.size();
+  for (u32 i = 0; i < cnt; i++) { ln.h_list[i] = batch[i]->slab; ln.h_list[cnt + i] = batch[i]->len; }
+  HIPDIE(hipMemcpyAsync(ln.d_list, ln.h_list, cnt * sizeof(u32), hipMemcpyHostToDevice, ln.q), "round");
   if (stage == 0) {
-    HIPDIE(hipMemcpyAsync(ln.d_len, len.data(), cnt * sizeof(u32), hipMemcpyHostToDevice, ln.q), "collect");
+    HIPDIE(hipMemcpyAsync(ln.d_len, ln.h_list + cnt, cnt * sizeof(u32), hipMemcpyHostToDevice, ln.q), "collect");
+    /* the callers' slabs: read from the page-locked staging area by the device itself (k_pool_in) -- one launch, not a copy
+       call per slab */
+    const u32 parts = cnt >= 128u ? 4u : (cnt >= 32u ? 8u : 16u);
+    hipLaunchKernelGGL(k_pool_in, dim3(parts * cnt), dim3(256), 0, ln.q, (const u8 *)p->h_in, c->d_in, c->L.M, (const u32 *)ln.d_list, (const u32 *)ln.d_len, parts);
     hipLaunchKernelGGL(k_collect, dim3(cnt), dim3(LBZ_COLLECT_WG), 0, ln.q, (const u8 *)c->d_in,
                        (u64)p->P * c->L.M, c->L, c->T, c->meta, 0u, (const u32 *)ln.d_list, (const u32 *)ln.d_len);
+    hipLaunchKernelGGL(k_meta_pick, dim3((cnt + 255u) / 256u), dim3(256), 0, ln.q, (const lbz_block_meta *)c->meta, (const u32 *)ln.d_list, cnt, ln.h_pick);
   } else {
-    u8 *ws = c->ws, *wsp = c->ws + (size_t)c->nslots * c->slot_bytes;
+    u8 *ws = ln.ws, *wsp = ln.ws + (size_t)c->nslots * c->slot_bytes;
+    const bool beside = p->lanes[1].size() > 1u;              /* other rounds may run beside this one */
+    /* A block the text rounds do not finish (a repeat-heavy one: 17 rank rounds, 60 ms for a lone block) must not hold up the
+       round's other blocks, whose callers wait: behind the text rounds the round's list is split in two of the same length
+       (k_pool_split: the absent entries name the pool's spare slab, whose blocks are empty) -- the blocks that are sorted go
+       through MTF, coding and k_pool_out at once and their callers are released; if any block is left, the rank rounds and
+       the same three stages follow for those. */
+    u32 *fast = ln.d_len, *slow = ln.d_len + cnt;             /* (d_len: free in an encode round; 2 P entries) */
+    for (u32 i = 0; i < cnt; i++) ln.h_pick[4u * i + 3u] = 0xFFFFFFFFu;          /* "not back yet" */
     for (u32 o = 0; o < cnt; o += c->nslots) {
       /* primaries only (grid = count): what collect() left over went back to the caller */
       const u32 count = cnt - o < c->nslots ? cnt - o : c->nslots;
       const u32 *lst = ln.d_list + o;
-      for (int ph = 0; ph < 3; ph++) launch_sort(c, ln.q, 0u, count, count, ws, wsp, lst, ph);
-      launch_mtf(c, ln.q, 0u, count, count, count, lst);
-      hipLaunchKernelGGL(k_encode, dim3(count), dim3(LBZ_ENCODE_WG), 0, ln.q, (const u16 *)c->V, (const u32 *)c->freq, c->O, c->meta, c->L, 0u, count, lst);
+      for (int ph = 0; ph < 2; ph++) launch_sort(c, ln.q, 0u, count, count, ws, wsp, lst, ph, beside);
+      launch_sort(c, ln.q, 0u, count, count, ws, wsp, lst, 3, beside);
+      hipLaunchKernelGGL(k_pool_split, dim3((count + 255u) / 256u), dim3(256), 0, ln.q, (const lbz_block_meta *)c->meta, lst, count, fast + o, slow + o, p->P);
+      launch_mtf(c, ln.q, 0u, count, count, count, fast + o);
+      hipLaunchKernelGGL(k_encode, dim3(count), dim3(LBZ_ENCODE_WG), 0, ln.q, (const u16 *)c->V, (const u32 *)c->freq, c->O, c->meta, c->L, 0u, count, (const u32 *)(fast + o));
+      if (cnt > c->nslots) {                                   /* (a round in pieces: the next piece needs the workspaces) */
+        launch_sort(c, ln.q, 0u, count, count, ws, wsp, slow + o, 4, beside);
+        launch_mtf(c, ln.q, 0u, count, count, count, slow + o);
+        hipLaunchKernelGGL(k_encode, dim3(count), dim3(LBZ_ENCODE_WG), 0, ln.q, (const u16 *)c->V, (const u32 *)c->freq, c->O, c->meta, c->L, 0u, count, (const u32 *)(slow + o));
+      }
+    }
+    /* the packed blocks and the four words each caller waits for: written into the page-locked staging area by the device */
+    const u32 oparts = cnt >= 64u ? 2u : 4u;
+    if (cnt > c->nslots) {
+      hipLaunchKernelGGL(k_pool_out, dim3(oparts * cnt), dim3(256), 0, ln.q, (const u8 *)c->O, (const lbz_block_meta *)c->meta, c->L,
+                         (const u32 *)ln.d_list, p->h_out, ln.h_pick, oparts, p->P);
+    } else {
+      hipLaunchKernelGGL(k_pool_out, dim3(oparts * cnt), dim3(256), 0, ln.q, (const u8 *)c->O, (const lbz_block_meta *)c->meta, c->L,
+                         (const u32 *)fast, p->h_out, ln.h_pick, oparts, p->P);
+      /* the callers whose blocks are done; the rank rounds and the rest only if a block needs them */
+      HIPDIE(hipStreamSynchronize(ln.q), "round");
+      u32 back = 0;
+      for (u32 i = 0; i < cnt; i++)
+        if (ln.h_pick[4u * i + 3u] != 0xFFFFFFFFu) back++;
+      if (back < cnt) {
+        launch_sort(c, ln.q, 0u, cnt, cnt, ws, wsp, slow, 4, beside);          /* (the split list: the released callers' slabs may be in other rounds by now) */
+        launch_mtf(c, ln.q, 0u, cnt, cnt, cnt, slow);
+        hipLaunchKernelGGL(k_encode, dim3(cnt), dim3(LBZ_ENCODE_WG), 0, ln.q, (const u16 *)c->V, (const u32 *)c->freq, c->O, c->meta, c->L, 0u, cnt, (const u32 *)slow);
+        hipLaunchKernelGGL(k_pool_out, dim3(oparts * cnt), dim3(256), 0, ln.q, (const u8 *)c->O, (const lbz_block_meta *)c->meta, c->L,
+                           (const u32 *)slow, p->h_out, ln.h_pick, oparts, p->P);
+        if (back) {
+          std::lock_guard<std::mutex> lk(p->mu);
+          for (u32 i = 0; i < cnt; i++)
+            if (ln.h_pick[4u * i + 3u] != 0xFFFFFFFFu) {
+              wu_req *b = batch[i];
+              b->consumed = ln.h_pick[4u * i]; b->out_len = ln.h_pick[4u * i + 1u]; b->crc = ln.h_pick[4u * i + 2u]; b->err = ln.h_pick[4u * i + 3u];
+              b->done = true;
+              b->cv.notify_one();
+              batch[i] = nullptr;                             /* its thread goes on: the request is gone */
+            }
+        }
+      }
     }
   }
-  /* the four words each caller waits for, packed on the device: one small copy */
-  hipLaunchKernelGGL(k_meta_pick, dim3((cnt + 255u) / 256u), dim3(256), 0, ln.q, (const lbz_block_meta *)c->meta, (const u32 *)ln.d_list, cnt, ln.d_pick);
-  HIPDIE(hipMemcpyAsync(ln.h_pick, ln.d_pick, (size_t)cnt * 4u * sizeof(u32), hipMemcpyDeviceToHost, ln.q), "round");
   HIPDIE(hipStreamSynchronize(ln.q), "round");
   HIPDIE(hipGetLastError(), "round");
   for (u32 i = 0; i < cnt; i++) {
     wu_req *b = batch[i];
+    if (!b) continue;                                          /* released early: its thread has gone on */
     b->consumed = ln.h_pick[4u * i]; b->out_len = ln.h_pick[4u * i + 1u]; b->crc = ln.h_pick[4u * i + 2u]; b->err = ln.h_pick[4u * i + 3u];
   }
-  if (stage == 1) {
-    /* the packed blocks, now that their sizes are known: DMA into the pinned staging area */
-    for (wu_req *b : batch) {
-      const size_t bytes = ((size_t)b->out_len + 3u) / 4u * 4u;
-      HIPDIE(hipMemcpyAsync(p->h_out + (size_t)b->slab * c->L.out_a, c->O + lbz_out_off(c->L, 2u * b->slab), bytes, hipMemcpyDeviceToHost, ln.q), "round");
-    }
-    HIPDIE(hipStreamSynchronize(ln.q), "round");
+  if (trace) {
+    const double t1 = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
+    fprintf(stderr, "round kind %d lane %d blocks %u at %.2f ms took %.2f ms\n", stage, (int)(&ln - &p->lanes[stage][0]), cnt, t0 - 1e3 * (double)(long)(t0 / 1e3), t1 - t0);
   }
 }
 
-/* post a request and return when it is done; whoever finds its lane without a leader leads one round of it */
+/* Post a request and return when it is done.  A waiting request's thread leads a round when a lane of its kind is free and
+ * the round is worth starting: a collect round at once (it is short; whoever arrives meanwhile forms the next one), an encode
+ * round when the device has no encode round to work on -- after a pause of a few hundred microseconds for the rest of the
+ * burst the last collect round released, for a round of two blocks costs the launch chain of a round of sixty -- or when
+ * HALF of the states that hold a slab are waiting for one: the callers then move as two convoys whose rounds overlap on the
+ * device, one in the kernels while the other is in transmit(), the caller's own code and collect().  The others sleep until
+ * their request is marked done. */
+/* may a round of kind k start now, and on which lane (mu held) */
+static wu_lane *pool_may_lead(wu_pool *p, int k)
+{
+  if (p->pending[k].empty() || p->gathering[k]) return nullptr;
+  const uint32_t in_use = p->P - (uint32_t)p->free_slabs.size();
+  if (!(k == 0 || p->inflight[1] == 0u || p->pending[1].size() * 2u >= in_use)) return nullptr;
+  for (wu_lane &l : p->lanes[k]) if (!l.busy) return &l;
+  return nullptr;
+}
+/* something changed that may allow a round (a lane is free again, fewer states hold slabs): wake ONE waiting request's thread
+   per kind to lead it (mu held) */
+static void pool_kick(wu_pool *p)
+{
+  for (int k = 0; k < 2; k++)
+    if (pool_may_lead(p, k)) p->pending[k].front()->cv.notify_one();
+}
+
 static void pool_submit(wu_pool *p, wu_req *r)
 {
+  static const int gather_us = getenv("LBZAMD_POOL_GATHER") ? atoi(getenv("LBZAMD_POOL_GATHER")) : 100;    /* (tuning) */
   std::unique_lock<std::mutex> lk(p->mu);
-  wu_lane &ln = p->lane[r->stage];
+  const int k = r->stage;
   r->done = false;
-  ln.pending.push_back(r);
+  p->pending[k].push_back(r);
+  if (p->gathering[k]) p->cv_arrive.notify_one();
   while (!r->done) {
-    if (!ln.leader) {
-      ln.leader = true;
-      std::vector<wu_req *> batch;
-      batch.swap(ln.pending);
-      lk.unlock();
-      pool_round(p, r->stage, batch);
-      lk.lock();
-      for (wu_req *b : batch) b->done = true;
-      ln.leader = false;
-      p->cv.notify_all();
-    } else {
-      p->cv.wait(lk);
+    wu_lane *free_lane = pool_may_lead(p, k);
+    if (!free_lane) { r->cv.wait_for(lk, std::chrono::milliseconds(20)); continue; }      /* (the time limit: a lost wake-up costs a pause, not the job) */
+    wu_lane &ln = *free_lane;
+    ln.busy = true;
+    if (k == 1 && p->inflight[1] == 0u && gather_us > 0) {
+      p->gathering[k] = true;
+      for (int waits = 0; waits < 6; waits++) {               /* as long as requests keep arriving */
+        const size_t had = p->pending[k].size();
+        const uint32_t in_use = p->P - (uint32_t)p->free_slabs.size();
+        if (had * 2u >= in_use) break;
+        p->cv_arrive.wait_for(lk, std::chrono::microseconds(gather_us));
+        if (p->pending[k].size() == had) break;
+      }
+      p->gathering[k] = false;
     }
+    std::vector<wu_req *> batch;
+    batch.swap(p->pending[k]);
+    p->inflight[k]++;
+    lk.unlock();
+    pool_round(p, k, ln, batch);
+    lk.lock();
+    for (wu_req *b : batch)
+      if (b) { b->done = true; if (b != r) b->cv.notify_one(); }
+    p->inflight[k]--;
+    ln.busy = false;
+    pool_kick(p);
   }
 }
 
@@ -1591,13 +1697,14 @@ extern "C" int lbzamd_collect(encoder_state *e, const uint8_t *buf, size_t *buf_
   wu_pool *p = pool_for(e->mbs / 100000u);
   {
     std::unique_lock<std::mutex> lk(p->mu);
-    while (p->free_slabs.empty()) p->cv.wait(lk);           /* more states in flight than the pool has slabs */
+    while (p->free_slabs.empty()) p->cv_slab.wait(lk);      /* more states in flight than the pool has slabs */
     e->slab = p->free_slabs.back();
     p->free_slabs.pop_back();
   }
   e->pool = p;
   memcpy(p->h_in + (size_t)e->slab * p->c->L.M, buf, avail);            /* in the caller's thread */
-  wu_req r = { e->slab, (uint32_t)avail, buf, 0, false, 0u, 0u, 0u, 0u };
+  wu_req r;
+  r.slab = e->slab; r.len = (uint32_t)avail; r.buf = buf; r.stage = 0; r.done = false; r.consumed = r.out_len = r.crc = r.err = 0u;
   pool_submit(p, &r);
   e->collected = r.consumed;
   *buf_sz -= r.consumed;
@@ -1609,7 +1716,8 @@ extern "C" size_t lbzamd_encode(encoder_state *e, uint32_t *crc)
 {
   if (!e || e->magic != ENC_MAGIC || !e->pool || !crc) { g_err = "encode() before collect()"; die("encode"); }
   wu_pool *p = e->pool;
-  wu_req r = { e->slab, 0u, nullptr, 1, false, 0u, 0u, 0u, 0u };
+  wu_req r;
+  r.slab = e->slab; r.len = 0u; r.buf = nullptr; r.stage = 1; r.done = false; r.consumed = r.out_len = r.crc = r.err = 0u;
   pool_submit(p, &r);
   if (r.err) { g_err = "device pipeline error"; die("encode"); }
   e->out_len = r.out_len;
@@ -1630,8 +1738,9 @@ static void pool_release(encoder_state *e)
   {
     std::lock_guard<std::mutex> lk(p->mu);
     p->free_slabs.push_back(e->slab);
+    pool_kick(p);                                   /* (one state fewer holds a slab: the waiting ones may be half of them now) */
   }
-  p->cv.notify_all();
+  p->cv_slab.notify_one();
   e->pool = nullptr;
 }
 
@@ -1688,10 +1797,10 @@ struct wd_req {
   uint64_t avail;                         /* bits there are (the 32 stand-in bits included) */
   lbz_dblock rec;
   bool past = false, done = false;
+  std::condition_variable cv;             /* the request's own (cf. wu_req): its thread alone is woken, when the request is done or to lead the next round */
 };
 struct wd_pool {
   std::mutex mu;
-  std::condition_variable cv;
   std::vector<wd_req *> queue;
   bool leader = false;
   lbzamd_dctx *c = nullptr;
@@ -1863,12 +1972,12 @@ void wd_submit(wd_req *r)
       lk.unlock();
       wd_round(batch);
       lk.lock();
-      for (wd_req *b : batch) b->done = true;
+      for (wd_req *b : batch) { b->done = true; if (b != r) b->cv.notify_one(); }
       g_wd.leader = false;
-      g_wd.cv.notify_all();
+      if (!g_wd.queue.empty()) g_wd.queue.front()->cv.notify_one();       /* the next round's leader */
       continue;
     }
-    g_wd.cv.wait(lk);
+    r->cv.wait_for(lk, std::chrono::milliseconds(20));
   }
 }
 }  // namespace

@@ -112,6 +112,9 @@ __global__ void k_gather(const u8 *Obase, const lbz_block_meta *meta, lbz_layout
                          const lbz_stream_state *st, u8 *out, u32 nslabs);
 
 __global__ void k_meta_pick(const lbz_block_meta *meta, const u32 *slabs, u32 count, u32 *out);
+__global__ void k_pool_out(const u8 *Obase, const lbz_block_meta *meta, lbz_layout L, const u32 *slabs, u8 *h_out, u32 *h_pick, u32 parts, u32 spare);
+__global__ void k_pool_split(const lbz_block_meta *meta, const u32 *slabs, u32 count, u32 *fast, u32 *slow, u32 spare);
+__global__ void k_pool_in(const u8 *h_in, u8 *d_in, u32 M, const u32 *slabs, const u32 *lens, u32 parts);
 
 __device__ __forceinline__ u32 lbz_queue_block(u32 q, u32 nslabs)      /* whole chunk: k_gather */
 {

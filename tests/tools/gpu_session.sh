@@ -21,7 +21,17 @@ for step in "$@"; do
     small) timeout 600 python tests/tools/small_rounds.py 2>&1 | tee gpurun_out/${TAG}_small_rounds.txt | tail -30 ;;
     prof)  timeout 1500 bash tests/tools/run_profiles.sh $TAG 2>&1 | tail -60 ;;
     pmc)   timeout 1500 bash tests/tools/run_pmc.sh ${TAG}_pmc $a $b 2>&1 | tail -40 ;;
-    wu)    for n in 16 64 256; do timeout 300 python tests/tools/hostpath_perf.py $n 2>&1 | tail -2; done | tee gpurun_out/${TAG}_workunits.txt ;;
+    wu)    # the work-unit interface driven by 16/64/256 pthreads (lbzamd_compress -w), 450 MB of wiki; wu:<lib> = with that library preloaded instead
+           python - <<PY
+import sys; sys.path.insert(0, "/root/repo")
+import bench
+open("/tmp/in.bin", "wb").write(bench.gen_input("wiki", 450 * 1000000, 2))
+PY
+           for w in 16 64 256; do
+             ( [ -n "$a" ] && export LD_PRELOAD=/root/repo/lbzip2_amd/csrc/variants/$a.so; timeout 120 ./lbzip2_amd/host/lbzamd_compress -9 -w $w -t -r 3 < /tmp/in.bin 2>&1 > /tmp/out_$w.bz2 | grep -v amdgpu | tail -1 )
+           done | sed "s/^/${a:-default} /" | tee -a gpurun_out/${TAG}_workunits.txt
+           timeout 120 ./lbzip2_amd/host/lbzamd_compress -9 -t -r 2 < /tmp/in.bin 2>&1 > /tmp/out_b.bz2 | grep -v amdgpu | tail -1
+           cmp /tmp/out_b.bz2 /tmp/out_256.bz2 && echo "work-unit stream identical to the batch call's" | tee -a gpurun_out/${TAG}_workunits.txt ;;
     file)  timeout 900 bash tests/tools/gpu_filemode.sh 2>&1 | tee gpurun_out/${TAG}_filemode.txt | tail -30 ;;
     ab)    # A/B on one box: sweep_r5.py with the default library, then with lbzip2_amd/csrc/variants/<a>.so    ab:<variant>:<slabs>:<kinds>
            for lib in default $a; do
