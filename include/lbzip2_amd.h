@@ -193,6 +193,24 @@ int  lbzamd_decompress_device(lbzamd_dctx *ctx, const void *d_in, size_t len, vo
  * (release it) and *out_len says how many.                                                                         */
 int  lbzamd_decompress_alloc(lbzamd_dctx *ctx, const uint8_t *in, size_t len, uint8_t **out, size_t *out_len);
 void lbzamd_free(void *p);
+/* A stream taken WINDOW BY WINDOW, in bounded memory (the reference reads, decodes and writes as it goes: src/expand.c:547-690,
+ * src/process.c:260-307): `in` holds the bytes of the input from the carry position of the window before it (the first
+ * window: from the start of the file) up to as far as the caller has read, `final` says that the input ends there.  The whole
+ * blocks of the window are decoded -- a block counts as whole when the magic behind it is in the window too -- and come back
+ * as lbzamd_decompress_alloc's do; `rs` (zeroed before the first window) carries the parser's state to the next call, and
+ * rs->consumed_bit says where it begins: the caller keeps the bytes from consumed_bit / 8 on, reads more behind them and calls
+ * again.  consumed_bit / 8 == 0 with final == 0 means the window held no whole block: it must grow.  rs->finished: the last
+ * stream is closed and what follows is not a stream header -- the rest of the input is ignored, as bzip2 does.
+ * An input that fits one window (first and final at once) is treated exactly as lbzamd_decompress_alloc treats it.  Across
+ * windows one thing differs from it: a block-level error (CRC, size, origin pointer) is reported with its window instead of
+ * being held back until the parser has looked at everything behind it. */
+typedef struct lbzamd_dresume {
+  uint64_t consumed_bit;     /* out: bit of `in` the next window starts at (its bits below consumed_bit % 8 are spent) */
+  uint32_t started;          /* 0 before the first window */
+  uint32_t in_stream, level, cc, stream_blocks, finished, nblocks_total, nstreams_total;
+  uint64_t base_bytes;       /* bytes of the input in front of the next window */
+} lbzamd_dresume;
+int  lbzamd_decompress_window(lbzamd_dctx *ctx, const uint8_t *in, size_t len, int final, lbzamd_dresume *rs, uint8_t **out, size_t *out_len);
 int  lbzamd_decompress_host(lbzamd_dctx *ctx, const uint8_t *in, size_t len, uint8_t *out, size_t out_cap, size_t *out_len);
 int  lbzamd_dget_stats(lbzamd_dctx *ctx, lbzamd_dstats *st);
 /* After a -3: WHY the stream was refused, as the reference's enum error (src/common.h:54-76: 3 ERR_MAGIC bad stream header

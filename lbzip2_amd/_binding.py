@@ -24,7 +24,7 @@ EXPORTS = [
     "lbzamd_compress_device_body", "lbzamd_compress_host_body", "lbzamd_fold_parts",
     "lbzamd_pinned_alloc", "lbzamd_pinned_free", "lbzamd_device_count",
     "lbzamd_dcreate", "lbzamd_ddestroy", "lbzamd_decompress_device", "lbzamd_decompress_host", "lbzamd_dget_stats",
-    "lbzamd_decompress_alloc", "lbzamd_free", "lbzamd_last_error_code",
+    "lbzamd_decompress_alloc", "lbzamd_free", "lbzamd_last_error_code", "lbzamd_decompress_window",
 ]
 
 
@@ -54,6 +54,12 @@ def fold_parts(cc, parts):
         r = nblocks & 31
         cc = (((cc << r) | (cc >> (32 - r))) & 0xFFFFFFFF if r else cc) ^ fold
     return cc
+
+
+class DResume(C.Structure):
+    _fields_ = [("consumed_bit", C.c_uint64), ("started", C.c_uint32), ("in_stream", C.c_uint32), ("level", C.c_uint32), ("cc", C.c_uint32),
+                ("stream_blocks", C.c_uint32), ("finished", C.c_uint32), ("nblocks_total", C.c_uint32), ("nstreams_total", C.c_uint32),
+                ("base_bytes", C.c_uint64)]
 
 
 class DStats(C.Structure):
@@ -127,6 +133,8 @@ class Library:
         lib.lbzamd_decompress_alloc.restype = C.c_int
         lib.lbzamd_free.argtypes = [vp]
         lib.lbzamd_free.restype = None
+        lib.lbzamd_decompress_window.argtypes = [vp, vp, sz, C.c_int, C.POINTER(DResume), C.POINTER(C.POINTER(C.c_uint8)), szp]
+        lib.lbzamd_decompress_window.restype = C.c_int
         lib.lbzamd_dget_stats.argtypes = [vp, C.POINTER(DStats)]
         lib.lbzamd_dget_stats.restype = C.c_int
         lib.lbzamd_bound.argtypes = [sz]
@@ -404,6 +412,40 @@ class Decoder:
         if rc:
             raise LbzError("lbzamd_decompress_host: " + self.L.error())
         return out.raw[:n.value]
+
+    def decompress_windows(self, data, window):
+        """The input taken `window` bytes at a time (lbzamd_decompress_window), as lbzamd_io_decompress does: the caller's loop of
+        include/lbzip2_amd.h -- keep the bytes from consumed_bit / 8 on, read more behind them, grow a window that held no
+        whole block.  Returns (bytes, windows taken); raises LbzError with .decoded_in_front like decompress()."""
+        data = bytes(data)
+        rs = DResume()
+        out = bytearray()
+        pos = 0                       # bytes of `data` "read" so far
+        buf = b""
+        calls = 0
+        while True:
+            want = max(window, 1)
+            take = data[pos:pos + max(0, want - len(buf))]
+            pos += len(take)
+            buf += take
+            final = pos >= len(data)
+            p = C.POINTER(C.c_uint8)(); n = C.c_size_t()
+            rc = self.L.lib.lbzamd_decompress_window(self.h, buf, len(buf), 1 if final else 0, C.byref(rs), C.byref(p), C.byref(n))
+            calls += 1
+            got = C.string_at(p, n.value) if p else b""
+            if p:
+                self.L.lib.lbzamd_free(p)
+            if rc:
+                e = LbzError("lbzamd_decompress_window: " + self.L.error())
+                e.decoded_in_front = bytes(out) + got
+                raise e
+            out += got
+            if final:
+                return bytes(out), calls
+            keep = rs.consumed_bit // 8
+            if keep == 0:
+                window *= 2
+            buf = buf[keep:]
 
     def decompress_device(self, d_in, length, d_out, out_cap):
         n = C.c_size_t()

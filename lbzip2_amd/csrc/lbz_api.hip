@@ -878,6 +878,8 @@ struct lbzamd_dctx {
   u8 *d_in = nullptr, *d_out = nullptr;
   size_t d_in_cap = 0, d_out_cap = 0;
   uint32_t marks_cap = 0;
+  lbzamd_dresume *rs = nullptr;              /* lbzamd_decompress_window: this call takes one window of a longer input (state in, state out) */
+  bool rs_final = true;
   bool grow_out = false;                     /* lbzamd_decompress_alloc: the output buffer (d_out) grows with what the blocks turn out to hold */
   u8 *h_in = nullptr, *h_out = nullptr;      /* the work-unit interface: page-locked staging of one block's bits and bytes (copies of pageable
                                                 memory wait for the whole device, i.e. for every other worker thread's block) */
@@ -950,7 +952,16 @@ extern "C" int lbzamd_decompress_device(lbzamd_dctx *c, const void *d_in_v, size
   c->stats.n_in = len;
   g_err_code = 0;
   *out_len = 0;
-  if (len < 14) {
+  lbzamd_dresume *const rs = c->rs;
+  const bool windowed = rs != nullptr && !(rs->started == 0u && c->rs_final);     /* (a first window that is the last one too: the whole input) */
+  const bool final = !windowed || c->rs_final;
+  const uint64_t lenbits = (uint64_t)len * 8u;
+  /* the reference takes its input in 32-bit words, the last one filled up with zero bytes (expand.c:835-842): where that
+     filling ends, in this buffer's bits (a later window begins rs->base_bytes into the file) */
+  const uint64_t base_bytes = windowed ? rs->base_bytes : 0u;
+  const uint64_t padbits = ((base_bytes + (uint64_t)len + 3u) / 4u * 4u - base_bytes) * 8u;
+  if (windowed && !final && len < 14) { rs->consumed_bit = rs->started && rs->in_stream ? rs->consumed_bit & 7u : 0u; return 0; }      /* nothing whole in here yet */
+  if (len < 14 && !(windowed && rs->started)) {
     /* no room for a header and a trailer.  As the reference tells the two apart (process.c:664-681, expand.c:435): without
        "BZh1".."BZh9" in front it is not a bzip2 file, with it the file ends too early */
     uint8_t h4[16] = { 0 };
@@ -1019,7 +1030,7 @@ extern "C" int lbzamd_decompress_device(lbzamd_dctx *c, const void *d_in_v, size
   /* What the reference's parser says when the chain ends at bit `at` with no magic there (parse.c:152-262): it takes a header
      16 bits at a time and stops at the first word that does not fit -- ERR_HEADER -- or that is not all there -- ERR_EOF. */
   auto no_magic_at = [&](uint64_t at) -> int {
-    const uint64_t nbits = ((uint64_t)len + 3u) / 4u * 32u, by = at >> 3;   /* the reference takes its input in 32-bit words, the last one filled up with zero bytes (expand.c:835-842) */
+    const uint64_t nbits = padbits, by = at >> 3;
     std::vector<uint8_t> h(12, 0);
     if (by < len && hipMemcpy(h.data(), d_in + by, std::min<size_t>(11, len - by), hipMemcpyDeviceToHost) != hipSuccess) return RE_HEADER;
     auto word = [&](unsigned k) -> int { return at + 16u * (k + 1u) > nbits ? -1 : (int)(rd_be32_bits(h, (at & 7u) + 16u * k) >> 16); };
@@ -1035,14 +1046,18 @@ extern "C" int lbzamd_decompress_device(lbzamd_dctx *c, const void *d_in_v, size
     return RE_EOF;                               /* a whole magic and no mark: its CRC words are cut off */
   };
   unsigned level0 = 0;
+  bool resume_finished = false;                 /* a later window that begins behind a closed stream with something that is no header */
   {
-    const int h = header_at(0, &level0);
+    int h = 1;
+    if (windowed && rs->started && rs->in_stream) level0 = rs->level;            /* a later window, in the middle of a stream */
+    else h = header_at(0, &level0);
     if (h < 0) return fail_msg("hipMemcpy", hipGetLastError());
+    if (h == 0 && windowed && rs->started) { resume_finished = true; h = 1; level0 = 9; }     /* trailing garbage is ignored, as bzip2 does */
     if (h == 0) { g_err = "lbzamd_decompress: not a bzip2 stream (bad header)"; g_err_code = RE_MAGIC; return -3; }
     unsigned lvl = level0;
     for (size_t i = 0; i < marks.size(); i++) {
       const uint64_t bit = marks[i] >> 1;
-      if (bit < 32) continue;
+      if (bit < 32 && !(windowed && rs->started && rs->in_stream)) continue;      /* (inside the stream header -- unless this window begins in the middle of a stream) */
       if (marks[i] & 1u) {
         unsigned l2;
         const int h2 = header_at((bit + 48 + 32 + 7) / 8, &l2);
@@ -1071,6 +1086,18 @@ extern "C" int lbzamd_decompress_device(lbzamd_dctx *c, const void *d_in_v, size
   unsigned level = level0;
   bool in_stream = true, finished = false;      /* finished: the last stream is closed and what follows is not a header */
   uint32_t cc = 0, nblocks = 0, stream_blocks = 0;
+  if (windowed && rs->started && rs->in_stream) { expect = rs->consumed_bit & 7u; cc = rs->cc; stream_blocks = rs->stream_blocks; }
+  if (resume_finished || (windowed && rs->finished)) { finished = true; in_stream = false; }
+  /* windows: a block (or an end-of-stream marker) is taken only if what must follow it can be seen -- the next magic, the
+     marker's CRC, the next stream's header; else the window's walk ends in front of it and the next window begins there.
+     What lies more than CUT_BITS in front of the window's end is not cut off by it: it is judged as the whole input's is. */
+  const uint64_t CUT_BITS = 24u << 20;          /* 3 MB: no block is longer */
+  bool carry = false;                           /* the walk ended at a cut: no error, `expect` is where the next window begins */
+  auto near_end = [&](uint64_t bit) { return windowed && !final && bit + CUT_BITS > lenbits; };
+  auto mark_at = [&](uint64_t bit) {             /* is a magic of either kind known at `bit`, all 48 bits of it in the window */
+    auto it = std::lower_bound(marks.begin(), marks.end(), bit << 1);
+    return it != marks.end() && (*it >> 1) == bit;
+  };
   int pend_code = 0;                            /* the first block-level error met on the chain (see the walk) */
   std::string pend_msg;
   /* On an error (-3) the bytes IN FRONT of it are still delivered, as the reference has written what it decoded by then:
@@ -1130,9 +1157,10 @@ extern "C" int lbzamd_decompress_device(lbzamd_dctx *c, const void *d_in_v, size
         break;
       }
       if (is_end) {
+        const uint64_t sbyte = (bit + 48 + 32 + 7) / 8;
+        if (windowed && !final && sbyte + 14 > len) { carry = true; break; }       /* its CRC, or what follows it, is not all here yet */
         trailers.push_back({ bit, cc });
         in_stream = false;
-        const uint64_t sbyte = (bit + 48 + 32 + 7) / 8;
         unsigned l2;
         const int h2 = sbyte + 14 <= len ? header_at(sbyte, &l2) : 0;
         if (h2 < 0) return fail_msg("hipMemcpy", hipGetLastError());
@@ -1141,6 +1169,7 @@ extern "C" int lbzamd_decompress_device(lbzamd_dctx *c, const void *d_in_v, size
         continue;
       }
       lbz_dblock &b = hb[ci];
+      if (near_end(bit) && !(b.bit_used + 48u <= lenbits && mark_at(b.bit_used))) { carry = true; break; }   /* perhaps cut off: the next window's */
       const bool kernel_ok = !b.err || b.err == 11u || b.err == 12u;   /* decoded to its last code (11: only the CRC differs; 12: it ends where a run's count should stand) */
       bool behind_the_block = b.err == 11u || b.err == 12u || b.err == 9u;   /* errors found with the block's bits all taken: the chain itself goes on */
       /* more bytes than the stream's block size allows: the muxer looks at that first, whatever else the block's status is
@@ -1163,7 +1192,7 @@ extern "C" int lbzamd_decompress_device(lbzamd_dctx *c, const void *d_in_v, size
           g_err = buf;
           /* (c) a block whose codes ran past the last byte of the file (what it read there were zeros): retrieve() asked
              for more input and there was none -- ERR_EOF (decode.c:393-399) */
-          g_err_code = b.bit_used > ((uint64_t)len + 3u) / 4u * 32u ? RE_EOF : RE_HEADER;
+          g_err_code = b.bit_used > padbits ? RE_EOF : RE_HEADER;
           stop = true;
           break;
         }
@@ -1176,7 +1205,8 @@ extern "C" int lbzamd_decompress_device(lbzamd_dctx *c, const void *d_in_v, size
       expect = b.bit_used;
       nblocks++; stream_blocks++;
     }
-    if (!stop && last_batch && in_stream) {
+    if (!stop && !carry && last_batch && in_stream && near_end(expect)) carry = true;      /* the next magic is not (all) here yet */
+    if (!stop && !carry && last_batch && in_stream) {
       g_err_code = no_magic_at(expect);
       g_err = g_err_code == RE_EOF ? "lbzamd_decompress: stream without end-of-stream marker (truncated?)"
                                    : "lbzamd_decompress: no block or end-of-stream magic where the previous block ends (damaged or overrun block)";
@@ -1212,7 +1242,7 @@ extern "C" int lbzamd_decompress_device(lbzamd_dctx *c, const void *d_in_v, size
       emitted = emit_total;
     }
     if (stop) { *out_len = (size_t)emitted; return -3; }
-    if (hb.empty()) break;
+    if (hb.empty() || carry) break;
   }
   c->stats.nblocks = nblocks;
   c->stats.nstreams = (uint32_t)trailers.size();
@@ -1224,12 +1254,21 @@ extern "C" int lbzamd_decompress_device(lbzamd_dctx *c, const void *d_in_v, size
       const size_t nbytes = std::min<size_t>(8, len - by);
       HIPCHK(hipMemcpy(tail.data(), d_in + by, nbytes, hipMemcpyDeviceToHost));
       std::vector<uint8_t> h(tail.begin(), tail.begin() + nbytes);
-      if (tr.bit + 80u > ((uint64_t)len + 3u) / 4u * 32u) { g_err = "lbzamd_decompress: the end-of-stream marker's CRC is cut off"; g_err_code = RE_EOF; *out_len = (size_t)emitted; return -3; }   /* parse.c:276 */
+      if (tr.bit + 80u > padbits) { g_err = "lbzamd_decompress: the end-of-stream marker's CRC is cut off"; g_err_code = RE_EOF; *out_len = (size_t)emitted; return -3; }   /* parse.c:276 */
       const uint32_t want = rd_be32_bits(h, (tr.bit + 48) & 7u);
       if (want != tr.cc) { g_err = "lbzamd_decompress: stream CRC mismatch"; g_err_code = RE_STRMCRC; *out_len = (size_t)emitted; return -3; }
     }
   }
   if (pend_code) { g_err = pend_msg; g_err_code = pend_code; *out_len = (size_t)emitted; return -3; }
+  if (rs) {
+    /* where the next window begins: in a stream at the magic the chain expects next; between streams (a marker whose sequel
+       was cut off cannot be here: it is carried as a whole) at the byte behind the last trailer */
+    rs->consumed_bit = finished ? lenbits : expect;
+    rs->in_stream = in_stream ? 1u : 0u; rs->level = level; rs->cc = cc; rs->stream_blocks = stream_blocks; rs->finished = finished ? 1u : 0u;
+    rs->started = 1u;
+    rs->base_bytes = base_bytes + rs->consumed_bit / 8u;
+    rs->nblocks_total += nblocks; rs->nstreams_total += (uint32_t)trailers.size();
+  }
   c->stats.n_out = total;
   c->stats.ms_scan = ms[0]; c->stats.ms_huff = ms[1]; c->stats.ms_sort = ms[2]; c->stats.ms_walk = ms[3]; c->stats.ms_emit = ms[4];
   c->stats.ms_blocks = ms[5];
@@ -1297,6 +1336,16 @@ extern "C" int lbzamd_decompress_alloc(lbzamd_dctx *c, const uint8_t *in, size_t
   return rc;
 }
 extern "C" void lbzamd_free(void *p) { free(p); }
+
+/* one window of a longer input: include/lbzip2_amd.h */
+extern "C" int lbzamd_decompress_window(lbzamd_dctx *c, const uint8_t *in, size_t len, int final, lbzamd_dresume *rs, uint8_t **out, size_t *out_len)
+{
+  if (!c || !rs || !out || !out_len) { g_err = "lbzamd_decompress_window: bad argument"; return -1; }
+  c->rs = rs; c->rs_final = final != 0;
+  const int rc = lbzamd_decompress_alloc(c, in, len, out, out_len);
+  c->rs = nullptr; c->rs_final = true;
+  return rc;
+}
 
 extern "C" int lbzamd_dget_stats(lbzamd_dctx *c, lbzamd_dstats *st)
 {

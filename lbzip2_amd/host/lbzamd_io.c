@@ -419,9 +419,24 @@ int lbzamd_io_compress(int fd_in, int fd_out, const struct lbzamd_io_cfg *cfg, s
      while this thread page-locks the ring, position by position -- a position is S_UNBORN until its buffers exist, and the
      readers, which take chunks in order, begin as soon as the first ones do. */
   for (unsigned i = 0; i < e.nslots; i++) { e.slots[i].state = S_UNBORN; e.slots[i].turn = i; }
-  for (unsigned i = 0; i < e.npipes; i++) pthread_create(&th[nth++], NULL, pipeline_main, &e);
-  for (unsigned i = 0; i < e.nreaders; i++) pthread_create(&th[nth++], NULL, reader_main, &e);
-  for (unsigned i = 0; i < e.nwriters; i++) pthread_create(&th[nth++], NULL, writer_main, &e);
+  {
+    /* a thread that cannot be created (RLIMIT_NPROC, --pipelines=64 on 64 devices) fails the job: the ones that exist see
+       `failed` and leave, and only they are joined */
+    void *(*const mains[3])(void *) = { pipeline_main, reader_main, writer_main };
+    const unsigned counts[3] = { e.npipes, e.nreaders, e.nwriters };
+    for (unsigned k = 0; k < 3u && !e.failed; k++)
+      for (unsigned i = 0; i < counts[k]; i++) {
+        const int err = pthread_create(&th[nth], NULL, mains[k], &e);
+        if (err) {
+          pthread_mutex_lock(&e.mu);
+          fail_locked(&e, LBZAMD_IO_MEMORY, err, "pthread_create");
+          pthread_cond_broadcast(&e.cv);
+          pthread_mutex_unlock(&e.mu);
+          break;
+        }
+        nth++;
+      }
+  }
   pthread_t watch;
   const int watched = getenv("LBZAMD_IO_DEBUG") != NULL && pthread_create(&watch, NULL, watch_main, &e) == 0;
   /* (Tried: the contexts first, then the ring beside the running pipelines.  The contexts are then ready after 0.1-0.3 s, but
@@ -453,6 +468,16 @@ int lbzamd_io_compress(int fd_in, int fd_out, const struct lbzamd_io_cfg *cfg, s
   e.t_ring = now_s();
   for (unsigned i = 0; i < nth; i++) pthread_join(th[i], NULL);
   if (watched) { e.watch_stop = 1; pthread_join(watch, NULL); }
+  if (!e.failed && e.map) {
+    /* the job was sized from the file's length when it was opened: a file that grew meanwhile would be compressed short and
+       its original removed (the reference reads to the end of the file) */
+    struct stat sb;
+    if (fstat(fd_in, &sb) == 0 && (uint64_t)sb.st_size != (uint64_t)e.in_base + e.map_size) {
+      pthread_mutex_lock(&e.mu);
+      fail_locked(&e, LBZAMD_IO_READ, EIO, "read(): the input file changed its size while it was being compressed");
+      pthread_mutex_unlock(&e.mu);
+    }
+  }
   if (e.failed) { rc = e.failed; *sys_errno = e.sys_errno; snprintf(msg, msg_cap, "%s", e.msg); goto out; }
   {
     const uint32_t cc = e.cc;                                                              /* compress.c:304-321 */
@@ -543,6 +568,12 @@ static int whole_input(int fd, uint8_t **buf, size_t *len, int *pinned)
   return 0;
 }
 
+/* .bz2 -> bytes in BOUNDED memory (round 6; until then the whole input was read and every block decoded before a byte was
+ * written, where the reference reads, decodes and writes as it goes: src/process.c:260-307, src/expand.c:547-690): the input is
+ * taken a WINDOW at a time -- LBZAMD_IO_DWINDOW bytes, 256 MB by default --, the whole blocks of the window are decoded at once
+ * (lbzamd_decompress_window) and written before more is read; what is left of the window -- from the magic of the first block
+ * that may be cut off -- moves to the front of the next one.  `bzcat big.bz2 | head` ends when head does, a stream of any length
+ * goes through in the memory of one window and its bytes.  An input that fits one window is decoded exactly as before. */
 int lbzamd_io_decompress(int fd_in, int fd_out, int not_bzip2_copy, int report, struct lbzamd_io_stats *st,
                          int *sys_errno, int *err_code, char *msg, size_t msg_cap)
 {
@@ -552,30 +583,69 @@ int lbzamd_io_decompress(int fd_in, int fd_out, int not_bzip2_copy, int report, 
   if (!err_code) err_code = &dummy2;
   if (!msg) { msg = dummy_msg; msg_cap = sizeof dummy_msg; }
   *sys_errno = 0; *err_code = 0; msg[0] = 0;
-  uint8_t *z = NULL, *out = NULL;
-  size_t zlen = 0, n = 0;
-  int pinned = 0, rc = LBZAMD_IO_OK;
-  lbzamd_dctx *d = NULL;
-  const double t0 = now_s();
-  if (whole_input(fd_in, &z, &zlen, &pinned)) { *sys_errno = errno; snprintf(msg, msg_cap, "read()"); return errno == ENOMEM ? LBZAMD_IO_MEMORY : LBZAMD_IO_READ; }
-  const double t1 = now_s();
-  double t2 = t1;
-  /* process.c:664-681: four bytes decide whether this is a bzip2 file at all */
-  const int is_bz = zlen >= 4 && z[0] == 'B' && z[1] == 'Z' && z[2] == 'h' && z[3] >= '1' && z[3] <= '9';
-  if (!is_bz) {
-    if (not_bzip2_copy && fd_out >= 0) {
-      if (write_fully(fd_out, z, zlen, 0, 0)) { rc = LBZAMD_IO_WRITE; *sys_errno = errno; snprintf(msg, msg_cap, "write()"); }
-      n = zlen;
-      goto done;
-    }
-    rc = LBZAMD_IO_DATA; *err_code = 3;                   /* ERR_MAGIC */
-    goto done;
-  }
+  size_t cap = 256u << 20;
+  { const char *e = getenv("LBZAMD_IO_DWINDOW"); if (e && atol(e) > 0) cap = (size_t)atol(e); }
+  if (cap < 64u) cap = 64u;
   {
-    unsigned maxb = (unsigned)(zlen / 20000u + 8u);
-    if (lbzamd_dcreate(&d, -1, maxb > 2400u ? 2400u : maxb)) { rc = LBZAMD_IO_DEVICE; snprintf(msg, msg_cap, "%s", lbzamd_last_error()); goto done; }
-    const int drc = lbzamd_decompress_alloc(d, z, zlen, &out, &n);
-    t2 = now_s();
+    off_t base = 0; uint64_t size = 0;
+    if (positioned_ok(fd_in, 0, &base, &size) && size + 1u < cap) cap = (size_t)size + 1u;      /* a short file: no more than it needs (+1: its end shows) */
+  }
+  uint8_t *buf = malloc(cap), *out = NULL;
+  size_t have = 0, n = 0, zlen = 0, total = 0;
+  int rc = LBZAMD_IO_OK, eof = 0, first = 1;
+  unsigned windows = 0;
+  lbzamd_dctx *d = NULL;
+  lbzamd_dresume rs;
+  lbzamd_dstats acc;
+  memset(&rs, 0, sizeof rs);
+  memset(&acc, 0, sizeof acc);
+  const double t0 = now_s();
+  double t_read = 0, t_dec = 0, t_write = 0;
+  if (!buf) { *sys_errno = ENOMEM; snprintf(msg, msg_cap, "read()"); return LBZAMD_IO_MEMORY; }
+  for (;;) {
+    double t = now_s();
+    while (have < cap && !eof) {
+      const ssize_t r = read(fd_in, buf + have, cap - have);
+      if (r < 0) { if (errno == EINTR) continue; rc = LBZAMD_IO_READ; *sys_errno = errno; snprintf(msg, msg_cap, "read()"); goto done; }
+      if (r == 0) eof = 1; else { have += (size_t)r; zlen += (size_t)r; }
+    }
+    t_read += now_s() - t;
+    if (first) {
+      /* process.c:664-681: four bytes decide whether this is a bzip2 file at all */
+      const int is_bz = have >= 4 && buf[0] == 'B' && buf[1] == 'Z' && buf[2] == 'h' && buf[3] >= '1' && buf[3] <= '9';
+      if (!is_bz) {
+        if (not_bzip2_copy && fd_out >= 0) {                  /* copied through as it is, a window at a time */
+          for (;;) {
+            if (have && write_fully(fd_out, buf, have, 0, 0)) { rc = LBZAMD_IO_WRITE; *sys_errno = errno; snprintf(msg, msg_cap, "write()"); goto done; }
+            total += have; have = 0;
+            if (eof) break;
+            const ssize_t r = read(fd_in, buf, cap);
+            if (r < 0) { if (errno == EINTR) continue; rc = LBZAMD_IO_READ; *sys_errno = errno; snprintf(msg, msg_cap, "read()"); goto done; }
+            if (r == 0) eof = 1; else { have = (size_t)r; zlen += (size_t)r; }
+          }
+          goto done;
+        }
+        rc = LBZAMD_IO_DATA; *err_code = 3;                   /* ERR_MAGIC */
+        goto done;
+      }
+      unsigned maxb = (unsigned)(have / 20000u + 8u);
+      if (lbzamd_dcreate(&d, -1, maxb > 2400u ? 2400u : maxb)) { rc = LBZAMD_IO_DEVICE; snprintf(msg, msg_cap, "%s", lbzamd_last_error()); goto done; }
+      first = 0;
+    }
+    if (rs.finished) {                                        /* behind the last stream: read to the end, as the reference does, and ignore it */
+      have = 0;
+      if (eof) break;
+      continue;
+    }
+    t = now_s();
+    const int drc = lbzamd_decompress_window(d, buf, have, eof, &rs, &out, &n);
+    t_dec += now_s() - t;
+    windows++;
+    {
+      lbzamd_dstats ds;
+      lbzamd_dget_stats(d, &ds);
+      acc.nblocks += ds.nblocks; acc.nstreams += ds.nstreams; acc.ms_scan += ds.ms_scan; acc.ms_blocks += ds.ms_blocks; acc.ms_emit += ds.ms_emit;
+    }
     if (drc == -3) {
       rc = LBZAMD_IO_DATA; *err_code = lbzamd_last_error_code(); snprintf(msg, msg_cap, "%s", lbzamd_last_error());
       /* the bytes in front of the damage -- the whole blocks before the one that was refused -- go out as the reference's do
@@ -584,23 +654,35 @@ int lbzamd_io_decompress(int fd_in, int fd_out, int not_bzip2_copy, int report, 
       goto done;
     }
     if (drc) { rc = LBZAMD_IO_DEVICE; snprintf(msg, msg_cap, "%s", lbzamd_last_error()); goto done; }
+    t = now_s();
+    if (fd_out >= 0 && n && write_fully(fd_out, out, n, 0, 0)) { rc = LBZAMD_IO_WRITE; *sys_errno = errno; snprintf(msg, msg_cap, "write()"); goto done; }
+    t_write += now_s() - t;
+    total += n;
+    lbzamd_free(out); out = NULL; n = 0;
+    if (eof) break;
+    const size_t keep = (size_t)(rs.consumed_bit / 8u);
+    if (keep == 0) {                                          /* no whole block in the window: a larger one */
+      uint8_t *b2 = realloc(buf, cap * 2u);
+      if (!b2) { rc = LBZAMD_IO_MEMORY; *sys_errno = ENOMEM; snprintf(msg, msg_cap, "read()"); goto done; }
+      buf = b2; cap *= 2u;
+    } else {
+      memmove(buf, buf + keep, have - keep);
+      have -= keep;
+    }
   }
-  if (fd_out >= 0 && write_fully(fd_out, out, n, 0, 0)) { rc = LBZAMD_IO_WRITE; *sys_errno = errno; snprintf(msg, msg_cap, "write()"); goto done; }
 done:;
   const double t3 = now_s();
   if (st) {
     memset(st, 0, sizeof *st);
-    st->in_bytes = zlen; st->out_bytes = rc ? 0 : n; st->chunks = 1; st->pipelines = 1; st->readers = st->writers = 1; st->devices = 1;
-    st->seconds = t3 - t0; st->reader_busy = t1 - t0; st->pipeline_busy = t2 - t1; st->writer_busy = t3 - t2;
+    st->in_bytes = zlen; st->out_bytes = rc ? 0 : total; st->chunks = windows ? windows : 1; st->pipelines = 1; st->readers = st->writers = 1; st->devices = 1;
+    st->seconds = t3 - t0; st->reader_busy = t_read; st->pipeline_busy = t_dec; st->writer_busy = t_write;
   }
   if (report && !rc && d) {
-    lbzamd_dstats ds;
-    lbzamd_dget_stats(d, &ds);
-    fprintf(stderr, "decode: %zu B -> %zu B, %u blocks in %u stream(s); read %.3f s, context + decode %.3f s = %.0f MB/s (device: scan %.1f blocks %.1f emit %.1f ms), write %.3f s\n",
-            zlen, n, ds.nblocks, ds.nstreams, t1 - t0, t2 - t1, (double)n / (t2 - t1 > 0 ? t2 - t1 : 1e-9) / 1e6, ds.ms_scan, ds.ms_blocks, ds.ms_emit, t3 - t2);
+    fprintf(stderr, "decode: %zu B -> %zu B, %u blocks in %u stream(s), %u window(s); read %.3f s, context + decode %.3f s = %.0f MB/s (device: scan %.1f blocks %.1f emit %.1f ms), write %.3f s\n",
+            zlen, total, acc.nblocks, acc.nstreams, windows, t_read, t_dec, (double)total / (t_dec > 0 ? t_dec : 1e-9) / 1e6, acc.ms_scan, acc.ms_blocks, acc.ms_emit, t_write);
   }
   if (d) lbzamd_ddestroy(d);
   lbzamd_free(out);
-  if (pinned) lbzamd_pinned_free(z); else free(z);
+  free(buf);
   return rc;
 }

@@ -56,8 +56,10 @@ enum { LBZAMD_IO_OK = 0, LBZAMD_IO_READ = 1, LBZAMD_IO_WRITE = 2, LBZAMD_IO_DEVI
 int lbzamd_io_compress(int fd_in, int fd_out, const struct lbzamd_io_cfg *cfg, struct lbzamd_io_stats *st,
                        int *sys_errno, char *msg, size_t msg_cap);
 
-/* .bz2 file(s) on fd_in -> bytes on fd_out (fd_out < 0: decode and check only, lbzip2 -t).  The whole file is read, every
- * block of it is decoded at once (lbzamd_decompress_alloc), the bytes are written.  not_bzip2_copy: a file that does not begin
+/* .bz2 file(s) on fd_in -> bytes on fd_out (fd_out < 0: decode and check only, lbzip2 -t), in bounded memory: the input is
+ * taken a window at a time (256 MB; LBZAMD_IO_DWINDOW=bytes), the whole blocks of a window are decoded at once
+ * (lbzamd_decompress_window) and written before more is read -- a pipe of any length goes through, a reader that leaves
+ * early (`| head`) ends the program.  An input of at most one window is decoded as one call decodes it.  not_bzip2_copy: a file that does not begin
  * with "BZh1".."BZh9" is copied through as it is instead of being refused (lbzip2 -dfc, process.c:675-678).
  * On LBZAMD_IO_DATA *err_code is the reference's enum error (3 = ERR_MAGIC: not a bzip2 file at all). */
 int lbzamd_io_decompress(int fd_in, int fd_out, int not_bzip2_copy, int report, struct lbzamd_io_stats *st,

@@ -460,3 +460,77 @@ def test_retrieve_error_just_in_front_of_a_chunk_boundary():
     rc, at, live = call(ds, w, 0, cut, True)
     assert rc == ERR_TREES, rc
     lib.lbzamd_decoder_free(C.byref(ds))
+
+
+def _window_cases():
+    text = bytes(gen("text", 230000, 3))
+    z1 = L.orc_compress(text, 1)                                          # three blocks of 100 000
+    other = b"second stream " * 3000
+    multi = z1 + bz2.compress(other, 2) + bz2.compress(b"") + L.orc_compress(b"z", 9)
+    return [("one stream", z1, text), ("four streams", multi, text + other + b"z"),
+            ("trailing garbage", multi + b"not a stream header " * 400, text + other + b"z"),
+            ("empty stream first", bz2.compress(b"") + z1, text),
+            ("zeros", L.orc_compress(bytes(1_000_000), 1), bytes(1_000_000))]
+
+
+def test_windows_decode_what_the_whole_input_decodes(emu):
+    """lbzamd_decompress_window (bounded memory: what lbzamd -d / bzcat read with): the input taken 40 000 and 2 500 bytes
+    at a time -- blocks begin at any bit, a window ends inside a block, inside a magic, between a marker and its CRC, between
+    two streams -- gives the bytes of the one-call form; a window that holds no whole block grows."""
+    with emu.decoder(4) as dec:
+        for name, z, want in _window_cases():
+            assert dec.decompress(z) == want, name
+            for w in (len(z) + 1, 40000, 2500):
+                got, calls = dec.decompress_windows(z, w)
+                assert got == want, (name, w)
+                assert calls == 1 if w > len(z) else calls > 1, (name, w, calls)
+
+
+def test_windows_refuse_what_the_whole_input_refuses(emu):
+    """damage in the middle, at the end, a file cut inside a block / inside the trailer: refused window by window too, with
+    the reference's error code where the parser finds it (a missing magic, the end of the file, the stream CRC), and the whole
+    blocks in front of the damage delivered"""
+    text = bytes(gen("text", 230000, 5))
+    z = L.orc_compress(text, 1)
+    cases = []
+    b = bytearray(z); b[len(b) // 2] ^= 0x10; cases.append(("payload bit", bytes(b)))
+    b = bytearray(z); b[-1] ^= 1; cases.append(("stream CRC", bytes(b)))
+    cases.append(("cut in a block", z[:len(z) * 3 // 4]))
+    cases.append(("cut in the trailer", z[:-3]))
+    with emu.decoder(4) as dec:
+        for name, bad in cases:
+            with pytest.raises(LbzError) as whole:
+                dec.decompress(bad)
+            code = emu.lib.lbzamd_last_error_code()
+            for w in (len(bad) + 1, 20000):
+                with pytest.raises(LbzError) as e:
+                    dec.decompress_windows(bad, w)
+                if name != "payload bit":                          # (a block's own error is reported with its window: lbzip2_amd.h)
+                    assert emu.lib.lbzamd_last_error_code() == code, (name, w)
+                assert text.startswith(e.value.decoded_in_front), (name, w)
+                if name == "stream CRC":
+                    assert len(e.value.decoded_in_front) >= len(whole.value.decoded_in_front), (name, w)
+
+
+def test_command_decodes_in_windows(emu, tmp_path):
+    """lbzamd -dc with LBZAMD_IO_DWINDOW=20000: the same bytes as with the default window, a pipe that closes early ends the
+    program (bzcat big | head), -t reads to the end; a file that is no bzip2 file is copied through with -f, window by window"""
+    exe = os.path.join(EMU_DIR, "_build", "lbzamd_emu")
+    subprocess.check_call(["make", "-s", "-C", EMU_DIR, "WG=1024"])
+    text = bytes(gen("text", 210000, 9))
+    z = L.orc_compress(text, 1) + bz2.compress(b"tail" * 5000, 1) + b"garbage" * 100
+    env = dict(os.environ, LBZAMD_IO_DWINDOW="20000")
+    for e in (os.environ, env):
+        r = subprocess.run([exe, "-dc"], input=z, capture_output=True, timeout=900, env=e)
+        assert r.returncode == 0 and r.stdout == text + b"tail" * 5000, r.stderr[-300:]
+    r = subprocess.run([exe, "-t"], input=z, capture_output=True, timeout=900, env=env)
+    assert r.returncode == 0 and r.stdout == b""
+    r = subprocess.run([exe, "-t"], input=z[:50000], capture_output=True, timeout=900, env=env)
+    assert r.returncode == 1 and b"lbzamd" in r.stderr
+    plain = bytes(gen("rand", 70000, 2))
+    r = subprocess.run([exe, "-dcf"], input=plain, capture_output=True, timeout=900, env=env)
+    assert r.returncode == 0 and r.stdout == plain
+    # a reader that leaves early: the writer gets EPIPE/SIGPIPE after the first windows, not after the whole input
+    p = subprocess.Popen(f"{exe} -dc | head -c 1000 | wc -c", shell=True, stdin=subprocess.PIPE, stdout=subprocess.PIPE, env=env)
+    out, _ = p.communicate(z, timeout=900)
+    assert out.strip() == b"1000"
