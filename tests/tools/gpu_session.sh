@@ -5,6 +5,7 @@
 #          rows:<slabs>:<kind> (diag_rows.py) | small (small_rounds.py) | prof (run_profiles.sh) | pmc:<slabs>:<kind> (run_pmc.sh)
 #          ab:<variant>:<slabs>:<kinds> (default library against a variant, same box)
 #          wu (work-unit interface at 16/64/256 threads) | file (file -> file, hostpath_perf) | py:<script and args>
+#          usepmc (the tag's PMC traffic becomes profiles/pmc_traffic.json for the bench steps that follow)
 cd /root/repo
 TAG=$1; shift
 export PYTHONPATH=/root/repo:/root/repo/tests:/root/repo/tests/tools
@@ -38,6 +39,7 @@ PY
              if [ "$lib" = default ]; then unset LBZ_LIB; else export LBZ_LIB=/root/repo/lbzip2_amd/csrc/variants/$lib.so; fi
              timeout 900 python tests/tools/sweep_r5.py $b $c "LBZAMD_STREAMS=1;LBZAMD_STREAMS=3" 2>&1 | grep -E "MB/s|rror" | sed "s/^/$lib /" | tee -a gpurun_out/${TAG}_ab.txt
            done; unset LBZ_LIB ;;
+    usepmc) cp gpurun_out/${TAG}_s1_pmc_traffic.json profiles/pmc_traffic.json && echo "profiles/pmc_traffic.json <- ${TAG}_s1_pmc_traffic.json" ;;   # bench.py's roofline.traffic reads it
     py)    timeout 900 python $a $b $c 2>&1 | tail -40 ;;
   esac
 done
