@@ -616,6 +616,37 @@ def main():
         dist.all_reduce(v)
         verified = None if int(v[1].item()) == world else int(v[0].item()) + int(v[1].item()) == world
 
+    # ---- N > 1: the extras below (host buffers on every rank at once, the strong leg's send/recv, the node's file leg) hold
+    # collectives that have never run on two devices.  None of them may cost the run its line: from here on a timer stands by
+    # -- if an extra hangs, rank 0 prints the WEAK result (all of it is measured by now) and every rank leaves with status 0 --
+    # and an extra that raises is recorded and the remaining collectives are skipped on that rank (the others meet the timer).
+    watchdog = None
+    extras_broken = []
+    if world > 1:
+        import threading
+
+        def minimal_line():
+            return {"metric": "compress MB/s (whole node) + ratio, enwik9 -9, at 1/2/4/8 MI355X",
+                    "value": round((len(full) if strong else total_in) * args.steps / elapsed / 1e6, 1), "unit": "MB/s",
+                    "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 2),
+                    "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": "u8",
+                    "data": "synthetic" if "synthetic" in source else "enwik9",
+                    "config": {"workload": f"{source}, level -{args.level}, {nslabs} slabs of {M} B per GPU", "bytes_per_gpu": n, "level": args.level,
+                               "parallelism": f"{world} independent shard(s)"},
+                    "ratio": round((len(full) if strong else total_in) / max(1, total_out), 4), "out_bytes": total_out, "verified": verified,
+                    "rccl_ranks": world, "roofline": None, "cpu_baseline": None,
+                    "extras": "an untimed extra leg did not come back within LBZ_BENCH_EXTRAS_TIMEOUT: this is the weak-scaling result alone "
+                              "(roofline and cpu_baseline are in the N = 1 line)", "extras_broken": extras_broken}
+
+        def give_up():
+            if rank == 0:
+                print(json.dumps(minimal_line()), flush=True)
+            os._exit(0)
+
+        watchdog = threading.Timer(float(os.environ.get("LBZ_BENCH_EXTRAS_TIMEOUT", "420")) + (0 if rank == 0 else 15), give_up)
+        watchdog.daemon = True
+        watchdog.start()
+
     # ---- untimed extras on rank 0 ----
     iso = None
     value_host = None
@@ -632,6 +663,7 @@ def main():
         finally:
             del os.environ["LBZAMD_STREAMS"]
     if not args.no_host and not strong:
+      try:
         # every rank at once, each its own host buffers: the node's host -> host rate is the sum
         hin = torch.frombuffer(data, dtype=torch.uint8)
         hout = torch.empty(lib.bound(n), dtype=torch.uint8)
@@ -658,13 +690,21 @@ def main():
                               "page-locked output buffer as k_gather writes it; timed like `value` (K steps, wall clock"
                               + ("; all %d ranks at once, each its own buffers: the sum)" % world if world > 1 else ")")}
         del hin, hout
+      except Exception as e:                                     # noqa: BLE001 -- an extra: never the line's failure
+        if world == 1:
+            raise
+        extras_broken.append("value_host: " + repr(e)[:200])
 
     strong_res = None
-    if world > 1 and not strong and not os.environ.get("LBZ_NO_STRONG"):
+    if world > 1 and not strong and not os.environ.get("LBZ_NO_STRONG") and not extras_broken:
         # the same run, the other scaling: rank 0's input over all ranks into ONE stream
         sfix = find_fixture(args.kind, args.bytes, args.seed, args.level) if "synthetic" in source else None
-        strong_res = strong_leg(args, torch, dist, shard, ctx, src if rank == 0 else None, len(full), dst, rank, world,
-                                dev, sync, sfix)
+        try:
+            strong_res = strong_leg(args, torch, dist, shard, ctx, src if rank == 0 else None, len(full), dst, rank, world,
+                                    dev, sync, sfix)
+        except Exception as e:                                   # noqa: BLE001
+            extras_broken.append("strong: " + repr(e)[:200])
+            strong_res = {"error": repr(e)[:200]} if rank == 0 else None
 
     decode = None
     if rank == 0 and not args.no_decode and world == 1 and not strong:     # (strong: dst holds the body only)
@@ -730,20 +770,23 @@ def main():
         except Exception as e:                                   # noqa: BLE001 -- a leg of its own: never the bench line's failure
             value_file = {"error": repr(e)[:200]}
     value_node_file = None
-    if world > 1 and not args.no_host and not strong and not os.environ.get("LBZ_NO_FILE_LEG"):
+    if world > 1 and not args.no_host and not strong and not os.environ.get("LBZ_NO_FILE_LEG") and not extras_broken:
         # the command over all N devices, file -> file: the ranks give their device memory back first (the command's own
         # contexts take up to half of what is free), rank 0 runs it, the others wait
-        ctx.close()
-        ctx = None
-        del src, dst
-        free_cache()
-        barrier()
-        if rank == 0:
-            try:
-                value_node_file = file_leg(data, args.level, fixture, devices=world)
-            except Exception as e:                               # noqa: BLE001
-                value_node_file = {"error": repr(e)[:200]}
-        barrier()
+        try:
+            ctx.close()
+            ctx = None
+            del src, dst
+            free_cache()
+            barrier()
+            if rank == 0:
+                try:
+                    value_node_file = file_leg(data, args.level, fixture, devices=world)
+                except Exception as e:                           # noqa: BLE001
+                    value_node_file = {"error": repr(e)[:200]}
+            barrier()
+        except Exception as e:                                   # noqa: BLE001
+            extras_broken.append("value_node_file: " + repr(e)[:200])
 
     legs = None
     if rank == 0 and not args.no_legs and world == 1 and not strong and args.kind == "wiki" and args.bytes == 1_000_000_000:
@@ -851,6 +894,8 @@ def main():
             res["backend"] = dist.get_backend() + (" (RCCL: one process per GPU, torch.distributed)" if not emu else " (emulated kernels, host memory)")
         if emu:
             res["emulated"] = True
+        if extras_broken:
+            res["extras_broken"] = extras_broken
         if strong_res:
             res["strong"] = strong_res
         if value_host:
@@ -867,7 +912,13 @@ def main():
             res["configs"] = legs
         if not args.no_cpu:
             res["cpu_baseline"] = cpu_baseline(full, args.level)
+        if watchdog:
+            watchdog.cancel()
         print(json.dumps(res), flush=True)
+    if watchdog:
+        watchdog.cancel()
+    if extras_broken:
+        os._exit(0)                                              # (ranks that wait in a collective this one skipped leave by their timer)
     if ctx is not None:
         ctx.close()
     if world > 1:

@@ -102,3 +102,22 @@ def test_bare_bench_starts_its_own_ranks(tmp_path):
     assert r["value_host"]["ranks"] == 2 and r["value_host"]["same_stream"] is True
     assert r["value_node_file"]["verified"] is True and r["value_node_file"]["devices"] == 2
     assert r["roofline"]["bound"] == "hbm" and "frac" in r["roofline"] and "isolated" in r["roofline"]      # (the emulator's events time nothing)
+
+
+def test_a_hanging_extra_does_not_cost_the_line(tmp_path):
+    """N > 1: the untimed extras (host buffers on all ranks, the strong leg's send/recv, the node's file leg) hold collectives that
+    have never run on two devices; if one of them does not come back, rank 0 prints the weak-scaling result -- measured by then
+    -- and every rank leaves with status 0 (bench.py: the timer behind the timed region).  Here the timer is set to fire at once."""
+    import json
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, LBZ_BENCH_EMU="1", LBZ_EMU_THREADS="2", LBZ_EMU_DEVICES="2", LBZ_BENCH_EXTRAS_TIMEOUT="0.001")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT"):
+        env.pop(k, None)
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1", "--bytes", "350000",
+                          "--level", "1", "--seed", "2", "--no-cpu"], env=env, capture_output=True, text=True, timeout=1500, cwd=str(tmp_path))
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-3000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    r = json.loads(lines[0])
+    assert r["n_gpus"] == 2 and r["scaling"] == "weak" and r["value"] > 0 and r["verified"] is True and "extras" in r
