@@ -1989,7 +1989,13 @@ struct deep_lds {
 
 /* steps a strip may take in launch r: 2 2 4 8 16 32 256 256.  A text step decides 13 symbols, or skips 16 to 64 that all
    its runs share; a rank step (from launch DEEP_BUILD + 1 on) as many as the run it looks up shares */
-__device__ __forceinline__ u32 deep_kmax(u32 round) { return round < 2u ? 2u : (round + 2u < DEEP_ROUNDS ? 2u << (round - 1u) : 256u); }
+#ifndef DEEP_K0
+#define DEEP_K0 2u                      /* text steps a strip may take in the first launch ... */
+#endif
+#ifndef DEEP_K1
+#define DEEP_K1 2u                      /* ... and in the second */
+#endif
+__device__ __forceinline__ u32 deep_kmax(u32 round) { return round == 0u ? DEEP_K0 : (round == 1u ? DEEP_K1 : (round + 2u < DEEP_ROUNDS ? 2u << (round - 1u) : 256u)); }
 
 /* Sort the strip inside its runs on `slice` (52 bits).  val and k2 move with their rows; hl (first lane of the lane's
  * run) and tied describe places, and are refined.  Lanes >= nv are not part of the strip.
