@@ -66,8 +66,16 @@
 #define MSD_BITS_FLAT 16u
 #define PART_HALO 48u
 #define PART_MAX 16u                    /* workgroups a block's rows are dealt over in the partition kernels (ranges of its input order) */
-#define BATCH_CAP (LBZ_WG * 4u)
-#define SMALL_BLOCK (LBZ_BWT_WG * 4u)    /* blocks of at most one batch of k_bwt_batch are sorted whole in LDS, without a partition */
+#define BATCH_CAP (LBZ_WG * 4u)          /* the tile a batch is loaded and (rarely) radix-sorted as: four rows per thread */
+#ifndef BATCH_ROWS
+#define BATCH_ROWS 832u                 /* rows a batch holds at most (<= BATCH_CAP): what the arrays of batch_lds are sized for.  Every phase of
+                                           k_bwt_batch is a chain of LDS round trips, so what it needs is waves to hide them behind: 832 rows
+                                           are 31.8 KB of LDS, the most that lets a CU hold FIVE workgroups (a CU hands LDS out in pieces
+                                           that put the limit at 32 000 bytes, not 32 768: 896 rows = 32 744 bytes ran as four); the kernel's
+                                           registers are budgeted to match (BATCH_WGS).  1024 rows, four a CU: k_bwt_batch 36.0 ms per 10^9
+                                           bytes of wiki; 832, five: 33.3; 768 / 704, five: 35.4 / 36.0 (profiles/r06_t_ab*.txt) */
+#endif
+#define SMALL_BLOCK BATCH_ROWS           /* blocks of at most one batch of k_bwt_batch are sorted whole in LDS, without a partition */
 #ifndef COUNT_GROUP
 #define COUNT_GROUP 128u                /* groups this short are ordered by counting */
 #endif
@@ -118,7 +126,7 @@ __device__ __forceinline__ u32 isa_before(u64 e, u32 tag)      /* the rank as of
 {
   return ISA_TAG(e) == tag ? (u32)(e >> 20) & 0x000FFFFFu : (u32)e & 0x000FFFFFu;
 }
-static_assert(BATCH_CAP == LBZ_WG * 4u, "a batch is one 4-rows-per-thread tile");
+static_assert(BATCH_CAP == LBZ_WG * 4u && BATCH_ROWS <= BATCH_CAP && BATCH_ROWS % 64u == 0u, "a batch is at most one 4-rows-per-thread tile, whole strips");
 
 #define BIG_FRAMES 14u                  /* big_group: BIG_LEVELS + 1 frames, rounded up */
 struct sort_core {                      /* HBM radix passes (partition, oversized groups, doubling): what a tile's scatter needs */
@@ -136,16 +144,19 @@ struct sort_lds : sort_core {           /* ... and the digit histograms of the s
   u32 hist[8][256];
 };
 struct batch_lds {                      /* one batch resident in LDS */
-  u64 kA[BATCH_CAP], kB[BATCH_CAP];
-  u32 vA[BATCH_CAP], vB[BATCH_CAP];
-  u16 gh[BATCH_CAP], ghn[BATCH_CAP];    /* local row of the run's first element */
-  u16 gend[BATCH_CAP];                  /* indexed by a run's first row: one past its last row */
-  u8 tied[BATCH_CAP];
+  u64 kA[BATCH_ROWS], kB[BATCH_ROWS];
+  u32 vA[BATCH_ROWS], vB[BATCH_ROWS];
+  u16 gh[BATCH_ROWS], ghn[BATCH_ROWS];    /* local row of the run's first element */
+  u16 gend[BATCH_ROWS];                  /* indexed by a run's first row: one past its last row */
+  u8 tied[BATCH_ROWS];
   u32 wcnt[LBZ_NW][256];
   u32 dbase[256];
   u16 cstart[BATCH_CAP / 64u + 2u];     /* first row of the chunk that belongs to each claim window */
   u8 corder[BATCH_CAP / 64u + 2u];      /* chunks, longest first */
   u16 ctied[BATCH_CAP / 64u + 2u];      /* doubling: rows of each chunk that stay tied */
+#ifdef BATCH_TICKS
+  u32 bt[16];                           /* (diagnostic build) k_bwt_batch: ticks by phase, summed over the waves; tests/tools/quickperf.py */
+#endif
 };
 struct bwt_lds {
   wg_scratch sc;
@@ -698,6 +709,7 @@ __device__ __forceinline__ void load_digit_offsets(const u32 *hist, u32 *dbase, 
 __device__ __forceinline__ u32 lds_radix_sort(batch_lds *B, u32 cnt, bwt_lds *S)
 {
   const u32 tid = threadIdx.x, lane = lane_id(), w = wave_id();
+  u32 *dbase = B->dbase;
   /* which key bytes differ between any two keys of the batch? */
   u64 vo = 0, va = ~0ull;
   for (u32 i = tid; i < cnt; i += LBZ_WG) { const u64 k = B->kA[i]; vo |= k; va &= k; }
@@ -721,15 +733,15 @@ __device__ __forceinline__ u32 lds_radix_sort(batch_lds *B, u32 cnt, bwt_lds *S)
       val[k] = i < cnt ? vin[i] : 0u;
       if (i < cnt) okmask |= 1u << k;
     }
-    if (tid < 256u) B->dbase[tid] = 0;
+    if (tid < 256u) dbase[tid] = 0;
     __syncthreads();
     /* digit totals -> exclusive offsets: count first, then the ordinary tile scatter */
 #pragma unroll
     for (u32 k = 0; k < SORT_IPT; k++)
-      if ((okmask >> k) & 1u) atomicAdd(&B->dbase[(u32)(key[k] >> shift) & 255u], 1u);
+      if ((okmask >> k) & 1u) atomicAdd(&dbase[(u32)(key[k] >> shift) & 255u], 1u);
     __syncthreads();
-    load_digit_offsets(B->dbase, B->dbase, S);
-    radix_tile_scatter(B->wcnt, B->dbase, key, val, okmask, shift, cur ? B->kA : B->kB, cur ? B->vA : B->vB);
+    load_digit_offsets(dbase, dbase, S);
+    radix_tile_scatter(B->wcnt, dbase, key, val, okmask, shift, cur ? B->kA : B->kB, cur ? B->vA : B->vB);
     cur ^= 1u;
   }
   return cur;
@@ -761,17 +773,31 @@ __device__ u32 wave_radix_range(batch_lds *B, u32 cs, u32 ce)
 #pragma unroll
     for (u32 i = 0; i < 4u; i++) cntw[lane + 64u * i] = 0;
     wave_sync();
-    for (u32 j0 = cs; j0 < ce; j0 += 64u) {             /* ranks of equal digits, in row order */
-      const u32 j = j0 + lane;
-      const bool ok = j < ce;
-      const u32 d = ok ? (u32)(kin[j] >> shift) & 255u : 0u;
-      const u64 mask = match_digit(d, ok);
-      const u32 below = (u32)__popcll(mask & lanes_below());
-      const u32 prev = ok ? cntw[d] : 0u;
-      wave_sync();
-      if (ok && below == 0u) cntw[d] = prev + (u32)__popcll(mask);
-      wave_sync();
-      if (ok) B->ghn[j] = (u16)(prev + below);
+    for (u32 j0 = cs; j0 < ce; j0 += 128u) {            /* ranks of equal digits, in row order; two strips a trip: their keys are read
+                                                           and their digits matched together, the counters take them one after the other */
+      u32 d2[2], below2[2], tot2[2];
+      bool ok2[2];
+#pragma unroll
+      for (u32 q = 0; q < 2u; q++) {
+        const u32 j = j0 + 64u * q + lane;
+        ok2[q] = j < ce;
+        d2[q] = (u32)(kin[ok2[q] ? j : cs] >> shift) & 255u;
+      }
+#pragma unroll
+      for (u32 q = 0; q < 2u; q++) {
+        const u64 mask = match_digit(d2[q], ok2[q]);
+        below2[q] = (u32)__popcll(mask & lanes_below());
+        tot2[q] = (u32)__popcll(mask);
+      }
+#pragma unroll
+      for (u32 q = 0; q < 2u; q++) {
+        const u32 j = j0 + 64u * q + lane;
+        const u32 prev = cntw[d2[q]];
+        wave_sync();
+        if (ok2[q] && below2[q] == 0u) cntw[d2[q]] = prev + tot2[q];
+        wave_sync();
+        if (ok2[q]) B->ghn[j] = (u16)(prev + below2[q]);
+      }
     }
     {                                                   /* exclusive scan of the 256 counters */
       const u32 c0 = cntw[4u * lane], c1 = cntw[4u * lane + 1u], c2 = cntw[4u * lane + 2u], c3 = cntw[4u * lane + 3u];
@@ -782,13 +808,24 @@ __device__ u32 wave_radix_range(batch_lds *B, u32 cs, u32 ce)
       cntw[4u * lane + 2u] = ex + c0 + c1; cntw[4u * lane + 3u] = ex + c0 + c1 + c2;
       wave_sync();
     }
-    for (u32 j0 = cs; j0 < ce; j0 += 64u) {
-      const u32 j = j0 + lane;
-      if (j < ce) {
-        const u64 k = kin[j];
-        const u32 dst = cs + cntw[(u32)(k >> shift) & 255u] + B->ghn[j];
-        kout[dst] = k;
-        vout[dst] = vin[j];
+    for (u32 j0 = cs; j0 < ce; j0 += 128u) {
+      u64 k2[2];
+      u32 v2[2], r2[2], c2[2];
+#pragma unroll
+      for (u32 q = 0; q < 2u; q++) {
+        const u32 j = j0 + 64u * q + lane, jc = j < ce ? j : cs;
+        k2[q] = kin[jc]; v2[q] = vin[jc]; r2[q] = B->ghn[jc];
+      }
+#pragma unroll
+      for (u32 q = 0; q < 2u; q++) c2[q] = cntw[(u32)(k2[q] >> shift) & 255u];
+#pragma unroll
+      for (u32 q = 0; q < 2u; q++) {
+        const u32 j = j0 + 64u * q + lane;
+        if (j < ce) {
+          const u32 dst = cs + c2[q] + r2[q];
+          kout[dst] = k2[q];
+          vout[dst] = v2[q];
+        }
       }
     }
     wave_sync();
@@ -801,6 +838,13 @@ __device__ u32 wave_radix_range(batch_lds *B, u32 cs, u32 ce)
   return 8u * ptop;
 }
 
+#ifdef BATCH_TICKS
+#define BT_MARK(v) const u64 v = wall_clock64()
+#define BT_ADD(S_, i, a, b) do { if (lane_id() == 0u) atomicAdd(&(S_)->u.B.bt[i], (u32)((b) - (a))); } while (0)
+#else
+#define BT_MARK(v)
+#define BT_ADD(S_, i, a, b)
+#endif
 /* Order the rows of chunk [cs, ce) (whole groups of equal top MSD_BITS, data in A) by their
  * full keys.  Rows of short groups are placed by counting the smaller keys of their group;
  * each long group is radix-sorted on its own.  Wave-private: no workgroup barrier.          */
@@ -808,6 +852,10 @@ template <bool PREFIX_EQUAL>
 __device__ void wave_sort_chunk(batch_lds *B, u32 cs, u32 ce)
 {
   const u32 lane = lane_id();
+#ifdef BATCH_TICKS
+  bwt_lds *St = reinterpret_cast<bwt_lds *>(reinterpret_cast<char *>(B) - offsetof(bwt_lds, u));
+#endif
+  BT_MARK(ta0);
   if (PREFIX_EQUAL) {
     /* comparison keys made unique by the row number: (key << 12) | row.  Rows of one group agree
        in the bits that are shifted out and in the 12 bits below them, so y < x is the sign of y - x */
@@ -828,12 +876,20 @@ __device__ void wave_sort_chunk(batch_lds *B, u32 cs, u32 ce)
           const u64 x = B->kB[j];
           const u64 top = B->kA[gs] & 0xFFF0000000000000ull;
           dst = gs;
-          u32 q = gs;
-          for (; q + 2u <= ge; q += 2u) {
-            const u64 y0 = B->kB[q], y1 = B->kB[q + 1u];
+          u32 p = gs;
+#ifndef COUNT_NARROW
+          for (; p + 8u <= ge; p += 8u) {                /* eight keys requested before the first is counted: the loop is LDS round trips */
+            const u64 y0 = B->kB[p], y1 = B->kB[p + 1u], y2 = B->kB[p + 2u], y3 = B->kB[p + 3u];
+            const u64 y4 = B->kB[p + 4u], y5 = B->kB[p + 5u], y6 = B->kB[p + 6u], y7 = B->kB[p + 7u];
+            dst += (u32)((y0 - x) >> 63) + (u32)((y1 - x) >> 63) + (u32)((y2 - x) >> 63) + (u32)((y3 - x) >> 63);
+            dst += (u32)((y4 - x) >> 63) + (u32)((y5 - x) >> 63) + (u32)((y6 - x) >> 63) + (u32)((y7 - x) >> 63);
+          }
+#endif
+          for (; p + 2u <= ge; p += 2u) {
+            const u64 y0 = B->kB[p], y1 = B->kB[p + 1u];
             dst += (u32)((y0 - x) >> 63) + (u32)((y1 - x) >> 63);
           }
-          if (q < ge) dst += (u32)((B->kB[q] - x) >> 63);
+          if (p < ge) dst += (u32)((B->kB[p] - x) >> 63);
           B->kA[dst] = top | (x >> 12);
         }
         B->vB[dst] = v;
@@ -872,6 +928,18 @@ __device__ void wave_sort_chunk(batch_lds *B, u32 cs, u32 ce)
 #ifdef SORT_TICKS
   const u64 tl0 = wall_clock64();
 #endif
+  BT_MARK(ta1);
+#ifdef BATCH_TICKS
+  if (PREFIX_EQUAL) {
+    u32 n1 = 0, nc = 0, nl = 0;
+    for (u32 j0 = cs; j0 < ce; j0 += 64u) {
+      const u32 j = j0 + lane;
+      const u32 g = j < ce ? (u32)B->gend[B->gh[j]] - (u32)B->gh[j] : 0u;
+      n1 += (u32)__popcll(__ballot(g == 1u)); nc += (u32)__popcll(__ballot(g > 1u && g <= COUNT_GROUP)); nl += (u32)__popcll(__ballot(g > COUNT_GROUP));
+    }
+    if (lane == 0u) { atomicAdd(&B->bt[11], n1); atomicAdd(&B->bt[12], nc); atomicAdd(&B->bt[13], nl); }
+  }
+#endif
   for (u32 j0 = cs; j0 < ce; j0 += 64u) {               /* long groups, one after the other */
     const u32 j = j0 + lane;
     bool longhead = false;
@@ -886,6 +954,8 @@ __device__ void wave_sort_chunk(batch_lds *B, u32 cs, u32 ce)
 #ifdef SORT_TICKS
   if (PREFIX_EQUAL && lane == 0u) atomicAdd(&reinterpret_cast<bwt_lds *>(reinterpret_cast<char *>(B) - offsetof(bwt_lds, u))->bc[15], (u32)(wall_clock64() - tl0));
 #endif
+  BT_MARK(ta2);
+  if (PREFIX_EQUAL) { BT_ADD(St, 0, ta0, ta1); BT_ADD(St, 1, ta1, ta2); }
 }
 
 /* Runs of equal 64-bit keys inside the sorted chunk [cs, ce): gh, gend, tied, wave-private.
@@ -896,26 +966,37 @@ __device__ u32 wave_runs(batch_lds *B, u32 cs, u32 ce, u32 sh = 0u)
 {
   const u32 lane = lane_id();
   u32 carry = cs, ntied = 0;
-  for (u32 j0 = cs; j0 < ce; j0 += 64u) {
-    const u32 j = j0 + lane;
-    const bool ok = j < ce;
-    const u64 k = ok ? B->kA[j] >> sh : 0ull;
-    bool hd = ok && (j == cs || (B->kA[j - 1u] >> sh) != k);
-    bool hn = ok && (j + 1u >= ce || (B->kA[j + 1u] >> sh) != k);
-    if (WITHIN && ok) {
-      hd = hd || B->gh[j] == j;
-      hn = hn || (j + 1u < ce && B->gh[j + 1u] == j + 1u);
+  for (u32 j0 = cs; j0 < ce; j0 += 128u) {               /* two strips a trip, their reads requested together (wave_finish_chunk's output loop) */
+    u64 kc[2], kp[2], kn[2];
+    u32 g0[2], g1[2];
+#pragma unroll
+    for (u32 q = 0; q < 2u; q++) {
+      const u32 j = j0 + 64u * q + lane, jc = j < ce ? j : cs;
+      const u32 jp = jc > cs ? jc - 1u : cs, jn = jc + 1u < ce ? jc + 1u : jc;
+      kc[q] = B->kA[jc] >> sh; kp[q] = B->kA[jp] >> sh; kn[q] = B->kA[jn] >> sh;
+      if (WITHIN) { g0[q] = B->gh[jc]; g1[q] = B->gh[jn]; }
     }
     wave_sync();                                         /* old gh read before it is rewritten */
-    u32 h = wave_incl_max(hd ? j : 0u);
-    if (h < carry) h = carry;                            /* run opened in an earlier strip */
-    if (ok) {
-      B->gh[j] = (u16)h;
-      B->tied[j] = (hd && hn) ? 0 : 1;
-      if (hn) B->gend[h] = (u16)(j + 1u);
+#pragma unroll
+    for (u32 q = 0; q < 2u; q++) {
+      const u32 j = j0 + 64u * q + lane;
+      const bool ok = j < ce;
+      bool hd = ok && (j == cs || kp[q] != kc[q]);
+      bool hn = ok && (j + 1u >= ce || kn[q] != kc[q]);
+      if (WITHIN && ok) {
+        hd = hd || g0[q] == j;
+        hn = hn || (j + 1u < ce && g1[q] == j + 1u);
+      }
+      u32 h = wave_incl_max(hd ? j : 0u);
+      if (h < carry) h = carry;                          /* run opened in an earlier strip */
+      if (ok) {
+        B->gh[j] = (u16)h;
+        B->tied[j] = (hd && hn) ? 0 : 1;
+        if (hn) B->gend[h] = (u16)(j + 1u);
+      }
+      ntied += (u32)__popcll(__ballot(ok && !(hd && hn)));
+      if (j0 + 64u * q < ce) carry = (u32)__builtin_amdgcn_readlane((int)h, 63);
     }
-    ntied += (u32)__popcll(__ballot(ok && !(hd && hn)));
-    carry = (u32)__builtin_amdgcn_readlane((int)h, 63);
   }
   wave_sync();
   return ntied;
@@ -936,7 +1017,10 @@ __device__ void wave_finish_chunk(batch_lds *B, u32 cs, u32 ce, bool need_sort, 
 #ifdef SORT_TICKS
     const u64 tr0 = wall_clock64();
 #endif
+    BT_MARK(tr0b);
     ntied = wave_runs<false>(B, cs, ce);
+    BT_MARK(tr1b);
+    BT_ADD(S, 2, tr0b, tr1b);
 #ifdef SORT_TICKS
     if (lane == 0u) atomicAdd(&S->bc[2], (u32)(wall_clock64() - tr0));
 #endif
@@ -958,55 +1042,98 @@ __device__ void wave_finish_chunk(batch_lds *B, u32 cs, u32 ce, bool need_sort, 
      `tied` byte (bit 1; every writer stores the same value). */
   u32 nclosed = 0;
   if (ntied) {
-    for (u32 j0 = cs; j0 < ce; j0 += 64u) {
-      const u32 j = j0 + lane;
-      if (j < ce && B->tied[j]) {
-        const u32 v = B->vA[j], hd = B->gh[j];
+    /* (two strips a trip, unconditional reads, as in the output loop below: `tied` is only ever tested for "not zero" here, so
+       a mark another strip sets meanwhile changes nothing) */
+    for (u32 j0 = cs; j0 < ce; j0 += 128u) {
+      u32 jj[2], v[2], tj[2], hd[2], vh[2];
+#pragma unroll
+      for (u32 q = 0; q < 2u; q++) {
+        const u32 j = j0 + 64u * q + lane;
+        jj[q] = j < ce ? j : cs;
+        const u32 t = B->tied[jj[q]];
+        tj[q] = j < ce ? t : 0u; v[q] = B->vA[jj[q]]; hd[q] = B->gh[jj[q]];
+      }
+#pragma unroll
+      for (u32 q = 0; q < 2u; q++) vh[q] = B->vA[tj[q] ? hd[q] : jj[q]];
+#pragma unroll
+      for (u32 q = 0; q < 2u; q++) {
 #ifdef DBG_NOCLOSE_BATCH
-        B->tied[hd] = 3;
+        if (tj[q]) B->tied[hd[q]] = 3;
 #else
-        if ((v >> 24) != (B->vA[hd] >> 24) || (v & 0x00FFFFFFu) == 0u) B->tied[hd] = 3;
+        if (tj[q] && ((v[q] >> 24) != (vh[q] >> 24) || (v[q] & 0x00FFFFFFu) == 0u)) B->tied[hd[q]] = 3;
 #endif
       }
     }
     wave_sync();
     u32 nopen = 0;
-    for (u32 j0 = cs; j0 < ce; j0 += 64u) {
-      const u32 j = j0 + lane;
-      nopen += (u32)__popcll(__ballot(j < ce && B->tied[j] && (B->tied[B->gh[j]] & 2)));
+    for (u32 j0 = cs; j0 < ce; j0 += 128u) {
+      u32 tj[2], hd[2];
+#pragma unroll
+      for (u32 q = 0; q < 2u; q++) {
+        const u32 j = j0 + 64u * q + lane, jc = j < ce ? j : cs;
+        const u32 t = B->tied[jc];
+        tj[q] = j < ce ? t : 0u; hd[q] = B->gh[jc];
+      }
+#pragma unroll
+      for (u32 q = 0; q < 2u; q++) {
+        const u32 th = B->tied[tj[q] ? hd[q] : cs];
+        nopen += (u32)__popcll(__ballot(tj[q] && (th & 2u)));
+      }
     }
     nclosed = ntied - nopen;
     ntied = nopen;
   }
+  BT_MARK(tc1);
+  BT_ADD(S, 3, tw1, tc1);
   const bwt_slot ls = seg_view(s, S->seglo);
   /* the chunk's tied runs take ONE stretch of the list: the rows of a run must lie side by side there */
   u32 lbase = ntied ? wave_reserve(&S->listn, ntied) : 0u;
   u32 nlong = 0;
-  for (u32 j0 = cs; j0 < ce; j0 += 64u) {
-    const u32 j = j0 + lane;
-    const bool ok = j < ce;
-    const u32 v = ok ? B->vA[j] : 0u;
-    const u32 idx = v & 0x00FFFFFFu;
-    const bool tdall = ok && (ntied || nclosed) && B->tied[j];           /* tied: in the suffix array */
-    const u32 head = tdall ? (u32)B->gh[j] : j;
-    const bool td = tdall && ntied && (B->tied[head] & 2);                /* ... and of an open run: listed */
-    if (ok) {
-      bwt[lo + j] = S->inv[v >> 24];
-      s.sa[lo + j] = SA_ENTRY(idx, v >> 24) | ((tdall && head != j) ? TIE_FLAG : 0u);
-      if (idx == 0u) meta->bwt_idx = lo + j;
+  /* Two strips a trip, their LDS reads requested together: a strip is two dependent round trips (the row; then its run's first
+     row and the byte's code) and nothing else of weight, so one strip at a time the wave mostly waits (20 of a wiki block's 62
+     wave-ms were this loop).  The reads are unconditional -- a lane past the chunk's end reads the chunk's first row -- so that
+     no branch stands between them. */
+  const bool anyt = (ntied | nclosed) != 0u;
+  for (u32 j0 = cs; j0 < ce; j0 += 128u) {
+    u32 jj[2], v[2], tj[2], hj[2], head[2], th[2], ge[2], by[2];
+    bool ok[2];
+#pragma unroll
+    for (u32 q = 0; q < 2u; q++) {
+      const u32 j = j0 + 64u * q + lane;
+      ok[q] = j < ce;
+      jj[q] = ok[q] ? j : cs;
+      v[q] = B->vA[jj[q]]; tj[q] = B->tied[jj[q]]; hj[q] = B->gh[jj[q]];
     }
-    const u64 mask = __ballot(td);
-    nlong += (u32)__popcll(__ballot(td && (u32)B->gend[head] - head > BIG_RUN));
-    if (td) {
-      const u32 o = lbase + (u32)__popcll(mask & lanes_below());
-      ls.sufx[o] = SA_ENTRY(idx, v >> 24);
-      ls.grp[o] = lo + head;                           /* rank of the run = its first row */
-      ls.pos[o] = depth;                               /* symbols the run shares */
+#pragma unroll
+    for (u32 q = 0; q < 2u; q++) {
+      head[q] = (anyt && tj[q]) ? hj[q] : jj[q];
+      th[q] = B->tied[head[q]]; ge[q] = B->gend[head[q]]; by[q] = S->inv[v[q] >> 24];
     }
-    lbase += (u32)__popcll(mask);
+#pragma unroll
+    for (u32 q = 0; q < 2u; q++) {
+      const u32 j = jj[q], idx = v[q] & 0x00FFFFFFu;
+      const bool tdall = ok[q] && anyt && tj[q];                          /* tied: in the suffix array */
+      const bool td = tdall && ntied && (th[q] & 2u);                      /* ... and of an open run: listed */
+      if (ok[q]) {
+        bwt[lo + j] = (u8)by[q];
+        s.sa[lo + j] = SA_ENTRY(idx, v[q] >> 24) | ((tdall && head[q] != j) ? TIE_FLAG : 0u);
+        if (idx == 0u) meta->bwt_idx = lo + j;
+      }
+      const u64 mask = __ballot(td);
+      nlong += (u32)__popcll(__ballot(td && ge[q] - head[q] > BIG_RUN));
+      if (td) {
+        const u32 o = lbase + (u32)__popcll(mask & lanes_below());
+        ls.sufx[o] = SA_ENTRY(idx, v[q] >> 24);
+        ls.grp[o] = lo + head[q];                        /* rank of the run = its first row */
+        ls.pos[o] = depth;                               /* symbols the run shares */
+      }
+      lbase += (u32)__popcll(mask);
+    }
   }
   if (ntied && lane == 0u) { atomicMin(&S->lmin, depth); if (nlong) atomicAdd(&S->bc[9], nlong); }
   if (nclosed && lane == 0u) atomicMin(&S->cmin, depth);
+  BT_MARK(tc2);
+  BT_ADD(S, 4, tc1, tc2);
   if (lane == 0u) {
     const u64 tw2 = wall_clock64();
     atomicAdd(&S->bc[13], (u32)(tw2 - tw0));
@@ -1111,8 +1238,24 @@ __device__ u32 batch_process(const u8 *T, u32 n, u8 *bwt, lbz_block_meta *meta, 
     /* The partition moved the keys' top halves only (8-byte rows, round 6); the low half is four bytes of the text behind the
        top half's symbols (row_key): a 4-byte gather from the text of the four blocks an XCD works on at a time, in its L2. */
     if (!kfull) {
+      /* all four gathers in flight before the first is waited for: the load is unconditional, from a place that lies inside the
+         text (n > BATCH_ROWS here), and only a row whose four bytes wrap round the block's end (three rows of a block) takes the
+         byte loop afterwards.  As a call of row_key per row each gather sat behind a branch and was waited for on its own: four
+         round trips a batch, most of the load phase (2.9 us of a batch's 37) */
+      u32 at[BATCH_CAP / LBZ_WG], raw[BATCH_CAP / LBZ_WG];
 #pragma unroll
-      for (u32 k = 0; k < BATCH_CAP / LBZ_WG; k++) kk[k] = row_key(T, n, (u32)kk[k], vv[k] & 0x00FFFFFFu, c);
+      for (u32 k = 0; k < BATCH_CAP / LBZ_WG; k++) {
+        u32 a = (vv[k] & 0x00FFFFFFu) + c.q0;
+        if (a >= n) a -= n;
+        at[k] = a;
+        raw[k] = ldg_text4(T + (a + 4u <= n ? a : n - 4u));
+      }
+#pragma unroll
+      for (u32 k = 0; k < BATCH_CAP / LBZ_WG; k++) {
+        u32 r = __builtin_bswap32(raw[k]);
+        if (at[k] + 4u > n) r = (u32)row_key(T, n, 0u, vv[k] & 0x00FFFFFFu, c);
+        kk[k] = (kk[k] << 32) | r;
+      }
     }
 #pragma unroll
     for (u32 k = 0; k < BATCH_CAP / LBZ_WG; k++) {
@@ -1136,6 +1279,8 @@ __device__ u32 batch_process(const u8 *T, u32 n, u8 *bwt, lbz_block_meta *meta, 
     need_sort = false;
   }
   batch_runs(B, B->kA, cnt, need_sort ? S->msd_shift : 0u, &maxrun, S);
+  BT_MARK(tg1);
+  if (threadIdx.x == 0u) { BT_ADD(S, 5, tb1, tg1); }
   if (trim && lo + cnt < S->seghi && (u32)(B->kA[cnt - 1u] >> S->msd_shift) == S->bc[1]) {
     cnt = B->gh[cnt - 1u];                       /* the last group goes on: it waits for the next batch */
     if (cnt == 0u) { __syncthreads(); return 0u; }
@@ -1176,7 +1321,10 @@ __device__ u32 batch_process(const u8 *T, u32 n, u8 *bwt, lbz_block_meta *meta, 
     __syncthreads();
   }
   const u64 tb2 = wall_clock64();
+  if (threadIdx.x == 0u) { BT_ADD(S, 6, tg1, tb2); }
   const u32 nwin = chunk_plan(B, cnt);
+  BT_MARK(tg3);
+  if (threadIdx.x == 0u) { BT_ADD(S, 7, tb2, tg3); BT_ADD(S, 9, 0, 1); BT_ADD(S, 10, 0, cnt); }
   for (;;) {
     const u32 t = wave_claim(&S->bc[7]);
     if (t >= nwin) break;
@@ -1322,7 +1470,7 @@ __device__ void big_group(const u8 *T, u32 n, u8 *bwt, lbz_block_meta *meta, bwt
   while (pos < hi) {
     while (pos >= S->fr_end[nf - 1u]) nf--;             /* (frame 0 ends at hi) */
     const u32 lim = S->fr_end[nf - 1u], dep = S->fr_dep[nf - 1u];
-    u32 e = pos + BATCH_CAP < lim ? pos + BATCH_CAP : lim;
+    u32 e = pos + BATCH_ROWS < lim ? pos + BATCH_ROWS : lim;
     if (e < lim) {
       const u32 cut = find_cut(K, pos, e, 0u, S);
       if (!cut) {
@@ -1375,7 +1523,7 @@ __device__ u32 doubling_round(const u8 *T, u32 n, u8 *bwt, bwt_slot s, bwt_lds *
   const u32 tid = threadIdx.x, lane = lane_id();
   u32 out_m = 0, k0 = 0;
   while (k0 < m) {
-    u32 e = k0 + BATCH_CAP < m ? k0 + BATCH_CAP : m;
+    u32 e = k0 + BATCH_ROWS < m ? k0 + BATCH_ROWS : m;
     if (e < m) {
       const u32 cut = find_cut(s.grp, k0, e, 0u, S);
       if (!cut) {
@@ -1862,7 +2010,10 @@ __device__ __forceinline__ bool seg_item(u32 nblk, u32 segs, u32 *i, u32 *seg)
 }
 
 /* ---- kernel 2: LDS batches of whole groups; emits BWT bytes + rows; flags deep ties ---- */
-__global__ void __launch_bounds__(LBZ_WG, 4)
+#ifndef BATCH_WGS
+#define BATCH_WGS 5                     /* workgroups of k_bwt_batch a CU is to hold: what the registers are budgeted for (LDS: BATCH_ROWS) */
+#endif
+__global__ void __launch_bounds__(LBZ_WG, BATCH_WGS)
 k_bwt_batch(const u8 *Tbase, u8 *Bbase, lbz_block_meta *meta, lbz_layout L, u32 first, u32 count, u32 nblk, u32 segs,
             u8 *ws, u64 slot_bytes, u8 *ws_spill, u64 spill_bytes, const u32 *slabs)
 {
@@ -1891,9 +2042,12 @@ k_bwt_batch(const u8 *Tbase, u8 *Bbase, lbz_block_meta *meta, lbz_layout L, u32 
   if (tid == 0) {
     S.listn = 0; S.seglo = lo; S.seghi = hi; S.h0min = 0xFFFFFFFFu; S.lmin = 0xFFFFFFFFu; S.cmin = 0xFFFFFFFFu;
     for (u32 i = 0; i < 4; i++) S.dbg[i] = 0;
+#ifdef BATCH_TICKS
+    for (u32 i = 0; i < 16; i++) S.u.B.bt[i] = 0;
+#endif
   }
   __syncthreads();
-  if (n <= BATCH_CAP) {
+  if (n <= BATCH_ROWS) {
     batch_lds *B = &S.u.B;
     for (u32 i = tid; i < n; i += LBZ_WG) {
       B->kA[i] = key_from_text(T, n, i, S.cmap, c);
@@ -1904,7 +2058,7 @@ k_bwt_batch(const u8 *Tbase, u8 *Bbase, lbz_block_meta *meta, lbz_layout L, u32 
   } else {
     u32 pos = lo;
     while (pos < hi) {
-      const u32 want = hi - pos < BATCH_CAP ? hi - pos : BATCH_CAP;
+      const u32 want = hi - pos < BATCH_ROWS ? hi - pos : BATCH_ROWS;
       const u32 used = batch_process(T, n, bwt, M, s, &S, c, pos, want, false, false, true, BATCH_DEPTH(c));
       if (used == 0u) {                          /* one group fills the batch: sort it in HBM first */
 #ifdef LDS_SORT_TICKS
@@ -1932,6 +2086,9 @@ k_bwt_batch(const u8 *Tbase, u8 *Bbase, lbz_block_meta *meta, lbz_layout L, u32 
     atomicAdd(&M->sort_elems, hi - lo);
     /* diagnostics, summed over the block's segments (tests/tools/quickperf.py) */
     atomicAdd(&M->ticks[0], (u32)(wall_clock64() - tk0));
+#ifdef BATCH_TICKS
+    for (u32 i = 0; i < 16; i++) atomicAdd(&M->fticks[i], S.u.B.bt[i]);
+#endif
 #ifndef DEEP_TICKS                                 /* (that diagnostic build keeps ticks[5..7] for the long runs of the text rounds) */
     for (u32 i = 0; i < 3; i++) atomicAdd(&M->ticks[3 + i], S.bc[10 + i]);   /* load, group scan (+block sorts), per-wave part */
 #ifndef COL_TICKS
@@ -2229,8 +2386,19 @@ __device__ void deep_big_run(deep_wave *W, u32 lane, u32 p, u32 g, deep_lists Ls
         u64x2 x4[4];
 #pragma unroll
         for (u32 q = 0; q < 4u; q++) { const u32 k = k0 + 64u * q + lane; v4[q] = src[k < len ? k : 0u]; }
+        /* unconditional loads from inside the text, the wrap round the block's end (sixteen rotations of a block) looked at
+           afterwards: as four calls of deep_load16 each load sat behind that test's branch and was waited for on its own */
+        u32 a4[4];
 #pragma unroll
-        for (u32 q = 0; q < 4u; q++) x4[q] = deep_load16(T, n, SA_IDX(v4[q]), d);
+        for (u32 q = 0; q < 4u; q++) {
+          u32 at = SA_IDX(v4[q]) + d;
+          if (at >= n) at -= n;
+          a4[q] = at;
+          const lbz_text16 *t16 = reinterpret_cast<const lbz_text16 *>(T + (at + 16u <= n ? at : (n >= 16u ? n - 16u : 0u)));
+          x4[q].x = t16->a; x4[q].y = t16->b;
+        }
+#pragma unroll
+        for (u32 q = 0; q < 4u; q++) if (a4[q] + 16u > n) x4[q] = deep_load16(T, n, SA_IDX(v4[q]), d);
 #pragma unroll
         for (u32 q = 0; q < 4u; q++) {
           const u64 xa = x4[q].x ^ ref.x, xb = x4[q].y ^ ref.y;

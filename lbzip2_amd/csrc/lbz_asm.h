@@ -225,6 +225,7 @@ __device__ __forceinline__ unsigned add_if_less2(unsigned acc, unsigned long lon
 __device__ __forceinline__ unsigned long long ldg_u64(const unsigned long long *p) { return *(const LBZ_GLOBAL(unsigned long long) *)p; }
 __device__ __forceinline__ unsigned ldg_u32(const unsigned *p) { return *(const LBZ_GLOBAL(unsigned) *)p; }
 __device__ __forceinline__ unsigned ldg_u8(const unsigned char *p) { return *(const LBZ_GLOBAL(unsigned char) *)p; }
+__device__ __forceinline__ unsigned ldg_text4(const unsigned char *p) { return ((const LBZ_GLOBAL(lbz_text4) *)p)->a; }      /* four bytes at any address */
 __device__ __forceinline__ void stg_u64(unsigned long long *p, unsigned long long v) { *(LBZ_GLOBAL(unsigned long long) *)p = v; }
 __device__ __forceinline__ void stg_u32(unsigned *p, unsigned v) { *(LBZ_GLOBAL(unsigned) *)p = v; }
 

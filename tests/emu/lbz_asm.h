@@ -76,6 +76,7 @@ static inline unsigned add_if_less2(unsigned acc, unsigned long long a0, unsigne
 static inline unsigned long long ldg_u64(const unsigned long long *p) { return *p; }
 static inline unsigned ldg_u32(const unsigned *p) { return *p; }
 static inline unsigned ldg_u8(const unsigned char *p) { return *p; }
+static inline unsigned ldg_text4(const unsigned char *p) { return ((const lbz_text4 *)p)->a; }
 static inline void stg_u64(unsigned long long *p, unsigned long long v) { *p = v; }
 static inline void stg_u32(unsigned *p, unsigned v) { *p = v; }
 #endif

@@ -40,6 +40,14 @@ for kind in (sys.argv[2].split(",") if len(sys.argv) > 2 else ("text", "rand")):
         print("   waves phase: busy/16 = %.2f ms (utilisation %.0f%%), first sort = %.2f ms/16"
               % (tk[6] / cnt / 1e5 / 16, 100.0 * tk[6] / 16 / max(1, tk[5]), tk[7] / cnt / 1e5 / 16), flush=True)
         print("   sum over batches of the longest chunk: first sort %.2f ms, sort+refine+emit %.2f ms" % (tk[1] / cnt / 1e5, tk[2] / cnt / 1e5), flush=True)
+        if os.environ.get("BATCH_TICKS"):
+            ft = [0] * 16
+            for b in range(0, min(2 * slabs, 64), 2):
+                bi = ctx.block_info(b)
+                for i in range(16): ft[i] += bi.fticks[i]
+            f = [x / cnt / 1e5 for x in ft]
+            print("   BATCH_TICKS per block: wave-ms short groups %.2f long groups %.2f runs %.2f closed %.2f emit %.2f | WG-ms batch_runs %.2f sort/split %.2f plan %.2f | batches %d rows %d: alone %d counted %d long %d"
+                  % (f[0], f[1], f[2], f[3], f[4], f[5], f[6], f[7], ft[9] // cnt, ft[10] // cnt, ft[11] // cnt, ft[12] // cnt, ft[13] // cnt), flush=True)
         if os.environ.get("MTF_TICKS"):
             print("   mtf kernel ms/blk: prelude %.2f ranks %.2f zrle %.2f" % (tk[3] / cnt / 1e5, tk[4] / cnt / 1e5, tk[5] / cnt / 1e5), flush=True)
         if os.environ.get("SORT_TICKS"):

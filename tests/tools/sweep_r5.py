@@ -25,7 +25,7 @@ for kind in kinds:
         s = ctx.stats()
         h = hashlib.md5(dst[:m].cpu().numpy().tobytes()).hexdigest()
         ref.setdefault(kind, h)
-        print(f"{kind:8s} {st:60s} {n/best/1e6:8.1f} MB/s  part={s.ms_bwt_part:.1f} batch={s.ms_bwt_batch:.1f} ties={s.ms_bwt_fix:.1f} mtf={s.ms_mtf:.1f} enc={s.ms_encode:.1f}  {'same stream' if h == ref[kind] else 'STREAM DIFFERS'}", flush=True)
+        print(f"{kind:8s} {st:60s} {n/best/1e6:8.1f} MB/s  part={s.ms_bwt_part:.1f} batch={s.ms_bwt_batch:.1f} ties={s.ms_bwt_fix:.1f} mtf={s.ms_mtf:.1f} enc={s.ms_encode:.1f}  {'same stream' if h == ref[kind] else 'STREAM DIFFERS'} {h[:8]}", flush=True)
         ctx.close()
         for k in env: del os.environ[k]
     del src, dst
