@@ -4,10 +4,10 @@ sys.path.insert(0, "/root/repo"); sys.path.insert(0, "/root/repo/tests")
 import torch, lbzip2_amd, ctypes as C
 if os.environ.get('LBZ_LIB'): lbzip2_amd.LIB_PATH = os.environ['LBZ_LIB']
 lib = lbzip2_amd.library()
-from bench import gen_input
+sys.path.insert(0, "/root/repo/tests/tools"); import inputs
 slabs = int(sys.argv[1]); kind = sys.argv[2]
 n = slabs * 900000
-data = gen_input(kind, n, 2)
+data = inputs.get(kind, n, 2)
 src = torch.frombuffer(data, dtype=torch.uint8).cuda()
 dst = torch.empty(lib.bound(n), dtype=torch.uint8, device="cuda")
 ctx = lib.context(9, slabs, slabs)
