@@ -50,6 +50,7 @@ struct engine {
   int plain_out;
   const uint8_t *map;               /* the input file mapped (a regular file): chunks are ranges of it, nothing is read or page-locked */
   uint64_t map_size;
+  int no_populate;                  /* LBZAMD_IO_NOPOPULATE: the mapped chunks are not faulted in ahead of the pipelines (tuning) */
   size_t chunk_bytes, out_cap;
   unsigned nslots, npipes, nreaders, nwriters, next_pipe_id, ctx_ready;
   volatile int watch_stop;
@@ -158,6 +159,16 @@ static void *reader_main(void *arg)
       const uint64_t at = seq * (uint64_t)e->chunk_bytes;
       n = at >= e->map_size ? 0 : (ssize_t)(e->map_size - at < e->chunk_bytes ? e->map_size - at : e->chunk_bytes);
       s->src = e->map + at;
+#ifdef MADV_POPULATE_READ
+      /* the chunk's pages into this process's page table NOW, on this thread, which runs ahead of the pipelines (and beside the
+         creation of their contexts): the runtime's staging copy of a pageable chunk then takes no page fault per 4 KB.  A hint:
+         an error (an older kernel, a file that shrank) changes nothing.  LBZAMD_IO_NOPOPULATE=1: without. */
+      if (n > 0 && !e->no_populate)                          /* (in pieces: one call for a whole chunk holds the address space's lock against the contexts' own mappings) */
+        for (size_t o = 0; o < (size_t)n; o += (size_t)8 << 20) {
+          const size_t len = (size_t)n - o < ((size_t)8 << 20) ? (size_t)n - o : (size_t)8 << 20;
+          if (madvise((void *)(uintptr_t)(e->map + at + o), len, MADV_POPULATE_READ)) break;
+        }
+#endif
     } else {
       n = read_fully(e->fd_in, s->in, e->chunk_bytes, e->in_seek, e->in_base + (off_t)(seq * e->chunk_bytes));
       s->src = s->in;
@@ -395,6 +406,7 @@ int lbzamd_io_compress(int fd_in, int fd_out, const struct lbzamd_io_cfg *cfg, s
       e.map = m;
       e.map_size = in_size;
       (void)madvise(m, (size_t)in_size, MADV_SEQUENTIAL);
+      e.no_populate = getenv("LBZAMD_IO_NOPOPULATE") != NULL;
     }
   }
   e.nreaders = e.map ? 1u : (e.in_seek ? (cfg->readers ? cfg->readers : 4u) : 1u);
