@@ -47,6 +47,15 @@ def test_stages_small(emu, name, data):
     _stages(emu, data, 1)
 
 
+def test_blocks_of_about_one_batch(emu):
+    """Blocks of at most one batch of k_bwt_batch (BATCH_ROWS = 832 rows since round 6, 1024 before) are sorted whole in LDS,
+    without a partition; one row more and the block is partitioned and cut into batches.  Sizes on both sides of either limit
+    and of the 64-row strips the per-wave loops take two at a time, on text (ties), few symbols (long groups) and random bytes."""
+    for n in (63, 64, 65, 127, 128, 129, 191, 193, 767, 831, 832, 833, 895, 897, 1023, 1024, 1025, 1663, 1664, 1665, 2500):
+        for data in (gen("text", n, n), bytes((i * i + (i >> 2)) % 3 + 65 for i in range(n)), gen("rand", n, n + 1), (b"abcab" * n)[:n]):
+            _stages(emu, data, 1)
+
+
 def test_streams_multi_slab_spill_chunked(emu):
     for kind, n, seed, slabs in [("text", 230000, 3, 2), ("runs", 150000, 4, 2)]:
         data = gen(kind, n, seed)

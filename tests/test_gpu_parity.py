@@ -210,6 +210,16 @@ def test_rle_boundary_cases(lib):
                 assert ctx.compress(data) == L.orc_compress(data, 1), (run, before)
 
 
+def test_blocks_of_about_one_batch(lib):
+    """Block sizes on both sides of a batch of k_bwt_batch (832 rows: sorted whole in LDS up to there, partitioned beyond), of the
+    old limit (1024) and of the 64-row strips, on text, three symbols, random bytes and a short period (tests/test_emu_kernels.py
+    holds the same under the emulator, stage by stage)."""
+    with lib.context(1, 1) as ctx:
+        for n in (63, 64, 65, 127, 128, 129, 191, 193, 767, 831, 832, 833, 895, 897, 1023, 1024, 1025, 1663, 1664, 1665, 2500, 4159, 4161):
+            for data in (bytes(gen("text", n, n)), bytes((i * i + (i >> 2)) % 3 + 65 for i in range(n)), bytes(gen("rand", n, n + 1)), (b"abcab" * n)[:n]):
+                assert ctx.compress(data) == L.orc_compress(data, 1), n
+
+
 def test_periodic_blocks_documented_divergence(lib):
     """T = u^k: identical stream except the origin pointer, which is the smallest equal row."""
     for data in (b"ab" * 450000, b"abc" * 1000, b"\x01" * 3, b"xy" * 50000):
