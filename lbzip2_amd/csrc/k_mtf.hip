@@ -42,6 +42,8 @@ struct mtf_lds {
   u8 rk[LBZ_NW][256];          /* move-to-front rank of every symbol (slot) in front of the wave's current strip */
   __attribute__((aligned(16))) u8 stage_in[LBZ_NW][MTF_CHUNK];
   __attribute__((aligned(16))) u8 stage_out[LBZ_NW][MTF_CHUNK];
+  u8 heads[LBZ_NW][MTF_CHUNK];   /* mtf_ranks: the codes of a chunk's run heads side by side, then their ranks */
+  u64 hmask[LBZ_NW][MTF_CHUNK / 64u];   /* ... and which positions of the chunk are heads, a word a strip */
 };
 
 __device__ __forceinline__ u32 zrun_digits(u32 z)          /* floor(log2(z+1)) */
@@ -105,6 +107,19 @@ __device__ __forceinline__ void mtf_ranks(const u8 *bwt, u8 *rk_out, u32 lo, u32
     wave_sync();
     const u32 left = hi - c0;
     const u32 nstrip = left >= MTF_CHUNK ? MTF_CHUNK / 64u : (left + 63u) / 64u;
+    /* RUN HEADS ONLY (round 6).  A position that repeats the symbol in front of it has rank 0 and changes nothing in the list, so
+       the chain of ranks runs over the run heads alone -- a third of the positions of a text block's BWT, a seventh of a source
+       tree's, though four strips in five hold at least one (the strip-at-a-time form did its whole work for each of those).
+       Three passes over the chunk: (1) codes, head flags (kept, a 64-bit word a strip) and the heads' codes side by side in `cb`;
+       (2) the ranks of the heads, 64 a strip, written over their codes; (3) every position takes its rank -- a head the next
+       of `cb`, anything else 0.  wiki: k_mtf 10.1 -> 7.4 ms per 10^9 bytes, Python sources 10.1 -> 7.0, real tar 7.0 -> 5.6; random
+       bytes, all heads, pay the two light passes: 14.2 -> 15.3 (profiles/r06_zz_mtf_heads2.txt).  (A variant that took the strips
+       of a chunk of nearly all heads as they stand cost eight more scalar registers: past the 80 that let two workgroups share a
+       CU.  And at amdgpu_num_sgpr(96) -- "occupancy 8" to the compiler -- the kernel computed WRONG ranks on the device, differently
+       from run to run: the 80 of the attribute below are a limit of the hardware, not a tuning.) */
+    u8 *cb = S->heads[w];
+    u64 *hmw = S->hmask[w];
+    u32 nh = 0;
     for (u32 t = 0; t < nstrip; t++) {
       const u32 p = c0 + 64u * t + lane;
       const bool ok = p < hi;
@@ -113,10 +128,16 @@ __device__ __forceinline__ void mtf_ranks(const u8 *bwt, u8 *rk_out, u32 lo, u32
       if (lane == 0u) cprev = carry;
       carry = __builtin_amdgcn_readlane(c, 63);
       const bool head = ok && c != cprev;
-      if (__ballot(head) == 0ull) {                                /* the strip continues one run: its symbol is at the front already */
-        outb[64u * t + lane] = 0;
-        continue;
-      }
+      const u64 hm = __ballot(head);
+      if (lane == 0u) hmw[t] = hm;
+      if (head) cb[nh + (u32)__popcll(hm & below)] = (u8)c;
+      nh += (u32)__popcll(hm);
+    }
+    wave_sync();
+    const u32 nwork = (nh + 63u) / 64u;
+    for (u32 t = 0; t < nwork; t++) {
+      const bool ok = 64u * t + lane < nh, head = ok;
+      const int c = ok ? (int)cb[64u * t + lane] : 0;
       const u64 okm = __ballot(ok);
       /* lanes with my symbol; the nearest one below me */
       const u64 mm = match_digit((u32)c, ok);                      /* (ballots: every lane takes part) */
@@ -141,7 +162,8 @@ __device__ __forceinline__ void mtf_ranks(const u8 *bwt, u8 *rk_out, u32 lo, u32
         const u64 lowbits = (r0 >> 6) > (u32)q ? ~0ull : ((r0 >> 6) == (u32)q ? (1ull << (r0 & 63u)) - 1ull : 0ull);
         B -= (u32)__popcll(seen & lowbits);
       }
-      outb[64u * t + lane] = (u8)(head ? A + (first ? B : 0u) : 0u);
+      const u32 myrank = head ? A + (first ? B : 0u) : 0u;
+      if (ok) cb[64u * t + lane] = (u8)myrank;                     /* (every lane of the strip has read its code by now) */
       /* the list behind the strip */
       wave_sync();
       u32 above[NQ];                                               /* strip symbols with ranks in the words above word q */
@@ -165,6 +187,16 @@ __device__ __forceinline__ void mtf_ranks(const u8 *bwt, u8 *rk_out, u32 lo, u32
       const u64 alive_end = okm & ~kall;                           /* last occurrence of every strip symbol */
       if (ok && ((alive_end >> lane) & 1ull)) rk[c] = (u8)__popcll(alive_end & ~((2ull << lane) - 1ull));
       wave_sync();
+    }
+    wave_sync();
+    {                                                             /* (3) the ranks back to their positions */
+      u32 base = 0;
+      for (u32 t = 0; t < nstrip; t++) {
+        const u64 hm = hmw[t];
+        const u32 r = ((hm >> lane) & 1ull) ? (u32)cb[base + (u32)__popcll(hm & below)] : 0u;
+        outb[64u * t + lane] = (u8)r;
+        base += (u32)__popcll(hm);
+      }
     }
     wave_sync();
     if (q0 + 16u <= hi) *reinterpret_cast<uint4 *>(rk_out + q0) = *reinterpret_cast<const uint4 *>(outb + 16u * lane);
@@ -353,7 +385,7 @@ __device__ __forceinline__ void mtf_zrle_stage(const u8 *rk, u16 *mtfv, u32 *fre
 }
 
 /* two workgroups per CU: the SGPR file admits 8 waves per SIMD only at <= 80 SGPRs per wave */
-__global__ void __launch_bounds__(LBZ_WG) __attribute__((amdgpu_num_sgpr(80)))
+__global__ void __launch_bounds__(LBZ_WG, 2) __attribute__((amdgpu_num_sgpr(80)))   /* (two a CU: 64 vector registers) */
 k_mtf(const u8 *Bbase, u8 *Rbase, u16 *Vbase, u32 *freq_out, lbz_block_meta *meta, lbz_layout L, u32 first, u32 count, const u32 *slabs)
 {
   __shared__ mtf_lds S;
