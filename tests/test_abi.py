@@ -62,7 +62,9 @@ def test_no_device_fails_loudly(lib):
 
 def test_kernels_contain_no_device_function_calls():
     """Every gfx950 code object of the product library is free of s_swappc: the sorter's out-of-line functions once made a
-    build that sorted wrongly on the device only (k_bwt.hip, note at lds_radix_sort; csrc/check_no_calls.sh)."""
+    build that sorted wrongly on the device only (k_bwt.hip, note at lds_radix_sort; csrc/check_no_calls.sh).  The same script
+    refuses a 1024-thread kernel built for two workgroups a CU (<= 64 vector registers) with more than 80 scalar registers:
+    k_mtf at 86 computed wrong ranks on the device (round 6)."""
     import subprocess
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([os.path.join(root, "lbzip2_amd", "csrc", "check_no_calls.sh")], capture_output=True, text=True)
