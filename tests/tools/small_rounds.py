@@ -3,6 +3,7 @@ library's tuning knobs from the environment.  usage: small_rounds.py "K=V,K=V;..
 import os, sys, time
 sys.path.insert(0, "/root/repo"); sys.path.insert(0, "/root/repo/tests"); sys.path.insert(0, "/root/repo/tests/tools")
 import torch, lbzip2_amd, inputs
+if os.environ.get("LBZ_LIB"): lbzip2_amd.LIB_PATH = os.environ["LBZ_LIB"]
 lib = lbzip2_amd.library()
 settings = sys.argv[1].split(";") if len(sys.argv) > 1 else [""]
 kind = sys.argv[2] if len(sys.argv) > 2 else "wiki"
